@@ -1,0 +1,187 @@
+/*
+ * mckpp_hip.h - C-ABI of the MI355X (gfx950) column-physics library.
+ *
+ * This is the drop-in boundary for MC-KPP's per-column physics step.  The
+ * reference (aosprey/mckpp-f90) has no FFI seam of its own: the seam is the
+ * Fortran call surface
+ *     CALL mckpp_physics_driver()          src/mckpp_physics_driver_mod.F90:15
+ *       -> mckpp_physics_ocnstep(kpp_1d_fields, kpp_const_fields)
+ *                                          src/mckpp_physics_ocnstep_mod.F90:43
+ *       -> mckpp_physics_overrides_check_profile   src/mckpp_physics_overrides.F90:42
+ *     CALL mckpp_initialize_ocean_model()  src/mckpp_initialize_ocean.F90:18
+ * operating on the module globals kpp_3d_fields / kpp_const_fields
+ * (src/mckpp_data_fields.F90:348-349).  The entry points below are what an
+ * iso_c_binding module in that code base binds (see INTEGRATION.md and
+ * mckpp_f90_amd/fortran/mckpp_hip_binding.F90): plain pointers into the
+ * Fortran-owned ALLOCATABLE components, plain sizes, int return codes.
+ *
+ * Conventions
+ *  - every array pointer addresses a Fortran array in its native layout
+ *    (column index `ipt` fastest), fp64 / int32 / 4-byte LOGICAL;
+ *  - the library never frees or keeps host pointers beyond the call;
+ *  - column state is device-resident between mckpp_hip_upload and
+ *    mckpp_hip_download;
+ *  - all functions return 0 on success, <0 on error (text from
+ *    mckpp_hip_last_error()).  Numerical conditions never abort: they are
+ *    reported per column through the status bitmask.
+ *  - not re-entrant; call from one host thread per handle.
+ */
+#ifndef MCKPP_HIP_H
+#define MCKPP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCKPP_NI 890 /* wmt/wst first extent  = NI+2 (src/mckpp_physics_lookup_mod.F90:20) */
+#define MCKPP_NJ 48  /* wmt/wst second extent = NJ+2 (:21) */
+
+/* per-column status bits (replace the reference's stderr warnings / STOP) */
+#define MCKPP_ST_ZERO_PIVOT   1  /* src/mckpp_physics_solvers.F90:140-151 (reference STOPs) */
+#define MCKPP_ST_LONG_ITER    2  /* src/mckpp_physics_ocnstep_mod.F90:184-191 */
+#define MCKPP_ST_RETRIED      4  /* :200-227 instability trap fired at least once */
+#define MCKPP_ST_FAILED       8  /* :229-236 ten retries exhausted */
+#define MCKPP_ST_DODGY_OLDNEW 16 /* :93-102 */
+
+/* kpp_const_type, hot-path subset (src/mckpp_data_fields.F90:187-346) plus
+ * the mckpp_parameters integers the path reads (src/mckpp_parameters.F90). */
+typedef struct mckpp_const_c {
+  int32_t nz;        /* layers; nzp1 = nz+1 grid points               */
+  int32_t nztmax;    /* >= nzp1 (sizes difm/difs/dift/wU/wX/wXNT/ghat) */
+  int32_t nsflxs;    /* first flux extent of sflux (9)                */
+  int32_t njdt;      /* sflux(npts,nsflxs,5,0:njdt)                   */
+  int32_t itermax;   /* 200                                           */
+  int32_t LKPP, LRI, LDD, L_SSref;
+  int32_t L_RELAX_SST, L_RELAX_CALCONLY, L_FCORR, L_FCORR_WITHZ;
+  int32_t L_SFCORR, L_SFCORR_WITHZ, L_RELAX_SAL, L_RELAX_OCNT;
+  int32_t L_NO_FREEZE, L_NO_ISOTHERM, L_DAMP_CURR;
+  int32_t clim_present; /* ocnT_file/='none' .and. sal_file/='none'   */
+  int32_t iso_bot, dt_uvdamp;
+  double hmixtolfrac, dto, grav, vonk, sice, iso_thresh;
+  const double *zm;  /* zm(nzp1)                                      */
+  const double *hm;  /* hm(nzp1)                                      */
+  const double *dm;  /* dm(0:nz)                                      */
+  const double *tri; /* tri(0:nztmax,0:1,ngrid): only (:,:,1) is read  */
+  const double *wmt; /* wmt(0:891,0:49)                               */
+  const double *wst; /* wst(0:891,0:49)                               */
+} mckpp_const_c;
+
+/* Pointers into kpp_3d_type components (src/mckpp_data_fields.F90:8-101,
+ * extents :353-447).  A NULL pointer means "field not exchanged". */
+typedef struct mckpp_state_ptrs_c {
+  int64_t npts;
+  /* prognostic and saved profiles */
+  double *U;       /* U(npts,nzp1,nvel)            */
+  double *X;       /* X(npts,nzp1,nsclr)           */
+  double *Us;      /* Us(npts,nzp1,nvel,0:1)       */
+  double *Xs;      /* Xs(npts,nzp1,nsclr,0:1)      */
+  double *U_init;  /* U_init(npts,nzp1,nvel)       */
+  double *hmixd;   /* hmixd(npts,0:1)              */
+  /* per-column scalars (npts) */
+  double *f, *ocdepth, *Sref, *SSref, *Ssurf;
+  double *hmix, *kmix, *Tref, *uref, *vref;
+  double *reset_flag, *dampu_flag, *dampv_flag, *freeze_flag;
+  double *sflux;   /* sflux(npts,nsflxs,5,0:njdt); (:,1:6,5,0) is read */
+  int32_t *old, *new_, *jerlov;
+  int32_t *l_ocean, *l_initflag, *run_physics; /* 4-byte LOGICAL       */
+  /* diagnostics of the last vmix/ocnint pass of the step */
+  double *rho, *cp;           /* (npts,0:nzp1tmax)                     */
+  double *buoy;               /* (npts,nzp1tmax)                       */
+  double *difm, *difs, *dift; /* (npts,0:nztmax)                       */
+  double *wU;                 /* (npts,0:nztmax,nvp1)                  */
+  double *wX;                 /* (npts,0:nztmax,nsp1)                  */
+  double *wXNT;               /* (npts,0:nztmax,nsclr)                 */
+  double *ghat;               /* (npts,nztmax)                         */
+  double *Rig, *Shsq;         /* (npts,nzp1)                           */
+  double *dbloc;              /* (npts,nz)                             */
+  double *swfrac;             /* (npts,nzp1)                           */
+  double *swdk_opt;           /* (npts,0:nz)                           */
+} mckpp_state_ptrs_c;
+
+/* field_mask bits for mckpp_hip_download */
+#define MCKPP_F_PROFILES 1u /* U, X                                         */
+#define MCKPP_F_SAVED    2u /* Us, Xs, hmixd, old, new                      */
+#define MCKPP_F_SCALARS  4u /* hmix,kmix,Tref,uref,vref,Ssurf,*_flag        */
+#define MCKPP_F_DIAG     8u /* rho..swdk_opt (needs diagnostics enabled)    */
+#define MCKPP_F_RESTART  (MCKPP_F_PROFILES | MCKPP_F_SAVED | MCKPP_F_SCALARS)
+#define MCKPP_F_ALL      0xFu
+
+typedef struct mckpp_hip_ctx *mckpp_hip_handle;
+
+const char *mckpp_hip_last_error(void);
+
+/* Number of visible gfx950 devices (<0 on error). */
+int mckpp_hip_device_count(void);
+
+/* Create a context on HIP device `device`; copies grid, tri and the lookup
+ * tables to the device.  Replaces nothing in the reference: it is the
+ * device-side mirror of kpp_const_fields after mckpp_initialize_namelist /
+ * mckpp_physics_lookup / the tri() set-up of initialize_ocean.F90:34-43. */
+int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out);
+int mckpp_hip_finalize(mckpp_hip_handle h);
+
+/* Host helpers with no device work (so a caller written in C can build
+ * kpp_const_fields): mckpp_physics_lookup (src/mckpp_physics_lookup_mod.F90:11)
+ * and the tri() factors (src/mckpp_initialize_ocean.F90:34-43). */
+void mckpp_host_lookup(double vonk, double *wmt, double *wst);
+void mckpp_host_tri(int32_t nz, int32_t nztmax, double dto, const double *zm,
+                    const double *hm, double *tri);
+
+/* 3D -> device: compacts run_physics columns, re-lays column-fastest Fortran
+ * arrays into level-fastest padded rows.  Replaces the gather half of
+ * mckpp_fields_3dto1d (src/mckpp_types_transfer.F90:15-193), once instead of
+ * every step. */
+int mckpp_hip_upload(mckpp_hip_handle h, const mckpp_state_ptrs_c *s);
+
+/* New surface forcing: sflux(:,1:6,5,0) as written by mckpp_fluxes
+ * (src/mckpp_fluxes_mod.F90:62-69).  `sflux` is the full Fortran array. */
+int mckpp_hip_set_forcing(mckpp_hip_handle h, const double *sflux);
+
+/* Enable/disable writing of the MCKPP_F_DIAG fields by step/init (default on). */
+int mckpp_hip_set_diagnostics(mckpp_hip_handle h, int on);
+
+/* mckpp_initialize_ocean_model's per-column part
+ * (src/mckpp_initialize_ocean.F90:48-107): initial vmix with l_initflag,
+ * hmix/kmix, initial diagnostic fluxes, old/new/Us/Xs/hmixd seeds. */
+int mckpp_hip_init_ocean(mckpp_hip_handle h, int ntime);
+
+/* mckpp_physics_driver (src/mckpp_physics_driver_mod.F90:15-73): nsteps calls,
+ * step i run with ntime+i.  Asynchronous on the context's stream. */
+int mckpp_hip_step(mckpp_hip_handle h, int ntime, int nsteps);
+
+/* One vmix + ocnint pass per column with Uo=U, Xo=X ("kppmix + tridiag
+ * only"): mckpp_physics_verticalmixing (src/mckpp_physics_verticalmixing_mod.F90:14)
+ * followed by mckpp_physics_ocnint (src/mckpp_physics_ocnint_mod.F90:19). */
+int mckpp_hip_vmix_pass(mckpp_hip_handle h, int ntime);
+
+int mckpp_hip_synchronize(mckpp_hip_handle h);
+
+/* device -> 3D: scatter half of mckpp_fields_1dto3d
+ * (src/mckpp_types_transfer.F90:199-327) for the fields selected. */
+int mckpp_hip_download(mckpp_hip_handle h, mckpp_state_ptrs_c *s, uint32_t field_mask);
+
+/* Per-column status words (npts entries in 3D ordering; land = 0), number of
+ * columns with a non-zero word, and (optional) vmix+ocnint passes per column
+ * of the last step. Any output pointer may be NULL. */
+int mckpp_hip_status(mckpp_hip_handle h, int32_t *per_col, int64_t *n_flagged,
+                     int32_t *npasses);
+
+/* Timing of the most recent step/init/vmix_pass launches on the context's
+ * stream, from HIP events recorded around the kernel: total ms and launches. */
+int mckpp_hip_last_kernel_ms(mckpp_hip_handle h, double *ms, int32_t *nlaunch);
+
+/* Number of device-resident (run_physics) columns. */
+int64_t mckpp_hip_ncolumns(mckpp_hip_handle h);
+
+/* Kernel-level batch entry points on caller-provided host arrays (tests). */
+int mckpp_hip_eos_batch(mckpp_hip_handle h, int64_t n, const double *s,
+                        const double *t, const double *p, double *alpha,
+                        double *beta, double *sig0, double *cp);
+int mckpp_hip_exp_batch(mckpp_hip_handle h, int64_t n, const double *x, double *y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

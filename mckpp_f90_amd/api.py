@@ -1,0 +1,340 @@
+"""Host-side mirror of the reference's call surface over the C-ABI.
+
+Names follow the reference so a parity test reads like the reference's own
+driver (src/mckpp_ocean_model_3D.F90:23-58):
+
+    kpp_const_fields = KppConstFields(nz=60)            # mckpp_initialize_namelist + geography
+    mckpp_physics_lookup(kpp_const_fields)              # src/mckpp_physics_lookup_mod.F90:11
+    kpp_3d_fields = Kpp3dFields(npts, kpp_const_fields) # mckpp_allocate_3d_fields
+    ... fill U, X, f, Sref, sflux ...
+    mckpp_initialize_ocean_model(kpp_3d_fields, kpp_const_fields)   # src/mckpp_initialize_ocean.F90:18
+    mckpp_physics_driver(kpp_3d_fields, kpp_const_fields, ntime)    # src/mckpp_physics_driver_mod.F90:15
+
+Arrays are numpy arrays in Fortran order with the reference's shapes
+(src/mckpp_data_fields.F90:353-447), so `U[ipt, k-1, l-1]` is the reference's
+`U(ipt,k,l)`; arrays with a 0 lower bound (rho, cp, difm, wU, ...) are indexed
+with the reference index directly.  All compute happens in libmckpp_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+NI, NJ = 890, 48
+
+F_PROFILES, F_SAVED, F_SCALARS, F_DIAG = 1, 2, 4, 8
+F_RESTART = F_PROFILES | F_SAVED | F_SCALARS
+F_ALL = 0xF
+
+ST_ZERO_PIVOT, ST_LONG_ITER, ST_RETRIED, ST_FAILED, ST_DODGY = 1, 2, 4, 8, 16
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+_SWITCHES = [
+    "LKPP", "LRI", "LDD", "L_SSref", "L_RELAX_SST", "L_RELAX_CALCONLY", "L_FCORR", "L_FCORR_WITHZ",
+    "L_SFCORR", "L_SFCORR_WITHZ", "L_RELAX_SAL", "L_RELAX_OCNT", "L_NO_FREEZE", "L_NO_ISOTHERM",
+    "L_DAMP_CURR", "clim_present",
+]
+
+
+class _ConstC(C.Structure):
+    _fields_ = (
+        [(n, C.c_int32) for n in ("nz", "nztmax", "nsflxs", "njdt", "itermax")]
+        + [(n, C.c_int32) for n in _SWITCHES]
+        + [("iso_bot", C.c_int32), ("dt_uvdamp", C.c_int32)]
+        + [(n, C.c_double) for n in ("hmixtolfrac", "dto", "grav", "vonk", "sice", "iso_thresh")]
+        + [(n, _dp) for n in ("zm", "hm", "dm", "tri", "wmt", "wst")]
+    )
+
+
+_STATE_D = [
+    "U", "X", "Us", "Xs", "U_init", "hmixd", "f", "ocdepth", "Sref", "SSref", "Ssurf", "hmix", "kmix",
+    "Tref", "uref", "vref", "reset_flag", "dampu_flag", "dampv_flag", "freeze_flag", "sflux",
+]
+_STATE_I = ["old", "new_", "jerlov", "l_ocean", "l_initflag", "run_physics"]
+_STATE_DIAG = [
+    "rho", "cp", "buoy", "difm", "difs", "dift", "wU", "wX", "wXNT", "ghat", "Rig", "Shsq", "dbloc",
+    "swfrac", "swdk_opt",
+]
+
+
+class _StateC(C.Structure):
+    _fields_ = (
+        [("npts", C.c_int64)]
+        + [(n, _dp) for n in _STATE_D]
+        + [(n, _ip) for n in _STATE_I]
+        + [(n, _dp) for n in _STATE_DIAG]
+    )
+
+
+class MckppHipError(RuntimeError):
+    pass
+
+
+def _bind(lib):
+    if getattr(lib, "_mckpp_bound", False):
+        return lib
+    lib.mckpp_hip_last_error.restype = C.c_char_p
+    lib.mckpp_hip_device_count.restype = C.c_int
+    lib.mckpp_hip_init.argtypes = [C.POINTER(_ConstC), C.c_int, C.POINTER(C.c_void_p)]
+    lib.mckpp_hip_finalize.argtypes = [C.c_void_p]
+    lib.mckpp_host_lookup.argtypes = [C.c_double, _dp, _dp]
+    lib.mckpp_host_lookup.restype = None
+    lib.mckpp_host_tri.argtypes = [C.c_int32, C.c_int32, C.c_double, _dp, _dp, _dp]
+    lib.mckpp_host_tri.restype = None
+    lib.mckpp_hip_upload.argtypes = [C.c_void_p, C.POINTER(_StateC)]
+    lib.mckpp_hip_set_forcing.argtypes = [C.c_void_p, _dp]
+    lib.mckpp_hip_set_diagnostics.argtypes = [C.c_void_p, C.c_int]
+    lib.mckpp_hip_init_ocean.argtypes = [C.c_void_p, C.c_int]
+    lib.mckpp_hip_step.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.mckpp_hip_vmix_pass.argtypes = [C.c_void_p, C.c_int]
+    lib.mckpp_hip_synchronize.argtypes = [C.c_void_p]
+    lib.mckpp_hip_download.argtypes = [C.c_void_p, C.POINTER(_StateC), C.c_uint32]
+    lib.mckpp_hip_status.argtypes = [C.c_void_p, _ip, C.POINTER(C.c_int64), _ip]
+    lib.mckpp_hip_last_kernel_ms.argtypes = [C.c_void_p, _dp, _ip]
+    lib.mckpp_hip_ncolumns.argtypes = [C.c_void_p]
+    lib.mckpp_hip_ncolumns.restype = C.c_int64
+    lib.mckpp_hip_eos_batch.argtypes = [C.c_void_p, C.c_int64] + [_dp] * 7
+    lib.mckpp_hip_exp_batch.argtypes = [C.c_void_p, C.c_int64, _dp, _dp]
+    lib._mckpp_bound = True
+    return lib
+
+
+def _lib():
+    from . import load_library
+
+    return _bind(load_library())
+
+
+def _chk(rc):
+    if rc != 0:
+        raise MckppHipError(_lib().mckpp_hip_last_error().decode())
+
+
+def _f(shape):
+    return np.zeros(shape, dtype=np.float64, order="F")
+
+
+class KppConstFields:
+    """kpp_const_type, hot-path subset (src/mckpp_data_fields.F90:187-346), with the
+    defaults of mckpp_initialize_namelist (src/mckpp_initialize_namelist_mod.F90:27-119)
+    and the uniform/stretched grid of mckpp_initialize_geography
+    (src/mckpp_initialize_geography_mod.F90:45-74)."""
+
+    def __init__(self, nz, nztmax=None, dto=3600.0, dmax=200.0, zm=None, hm=None, dm=None):
+        from . import synth
+
+        self.nz, self.nzp1 = nz, nz + 1
+        self.nztmax = nztmax if nztmax is not None else nz + 1
+        self.nsflxs, self.njdt, self.itermax = 9, 1, 200
+        self.hmixtolfrac = 0.1
+        self.dto = float(dto)
+        self.grav, self.vonk, self.sice = 9.816, 0.4, 4.0
+        self.iso_bot, self.iso_thresh, self.dt_uvdamp = 2, 0.002, 360
+        for s in _SWITCHES:
+            setattr(self, s, 0)
+        self.LKPP = self.LRI = self.L_SSref = 1
+        if zm is None:
+            z, h, d = synth.uniform_grid(nz, dmax)
+            zm, hm, dm = z[1:nz + 2], h[1:nz + 2], d
+        self.zm = np.ascontiguousarray(zm, dtype=np.float64)      # zm(1:nzp1)
+        self.hm = np.ascontiguousarray(hm, dtype=np.float64)      # hm(1:nzp1)
+        self.dm = np.ascontiguousarray(dm, dtype=np.float64)      # dm(0:nz)
+        assert self.zm.shape == (nz + 1,) and self.hm.shape == (nz + 1,) and self.dm.shape == (nz + 1,)
+        self.wmt = _f((NI + 2, NJ + 2))                           # wmt(0:891,0:49)
+        self.wst = _f((NI + 2, NJ + 2))
+        self.tri = _f((self.nztmax + 1, 2, 1))                    # tri(0:nztmax,0:1,ngrid)
+        _lib().mckpp_host_tri(nz, self.nztmax, self.dto, self.zm.ctypes.data_as(_dp),
+                              self.hm.ctypes.data_as(_dp), self.tri.ctypes.data_as(_dp))
+
+    def as_c(self):
+        c = _ConstC()
+        for n in ("nz", "nztmax", "nsflxs", "njdt", "itermax", "iso_bot", "dt_uvdamp"):
+            setattr(c, n, int(getattr(self, n)))
+        for n in _SWITCHES:
+            setattr(c, n, int(getattr(self, n)))
+        for n in ("hmixtolfrac", "dto", "grav", "vonk", "sice", "iso_thresh"):
+            setattr(c, n, float(getattr(self, n)))
+        for n in ("zm", "hm", "dm", "tri", "wmt", "wst"):
+            setattr(c, n, getattr(self, n).ctypes.data_as(_dp))
+        return c
+
+
+def mckpp_physics_lookup(kpp_const_fields):
+    """src/mckpp_physics_lookup_mod.F90:11 - fill wmt, wst."""
+    _lib().mckpp_host_lookup(kpp_const_fields.vonk, kpp_const_fields.wmt.ctypes.data_as(_dp),
+                             kpp_const_fields.wst.ctypes.data_as(_dp))
+
+
+class Kpp3dFields:
+    """kpp_3d_type, hot-path subset, allocated like mckpp_allocate_3d_fields
+    (src/mckpp_data_fields.F90:353-447)."""
+
+    def __init__(self, npts, c):
+        nz, nzp1, nzt = c.nz, c.nzp1, c.nztmax
+        self.npts = npts
+        self.U = _f((npts, nzp1, 2))
+        self.X = _f((npts, nzp1, 2))
+        self.Us = _f((npts, nzp1, 2, 2))
+        self.Xs = _f((npts, nzp1, 2, 2))
+        self.U_init = _f((npts, nzp1, 2))
+        self.hmixd = _f((npts, 2))
+        for n in ("f", "ocdepth", "Sref", "SSref", "Ssurf", "hmix", "kmix", "Tref", "uref", "vref",
+                  "reset_flag", "dampu_flag", "dampv_flag", "freeze_flag"):
+            setattr(self, n, _f((npts,)))
+        self.ocdepth[:] = -10000.0
+        self.sflux = _f((npts, c.nsflxs, 5, c.njdt + 1))
+        self.old = np.zeros(npts, dtype=np.int32)
+        self.new_ = np.ones(npts, dtype=np.int32)
+        self.jerlov = np.full(npts, 3, dtype=np.int32)
+        self.l_ocean = np.ones(npts, dtype=np.int32)
+        self.l_initflag = np.zeros(npts, dtype=np.int32)
+        self.run_physics = np.ones(npts, dtype=np.int32)
+        self.rho = _f((npts, nzt + 2))
+        self.cp = _f((npts, nzt + 2))
+        self.buoy = _f((npts, nzt + 1))
+        self.difm = _f((npts, nzt + 1))
+        self.difs = _f((npts, nzt + 1))
+        self.dift = _f((npts, nzt + 1))
+        self.wU = _f((npts, nzt + 1, 3))
+        self.wX = _f((npts, nzt + 1, 3))
+        self.wXNT = _f((npts, nzt + 1, 2))
+        self.ghat = _f((npts, nzt))
+        self.Rig = _f((npts, nzp1))
+        self.Shsq = _f((npts, nzp1))
+        self.dbloc = _f((npts, nz))
+        self.swfrac = _f((npts, nzp1))
+        self.swdk_opt = _f((npts, nz + 1))
+
+    def as_c(self):
+        s = _StateC()
+        s.npts = self.npts
+        for n in _STATE_D + _STATE_DIAG:
+            a = getattr(self, n)
+            assert a.flags["F_CONTIGUOUS"] and a.dtype == np.float64, n
+            setattr(s, n, a.ctypes.data_as(_dp))
+        for n in _STATE_I:
+            a = getattr(self, n)
+            assert a.dtype == np.int32, n
+            setattr(s, n, a.ctypes.data_as(_ip))
+        return s
+
+
+class MckppHip:
+    """One device context (mckpp_hip_init ... mckpp_hip_finalize)."""
+
+    def __init__(self, kpp_const_fields, device=0):
+        self._h = C.c_void_p()
+        self._const = kpp_const_fields
+        cc = kpp_const_fields.as_c()
+        _chk(_lib().mckpp_hip_init(C.byref(cc), int(device), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            _lib().mckpp_hip_finalize(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, kpp_3d_fields):
+        s = kpp_3d_fields.as_c()
+        _chk(_lib().mckpp_hip_upload(self._h, C.byref(s)))
+        self._npts_cache = kpp_3d_fields.npts
+
+    def set_forcing(self, sflux):
+        assert sflux.flags["F_CONTIGUOUS"]
+        _chk(_lib().mckpp_hip_set_forcing(self._h, sflux.ctypes.data_as(_dp)))
+
+    def set_diagnostics(self, on):
+        _chk(_lib().mckpp_hip_set_diagnostics(self._h, int(on)))
+
+    def init_ocean(self, ntime=0):
+        _chk(_lib().mckpp_hip_init_ocean(self._h, int(ntime)))
+
+    def step(self, ntime, nsteps=1):
+        _chk(_lib().mckpp_hip_step(self._h, int(ntime), int(nsteps)))
+
+    def vmix_pass(self, ntime):
+        _chk(_lib().mckpp_hip_vmix_pass(self._h, int(ntime)))
+
+    def synchronize(self):
+        _chk(_lib().mckpp_hip_synchronize(self._h))
+
+    def download(self, kpp_3d_fields, mask=F_ALL):
+        s = kpp_3d_fields.as_c()
+        _chk(_lib().mckpp_hip_download(self._h, C.byref(s), int(mask)))
+
+    def status(self):
+        n = self._npts()
+        st = np.zeros(n, dtype=np.int32)
+        npass = np.zeros(n, dtype=np.int32)
+        nf = C.c_int64(0)
+        _chk(_lib().mckpp_hip_status(self._h, st.ctypes.data_as(_ip), C.byref(nf), npass.ctypes.data_as(_ip)))
+        return st, int(nf.value), npass
+
+    def _npts(self):
+        return self._npts_cache
+
+    def last_kernel_ms(self):
+        ms = C.c_double(0)
+        nl = C.c_int32(0)
+        _chk(_lib().mckpp_hip_last_kernel_ms(self._h, C.byref(ms), C.byref(nl)))
+        return ms.value, nl.value
+
+    @property
+    def ncolumns(self):
+        return int(_lib().mckpp_hip_ncolumns(self._h))
+
+    def eos_batch(self, s, t, p):
+        n = len(s)
+        out = [np.zeros(n) for _ in range(4)]
+        _chk(_lib().mckpp_hip_eos_batch(self._h, n, *[np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(_dp) for a in (s, t, p)],
+                                        *[o.ctypes.data_as(_dp) for o in out]))
+        return out
+
+    def exp_batch(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros_like(x)
+        _chk(_lib().mckpp_hip_exp_batch(self._h, len(x), x.ctypes.data_as(_dp), y.ctypes.data_as(_dp)))
+        return y
+
+
+# ---------------------------------------------------------------------------
+# The reference's call surface.  The reference operates on module globals; the
+# Python mirror passes them explicitly and keeps the device context on the
+# const-fields object (one context per kpp_const_fields, created on first use).
+# ---------------------------------------------------------------------------
+def _ctx(kpp_3d_fields, kpp_const_fields, device=0):
+    ctx = getattr(kpp_const_fields, "_hip_ctx", None)
+    if ctx is None:
+        ctx = MckppHip(kpp_const_fields, device)
+        kpp_const_fields._hip_ctx = ctx
+        ctx._resident = None
+    if ctx._resident is not kpp_3d_fields:
+        ctx.upload(kpp_3d_fields)
+        ctx._resident = kpp_3d_fields
+    return ctx
+
+
+def mckpp_initialize_ocean_model(kpp_3d_fields, kpp_const_fields, ntime=0, device=0, download=True):
+    """src/mckpp_initialize_ocean.F90:18 (tri() is already set by KppConstFields)."""
+    ctx = _ctx(kpp_3d_fields, kpp_const_fields, device)
+    ctx.init_ocean(ntime)
+    if download:
+        ctx.download(kpp_3d_fields, F_ALL)
+    return ctx
+
+
+def mckpp_physics_driver(kpp_3d_fields, kpp_const_fields, ntime, device=0, download=True, new_forcing=True):
+    """src/mckpp_physics_driver_mod.F90:15 - one ocnstep + check_profile per run_physics column."""
+    ctx = _ctx(kpp_3d_fields, kpp_const_fields, device)
+    if new_forcing:
+        ctx.set_forcing(kpp_3d_fields.sflux)
+    ctx.step(ntime, 1)
+    if download:
+        ctx.download(kpp_3d_fields, F_ALL)
+    return ctx

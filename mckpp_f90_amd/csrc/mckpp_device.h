@@ -1,0 +1,67 @@
+// mckpp_device.h - shared between the HIP kernels and the host runtime.
+//
+// Device-resident layout (see DESIGN.md "Data layout in HBM"):
+//   level arrays   double[ncol][ld]     ld = 64*LPL, level-fastest, one row
+//                                        per water column (512 B at nz<=61)
+//     profiles (U,V,T,S,Us*,Xs*,U_init)  element j  <-> reference level k=j+1
+//     diagnostics (rho,cp,dif*,wU,wX...) element k  <-> reference index k
+//   column record  double cs[ncol][MCKPP_CS]   (scalars in/out, in place)
+//                  int    ci[ncol][MCKPP_CI]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MCKPP_CS 24
+#define MCKPP_CI 8
+
+// cs[] slots
+enum {
+  CS_F = 0, CS_SSURF, CS_SREF, CS_SSREF, CS_OCDEPTH,
+  CS_SFLUX1, CS_SFLUX2, CS_SFLUX3, CS_SFLUX4, CS_SFLUX5, CS_SFLUX6,
+  CS_HMIXD0, CS_HMIXD1, CS_HMIX, CS_KMIX, CS_UREF, CS_VREF, CS_TREF,
+  CS_RESET, CS_DAMPU, CS_DAMPV, CS_FREEZE, CS_SPARE0, CS_SPARE1
+};
+// ci[] slots
+enum { CI_OLD = 0, CI_NEW, CI_JERLOV, CI_INITFLAG, CI_STATUS, CI_NPASS, CI_LOCEAN, CI_IPT };
+
+enum { MCKPP_MODE_STEP = 0, MCKPP_MODE_INIT = 1, MCKPP_MODE_PASS = 2 };
+
+struct mckpp_kparams {
+  int nz, nzp1, ncol, ld;
+  int ntime, itermax, mode, diag;
+  int L_SSref, LDD, clim_present, pad0;
+  double hmixtolfrac, dto, grav, vonk, sice;
+  double Vtc;     // bldepth_mod.F90:91, host-evaluated
+  double cg;      // blmix_mod.F90:62, host-evaluated (libm pow)
+  double dm_nz;   // dm(NZ)
+  // constants, device pointers; Fortran-indexed, padded to ldc doubles
+  const double *zm, *hm, *tri0, *tri1;
+  const double *swfrac_tab;  // [6][ldc]  swfrac(k), k=1..nzp1, per Jerlov type
+  const double *swdk_tab;    // [6][ldc]  swdk_opt(k), k=0..nz
+  int ldc, pad1;
+  const double2 *wtab;       // [(NJ+2)][(NI+2)] {wmt, wst}
+  // state
+  double *U, *V, *T, *S;
+  double *Us[2], *Vs[2], *Ts[2], *Ss[2];
+  const double *U_init, *V_init;
+  double *cs;
+  int *ci;
+  // diagnostics (all or none)
+  double *rho, *cp, *buoy, *talpha, *sbeta, *difm, *difs, *dift, *ghat;
+  double *wU1, *wU2, *wX1, *wX2, *wX3, *wXNT1, *Rig, *dbloc, *Shsq;
+};
+
+// launchers (mckpp_kernels.hip)
+hipError_t mckpp_launch_column_kernel(const mckpp_kparams &p, hipStream_t stream);
+size_t mckpp_column_kernel_lds_bytes(int nzp1);
+hipError_t mckpp_launch_eos_batch(int64_t n, const double *s, const double *t, const double *p,
+                                  double *alpha, double *beta, double *sig0, double *cp,
+                                  hipStream_t stream);
+hipError_t mckpp_launch_exp_batch(int64_t n, const double *x, double *y, hipStream_t stream);
+// layout kernels: Fortran (npts-fastest) <-> device rows
+hipError_t mckpp_launch_gather_rows(const double *src3d, int64_t npts, int nlev, int lev_off,
+                                    const int *ipt, int64_t ncol, double *dst, int ld, int dst_off,
+                                    hipStream_t stream);
+hipError_t mckpp_launch_scatter_rows(const double *src, int ld, int src_off, const int *ipt,
+                                     int64_t ncol, double *dst3d, int64_t npts, int nlev, int lev_off,
+                                     hipStream_t stream);

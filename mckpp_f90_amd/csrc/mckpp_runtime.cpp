@@ -1,0 +1,632 @@
+// mckpp_runtime.cpp - host side of the C-ABI declared in include/mckpp_hip.h.
+//
+// Owns the device-resident column state (level-fastest rows, one per
+// run_physics column), the device copies of kpp_const_fields, one HIP stream
+// and a pair of events per context.  No CPU fallback exists: every entry
+// point that computes does so by launching the gfx950 kernels of
+// mckpp_kernels.hip, and fails with an error code if HIP is unavailable.
+#include "../../include/mckpp_hip.h"
+#include "mckpp_device.h"
+#include "mckpp_math.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char *fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return -1;
+}
+
+#define HIPCHK(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) return fail("%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// profile rows (element j <-> level j+1)
+enum { P_U = 0, P_V, P_T, P_S, P_US0, P_US1, P_VS0, P_VS1, P_TS0, P_TS1, P_SS0, P_SS1, P_UINIT, P_VINIT, P_COUNT };
+// diagnostic rows (element k <-> reference index k)
+enum { D_RHO = 0, D_CP, D_BUOY, D_TALPHA, D_SBETA, D_DIFM, D_DIFS, D_DIFT, D_GHAT, D_WU1, D_WU2,
+       D_WX1, D_WX2, D_WX3, D_WXNT1, D_RIG, D_DBLOC, D_SHSQ, D_COUNT };
+
+const double jer_rfac[6] = {0, 0.58, 0.62, 0.67, 0.77, 0.78};
+const double jer_a1[6] = {0, 0.35, 0.6, 1.0, 1.5, 1.4};
+const double jer_a2[6] = {0, 23.0, 20.0, 17.0, 14.0, 7.9};
+
+}  // namespace
+
+struct mckpp_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  int nlaunch = 0;
+  mckpp_const_c c{};
+  int nz = 0, nzp1 = 0, lpl = 1, ld = 64, ldc = 72;
+  double Vtc = 0, cg = 0, dm_nz = 0;
+  std::vector<double> h_swfrac_tab, h_swdk_tab;
+  double *d_zm = nullptr, *d_hm = nullptr, *d_tri0 = nullptr, *d_tri1 = nullptr;
+  double *d_swfrac_tab = nullptr, *d_swdk_tab = nullptr;
+  double2 *d_wtab = nullptr;
+  // state
+  int64_t npts = 0, ncol = 0;
+  std::vector<int> ipt;
+  int *d_ipt = nullptr;
+  double *d_prof[P_COUNT] = {};
+  double *d_diag[D_COUNT] = {};
+  double *d_cs = nullptr;
+  int *d_ci = nullptr;
+  double *d_stage = nullptr;
+  size_t stage_elems = 0;
+  int diag = 1;
+};
+
+extern "C" {
+
+const char *mckpp_hip_last_error(void) { return g_err.c_str(); }
+
+int mckpp_hip_device_count(void)
+{
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail("hipGetDeviceCount: %s", hipGetErrorString(e));
+  return n;
+}
+
+// mckpp_physics_lookup, src/mckpp_physics_lookup_mod.F90:11-66 (host, libm pow).
+void mckpp_host_lookup(double vonk, double *wmt, double *wst)
+{
+  const int ni = MCKPP_NI, nj = MCKPP_NJ, n1 = ni + 2;
+  const double epsln = 1.e-20, c1 = 5.0, zmin = -4.e-7, zmax = 0.0, umin = 0.0, umax = 0.04;
+  const double am = 1.257, cm = 8.380, c2 = 16.0, zetam = -0.2, as = -28.86, cs = 98.96, c3 = 16.0,
+               zetas = -1.0;
+  const double deltaz = (zmax - zmin) / (ni + 1);
+  const double deltau = (umax - umin) / (nj + 1);
+  for (int j = 0; j <= nj + 1; ++j) {
+    const double usta = deltau * (j) + umin;
+    const double u3 = (usta * usta) * usta;
+    for (int i = 0; i <= ni + 1; ++i) {
+      const double zehat = deltaz * (i) + zmin;
+      const double zeta = zehat / (u3 + epsln);
+      double wm, ws;
+      if (zehat >= 0.) {
+        wm = vonk * usta / (1. + c1 * zeta);
+        ws = wm;
+      } else {
+        wm = (zeta > zetam) ? vonk * usta * std::pow(1. - c2 * zeta, 1. / 4.)
+                            : vonk * std::pow(am * u3 - cm * zehat, 1. / 3.);
+        ws = (zeta > zetas) ? vonk * usta * std::pow(1. - c3 * zeta, 1. / 2.)
+                            : vonk * std::pow(as * u3 - cs * zehat, 1. / 3.);
+      }
+      wmt[(size_t)j * n1 + i] = wm;
+      wst[(size_t)j * n1 + i] = ws;
+    }
+  }
+}
+
+// tri(0:nztmax,0:1,1), src/mckpp_initialize_ocean.F90:30-43.  zm, hm are zm(1:nzp1), hm(1:nzp1).
+void mckpp_host_tri(int32_t nz, int32_t nztmax, double dto, const double *zm, const double *hm, double *tri)
+{
+  const int n1 = nztmax + 1;
+  auto Z = [&](int k) { return zm[k - 1]; };
+  auto H = [&](int k) { return hm[k - 1]; };
+  double *t0 = tri, *t1 = tri + n1;
+  for (int k = 0; k < n1; ++k) { t0[k] = 0.0; t1[k] = 0.0; }
+  t1[0] = dto / H(1);
+  t1[1] = dto / H(1) / (Z(1) - Z(2));
+  for (int k = 2; k <= nz; ++k) {
+    t1[k] = dto / H(k) / (Z(k) - Z(k + 1));
+    t0[k] = dto / H(k) / (Z(k - 1) - Z(k));
+  }
+}
+
+int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
+{
+  if (!c || !out) return fail("mckpp_hip_init: null argument");
+  if (c->nz < 2) return fail("mckpp_hip_init: nz=%d (need >= 2)", c->nz);
+  if (c->nztmax < c->nz + 1) return fail("mckpp_hip_init: nztmax=%d < nzp1=%d", c->nztmax, c->nz + 1);
+  if (!c->zm || !c->hm || !c->dm || !c->tri || !c->wmt || !c->wst)
+    return fail("mckpp_hip_init: zm/hm/dm/tri/wmt/wst must all be set");
+  if (!c->LKPP || !c->LRI) return fail("mckpp_hip_init: LKPP and LRI must be .TRUE. (the device path implements the KPP scheme)");
+  if (c->LDD || c->L_RELAX_SST || c->L_FCORR || c->L_FCORR_WITHZ || c->L_SFCORR || c->L_SFCORR_WITHZ ||
+      c->L_RELAX_SAL || c->L_RELAX_OCNT || c->L_NO_FREEZE || c->L_NO_ISOTHERM || c->L_DAMP_CURR || c->clim_present)
+    return fail("mckpp_hip_init: LDD / relaxation / flux-correction / damping / freeze / isotherm / "
+                "climatology-reset switches are not implemented on the device path yet (SURVEY 8(f) N3)");
+  const int nzp1 = c->nz + 1;
+  const int lpl = (nzp1 + 2 + 63) / 64;
+  if (lpl > 3) return fail("mckpp_hip_init: nz=%d too deep (max 190 levels)", c->nz);
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail("mckpp_hip_init: device %d of %d", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail("mckpp_hip_init: device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+
+  mckpp_hip_ctx *h = new mckpp_hip_ctx();
+  h->device = device;
+  h->c = *c;
+  h->nz = c->nz;
+  h->nzp1 = nzp1;
+  h->lpl = lpl;
+  h->ld = 64 * lpl;
+  h->ldc = 64 * lpl + 8;
+  HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreate(&h->ev0));
+  HIPCHK(hipEventCreate(&h->ev1));
+
+  const int ldc = h->ldc, nz = h->nz, n1 = c->nztmax + 1;
+  std::vector<double> zm(ldc, 0.0), hm(ldc, 0.0), t0(ldc, 0.0), t1(ldc, 0.0);
+  for (int k = 1; k <= nzp1; ++k) { zm[k] = c->zm[k - 1]; hm[k] = c->hm[k - 1]; }
+  for (int k = 0; k <= nz; ++k) { t0[k] = c->tri[k]; t1[k] = c->tri[n1 + k]; }
+  h->dm_nz = c->dm[nz];
+  // Jerlov tables: swfrac_opt (swfrac_mod.F90:36-41, fact = hbf = 1) and swdk_opt (fluxes_mod.F90:104-107)
+  h->h_swfrac_tab.assign((size_t)6 * ldc, 0.0);
+  h->h_swdk_tab.assign((size_t)6 * ldc, 0.0);
+  for (int jw = 1; jw <= 5; ++jw) {
+    for (int l = 1; l <= nzp1; ++l) {
+      const double rmin = -80.;
+      double r1 = zm[l] * 1.0 / jer_a1[jw]; r1 = r1 > rmin ? r1 : rmin;
+      double r2 = zm[l] * 1.0 / jer_a2[jw]; r2 = r2 > rmin ? r2 : rmin;
+      h->h_swfrac_tab[(size_t)jw * ldc + l] = jer_rfac[jw] * mckpp_exp(r1) + (1. - jer_rfac[jw]) * mckpp_exp(r2);
+    }
+    for (int k = 0; k <= nz; ++k) {
+      const double z = -c->dm[k];
+      h->h_swdk_tab[(size_t)jw * ldc + k] =
+          jer_rfac[jw] * mckpp_exp(z / jer_a1[jw]) + (1.0 - jer_rfac[jw]) * mckpp_exp(z / jer_a2[jw]);
+    }
+  }
+  {  // bldepth_mod.F90:91 and blmix_mod.F90:62
+    const double cv = 1.6, cs = 98.96, epsilon = 0.1, Ricr = 0.30, cstar = 5.0;
+    h->Vtc = cv * std::sqrt(0.2 / cs / epsilon) / (c->vonk * c->vonk) / Ricr;
+    h->cg = cstar * c->vonk * std::pow(cs * c->vonk * epsilon, 1. / 3.);
+  }
+  const size_t nt = (size_t)(MCKPP_NI + 2) * (MCKPP_NJ + 2);
+  std::vector<double2> wtab(nt);
+  for (size_t i = 0; i < nt; ++i) wtab[i] = make_double2(c->wmt[i], c->wst[i]);
+
+  auto up = [&](double **dst, const double *src, size_t n) -> hipError_t {
+    hipError_t e = hipMalloc(dst, n * sizeof(double));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src, n * sizeof(double), hipMemcpyHostToDevice);
+  };
+  HIPCHK(up(&h->d_zm, zm.data(), ldc));
+  HIPCHK(up(&h->d_hm, hm.data(), ldc));
+  HIPCHK(up(&h->d_tri0, t0.data(), ldc));
+  HIPCHK(up(&h->d_tri1, t1.data(), ldc));
+  HIPCHK(up(&h->d_swfrac_tab, h->h_swfrac_tab.data(), (size_t)6 * ldc));
+  HIPCHK(up(&h->d_swdk_tab, h->h_swdk_tab.data(), (size_t)6 * ldc));
+  HIPCHK(hipMalloc(&h->d_wtab, nt * sizeof(double2)));
+  HIPCHK(hipMemcpy(h->d_wtab, wtab.data(), nt * sizeof(double2), hipMemcpyHostToDevice));
+  // the host pointers are not kept
+  h->c.zm = h->c.hm = h->c.dm = h->c.tri = h->c.wmt = h->c.wst = nullptr;
+  *out = h;
+  return 0;
+}
+
+static void free_state(mckpp_hip_ctx *h)
+{
+  for (auto &p : h->d_prof) { if (p) hipFree(p); p = nullptr; }
+  for (auto &p : h->d_diag) { if (p) hipFree(p); p = nullptr; }
+  if (h->d_cs) hipFree(h->d_cs);
+  if (h->d_ci) hipFree(h->d_ci);
+  if (h->d_ipt) hipFree(h->d_ipt);
+  if (h->d_stage) hipFree(h->d_stage);
+  h->d_cs = nullptr; h->d_ci = nullptr; h->d_ipt = nullptr; h->d_stage = nullptr;
+  h->stage_elems = 0;
+  h->ncol = 0; h->npts = 0;
+}
+
+int mckpp_hip_finalize(mckpp_hip_handle h)
+{
+  if (!h) return 0;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  free_state(h);
+  hipFree(h->d_zm); hipFree(h->d_hm); hipFree(h->d_tri0); hipFree(h->d_tri1);
+  hipFree(h->d_swfrac_tab); hipFree(h->d_swdk_tab); hipFree(h->d_wtab);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+int64_t mckpp_hip_ncolumns(mckpp_hip_handle h) { return h ? h->ncol : -1; }
+
+static int ensure_stage(mckpp_hip_ctx *h, size_t elems)
+{
+  if (elems <= h->stage_elems) return 0;
+  if (h->d_stage) hipFree(h->d_stage);
+  h->d_stage = nullptr;
+  h->stage_elems = 0;
+  HIPCHK(hipMalloc(&h->d_stage, elems * sizeof(double)));
+  h->stage_elems = elems;
+  return 0;
+}
+
+// host Fortran slab (npts x nlev, from `src`) -> device rows
+static int up_rows(mckpp_hip_ctx *h, const double *src, int nlev, double *dst, int dst_off)
+{
+  const size_t n = (size_t)h->npts * nlev;
+  if (ensure_stage(h, n)) return -1;
+  HIPCHK(hipMemcpyAsync(h->d_stage, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(mckpp_launch_gather_rows(h->d_stage, h->npts, nlev, 0, h->d_ipt, h->ncol, dst, h->ld, dst_off, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// device rows -> host Fortran slab; entries of non-resident (land) columns keep their host values
+static int down_rows(mckpp_hip_ctx *h, const double *src, int src_off, int nlev, double *dst)
+{
+  const size_t n = (size_t)h->npts * nlev;
+  if (ensure_stage(h, n)) return -1;
+  if (h->ncol < h->npts)
+    HIPCHK(hipMemcpyAsync(h->d_stage, dst, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(mckpp_launch_scatter_rows(src, h->ld, src_off, h->d_ipt, h->ncol, h->d_stage, h->npts, nlev, 0, h->stream));
+  HIPCHK(hipMemcpyAsync(dst, h->d_stage, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int mckpp_hip_upload(mckpp_hip_handle h, const mckpp_state_ptrs_c *s)
+{
+  if (!h || !s) return fail("mckpp_hip_upload: null argument");
+  if (s->npts <= 0) return fail("mckpp_hip_upload: npts=%lld", (long long)s->npts);
+  if (!s->U || !s->X) return fail("mckpp_hip_upload: U and X are required");
+  HIPCHK(hipSetDevice(h->device));
+  const int64_t npts = s->npts;
+  const int nzp1 = h->nzp1;
+  std::vector<int> ipt;
+  ipt.reserve(npts);
+  for (int64_t i = 0; i < npts; ++i)
+    if (!s->run_physics || s->run_physics[i]) ipt.push_back((int)i);
+  const int64_t ncol = (int64_t)ipt.size();
+  if (ncol != h->ncol || npts != h->npts) {
+    free_state(h);
+    h->npts = npts;
+    h->ncol = ncol;
+    if (ncol > 0) {
+      const size_t rowbytes = (size_t)ncol * h->ld * sizeof(double);
+      for (auto &p : h->d_prof) { HIPCHK(hipMalloc(&p, rowbytes)); HIPCHK(hipMemsetAsync(p, 0, rowbytes, h->stream)); }
+      for (auto &p : h->d_diag) { HIPCHK(hipMalloc(&p, rowbytes)); HIPCHK(hipMemsetAsync(p, 0, rowbytes, h->stream)); }
+      HIPCHK(hipMalloc(&h->d_cs, (size_t)ncol * MCKPP_CS * sizeof(double)));
+      HIPCHK(hipMalloc(&h->d_ci, (size_t)ncol * MCKPP_CI * sizeof(int)));
+      HIPCHK(hipMalloc(&h->d_ipt, (size_t)ncol * sizeof(int)));
+    }
+  }
+  h->ipt = ipt;
+  if (ncol == 0) return 0;
+  HIPCHK(hipMemcpyAsync(h->d_ipt, ipt.data(), (size_t)ncol * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  const size_t slab = (size_t)npts * nzp1;
+  if (up_rows(h, s->U, nzp1, h->d_prof[P_U], 0)) return -1;
+  if (up_rows(h, s->U + slab, nzp1, h->d_prof[P_V], 0)) return -1;
+  if (up_rows(h, s->X, nzp1, h->d_prof[P_T], 0)) return -1;
+  if (up_rows(h, s->X + slab, nzp1, h->d_prof[P_S], 0)) return -1;
+  if (s->Us) {   // Us(npts,nzp1,nvel,0:1)
+    if (up_rows(h, s->Us + 0 * slab, nzp1, h->d_prof[P_US0], 0)) return -1;
+    if (up_rows(h, s->Us + 1 * slab, nzp1, h->d_prof[P_VS0], 0)) return -1;
+    if (up_rows(h, s->Us + 2 * slab, nzp1, h->d_prof[P_US1], 0)) return -1;
+    if (up_rows(h, s->Us + 3 * slab, nzp1, h->d_prof[P_VS1], 0)) return -1;
+  }
+  if (s->Xs) {
+    if (up_rows(h, s->Xs + 0 * slab, nzp1, h->d_prof[P_TS0], 0)) return -1;
+    if (up_rows(h, s->Xs + 1 * slab, nzp1, h->d_prof[P_SS0], 0)) return -1;
+    if (up_rows(h, s->Xs + 2 * slab, nzp1, h->d_prof[P_TS1], 0)) return -1;
+    if (up_rows(h, s->Xs + 3 * slab, nzp1, h->d_prof[P_SS1], 0)) return -1;
+  }
+  if (s->U_init) {
+    if (up_rows(h, s->U_init, nzp1, h->d_prof[P_UINIT], 0)) return -1;
+    if (up_rows(h, s->U_init + slab, nzp1, h->d_prof[P_VINIT], 0)) return -1;
+  }
+  std::vector<double> cs((size_t)ncol * MCKPP_CS, 0.0);
+  std::vector<int> ci((size_t)ncol * MCKPP_CI, 0);
+  const int64_t fl_i = npts;                                        // stride of the flux index
+  const int64_t fl_5 = npts * (int64_t)h->c.nsflxs * (5 - 1);       // offset of (:,:,5,0)
+  for (int64_t c = 0; c < ncol; ++c) {
+    const int64_t i = ipt[c];
+    double *r = &cs[(size_t)c * MCKPP_CS];
+    int *q = &ci[(size_t)c * MCKPP_CI];
+    auto g = [&](const double *a, double def) { return a ? a[i] : def; };
+    r[CS_F] = g(s->f, 0.0);
+    r[CS_SSURF] = g(s->Ssurf, 0.0);
+    r[CS_SREF] = g(s->Sref, 0.0);
+    r[CS_SSREF] = g(s->SSref, 0.0);
+    r[CS_OCDEPTH] = g(s->ocdepth, -10000.0);
+    for (int m = 0; m < 6; ++m) r[CS_SFLUX1 + m] = s->sflux ? s->sflux[i + fl_i * m + fl_5] : 0.0;
+    r[CS_HMIXD0] = s->hmixd ? s->hmixd[i] : 0.0;
+    r[CS_HMIXD1] = s->hmixd ? s->hmixd[i + npts] : 0.0;
+    r[CS_HMIX] = g(s->hmix, 0.0);
+    r[CS_KMIX] = g(s->kmix, 0.0);
+    r[CS_UREF] = g(s->uref, 0.0);
+    r[CS_VREF] = g(s->vref, 0.0);
+    r[CS_TREF] = g(s->Tref, 0.0);
+    r[CS_RESET] = g(s->reset_flag, 0.0);
+    r[CS_DAMPU] = g(s->dampu_flag, 0.0);
+    r[CS_DAMPV] = g(s->dampv_flag, 0.0);
+    r[CS_FREEZE] = g(s->freeze_flag, 0.0);
+    q[CI_OLD] = s->old ? s->old[i] : 0;
+    q[CI_NEW] = s->new_ ? s->new_[i] : 1;
+    q[CI_JERLOV] = s->jerlov ? s->jerlov[i] : 3;
+    if (q[CI_JERLOV] < 1 || q[CI_JERLOV] > 5) return fail("mckpp_hip_upload: jerlov(%lld)=%d outside 1..5", (long long)i + 1, q[CI_JERLOV]);
+    q[CI_INITFLAG] = s->l_initflag ? (s->l_initflag[i] != 0) : 0;
+    q[CI_LOCEAN] = s->l_ocean ? (s->l_ocean[i] != 0) : 1;
+    q[CI_IPT] = (int)i;
+  }
+  HIPCHK(hipMemcpyAsync(h->d_cs, cs.data(), cs.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_ci, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int mckpp_hip_set_forcing(mckpp_hip_handle h, const double *sflux)
+{
+  if (!h || !sflux) return fail("mckpp_hip_set_forcing: null argument");
+  if (h->ncol == 0) return 0;
+  HIPCHK(hipSetDevice(h->device));
+  std::vector<double> f6((size_t)h->ncol * 6);
+  const int64_t fl_i = h->npts, fl_5 = h->npts * (int64_t)h->c.nsflxs * 4;
+  for (int64_t c = 0; c < h->ncol; ++c)
+    for (int m = 0; m < 6; ++m) f6[(size_t)c * 6 + m] = sflux[h->ipt[c] + fl_i * m + fl_5];
+  HIPCHK(hipMemcpy2DAsync(h->d_cs + CS_SFLUX1, MCKPP_CS * sizeof(double), f6.data(), 6 * sizeof(double),
+                          6 * sizeof(double), (size_t)h->ncol, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int mckpp_hip_set_diagnostics(mckpp_hip_handle h, int on)
+{
+  if (!h) return fail("null handle");
+  h->diag = on ? 1 : 0;
+  return 0;
+}
+
+static void fill_params(mckpp_hip_ctx *h, mckpp_kparams &p, int ntime, int mode)
+{
+  memset(&p, 0, sizeof p);
+  p.nz = h->nz; p.nzp1 = h->nzp1; p.ncol = (int)h->ncol; p.ld = h->ld;
+  p.ntime = ntime; p.itermax = h->c.itermax; p.mode = mode; p.diag = h->diag;
+  p.L_SSref = h->c.L_SSref; p.LDD = h->c.LDD; p.clim_present = h->c.clim_present;
+  p.hmixtolfrac = h->c.hmixtolfrac; p.dto = h->c.dto; p.grav = h->c.grav; p.vonk = h->c.vonk; p.sice = h->c.sice;
+  p.Vtc = h->Vtc; p.cg = h->cg; p.dm_nz = h->dm_nz;
+  p.zm = h->d_zm; p.hm = h->d_hm; p.tri0 = h->d_tri0; p.tri1 = h->d_tri1;
+  p.swfrac_tab = h->d_swfrac_tab; p.swdk_tab = h->d_swdk_tab; p.ldc = h->ldc; p.wtab = h->d_wtab;
+  p.U = h->d_prof[P_U]; p.V = h->d_prof[P_V]; p.T = h->d_prof[P_T]; p.S = h->d_prof[P_S];
+  p.Us[0] = h->d_prof[P_US0]; p.Us[1] = h->d_prof[P_US1]; p.Vs[0] = h->d_prof[P_VS0]; p.Vs[1] = h->d_prof[P_VS1];
+  p.Ts[0] = h->d_prof[P_TS0]; p.Ts[1] = h->d_prof[P_TS1]; p.Ss[0] = h->d_prof[P_SS0]; p.Ss[1] = h->d_prof[P_SS1];
+  p.U_init = h->d_prof[P_UINIT]; p.V_init = h->d_prof[P_VINIT];
+  p.cs = h->d_cs; p.ci = h->d_ci;
+  p.rho = h->d_diag[D_RHO]; p.cp = h->d_diag[D_CP]; p.buoy = h->d_diag[D_BUOY];
+  p.talpha = h->d_diag[D_TALPHA]; p.sbeta = h->d_diag[D_SBETA];
+  p.difm = h->d_diag[D_DIFM]; p.difs = h->d_diag[D_DIFS]; p.dift = h->d_diag[D_DIFT]; p.ghat = h->d_diag[D_GHAT];
+  p.wU1 = h->d_diag[D_WU1]; p.wU2 = h->d_diag[D_WU2];
+  p.wX1 = h->d_diag[D_WX1]; p.wX2 = h->d_diag[D_WX2]; p.wX3 = h->d_diag[D_WX3]; p.wXNT1 = h->d_diag[D_WXNT1];
+  p.Rig = h->d_diag[D_RIG]; p.dbloc = h->d_diag[D_DBLOC]; p.Shsq = h->d_diag[D_SHSQ];
+}
+
+static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode)
+{
+  if (!h) return fail("null handle");
+  if (h->ncol == 0) { h->nlaunch = 0; h->timed = false; return 0; }
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  for (int i = 0; i < nsteps; ++i) {
+    mckpp_kparams p;
+    fill_params(h, p, ntime + i, mode);
+    HIPCHK(mckpp_launch_column_kernel(p, h->stream));
+  }
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  h->nlaunch = nsteps;
+  h->timed = true;
+  return 0;
+}
+
+int mckpp_hip_init_ocean(mckpp_hip_handle h, int ntime) { return run(h, ntime, 1, MCKPP_MODE_INIT); }
+int mckpp_hip_step(mckpp_hip_handle h, int ntime, int nsteps)
+{
+  if (nsteps < 0) return fail("mckpp_hip_step: nsteps=%d", nsteps);
+  return run(h, ntime, nsteps, MCKPP_MODE_STEP);
+}
+int mckpp_hip_vmix_pass(mckpp_hip_handle h, int ntime) { return run(h, ntime, 1, MCKPP_MODE_PASS); }
+
+int mckpp_hip_synchronize(mckpp_hip_handle h)
+{
+  if (!h) return fail("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int mckpp_hip_last_kernel_ms(mckpp_hip_handle h, double *ms, int32_t *nlaunch)
+{
+  if (!h) return fail("null handle");
+  if (!h->timed) { if (ms) *ms = 0.0; if (nlaunch) *nlaunch = 0; return 0; }
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipEventSynchronize(h->ev1));
+  float t = 0.f;
+  HIPCHK(hipEventElapsedTime(&t, h->ev0, h->ev1));
+  if (ms) *ms = (double)t;
+  if (nlaunch) *nlaunch = h->nlaunch;
+  return 0;
+}
+
+int mckpp_hip_download(mckpp_hip_handle h, mckpp_state_ptrs_c *s, uint32_t mask)
+{
+  if (!h || !s) return fail("mckpp_hip_download: null argument");
+  if (s->npts != h->npts) return fail("mckpp_hip_download: npts=%lld but %lld were uploaded", (long long)s->npts, (long long)h->npts);
+  if (h->ncol == 0) return 0;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const int nzp1 = h->nzp1, nz = h->nz;
+  const int64_t npts = h->npts, ncol = h->ncol;
+  const size_t slab = (size_t)npts * nzp1;
+  if ((mask & MCKPP_F_PROFILES)) {
+    if (s->U) {
+      if (down_rows(h, h->d_prof[P_U], 0, nzp1, s->U)) return -1;
+      if (down_rows(h, h->d_prof[P_V], 0, nzp1, s->U + slab)) return -1;
+    }
+    if (s->X) {
+      if (down_rows(h, h->d_prof[P_T], 0, nzp1, s->X)) return -1;
+      if (down_rows(h, h->d_prof[P_S], 0, nzp1, s->X + slab)) return -1;
+    }
+  }
+  if ((mask & MCKPP_F_SAVED)) {
+    if (s->Us) {
+      if (down_rows(h, h->d_prof[P_US0], 0, nzp1, s->Us + 0 * slab)) return -1;
+      if (down_rows(h, h->d_prof[P_VS0], 0, nzp1, s->Us + 1 * slab)) return -1;
+      if (down_rows(h, h->d_prof[P_US1], 0, nzp1, s->Us + 2 * slab)) return -1;
+      if (down_rows(h, h->d_prof[P_VS1], 0, nzp1, s->Us + 3 * slab)) return -1;
+    }
+    if (s->Xs) {
+      if (down_rows(h, h->d_prof[P_TS0], 0, nzp1, s->Xs + 0 * slab)) return -1;
+      if (down_rows(h, h->d_prof[P_SS0], 0, nzp1, s->Xs + 1 * slab)) return -1;
+      if (down_rows(h, h->d_prof[P_TS1], 0, nzp1, s->Xs + 2 * slab)) return -1;
+      if (down_rows(h, h->d_prof[P_SS1], 0, nzp1, s->Xs + 3 * slab)) return -1;
+    }
+  }
+  if (mask & (MCKPP_F_SAVED | MCKPP_F_SCALARS)) {
+    std::vector<double> cs((size_t)ncol * MCKPP_CS);
+    std::vector<int> ci((size_t)ncol * MCKPP_CI);
+    HIPCHK(hipMemcpy(cs.data(), h->d_cs, cs.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ci.data(), h->d_ci, ci.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int64_t c = 0; c < ncol; ++c) {
+      const int64_t i = h->ipt[c];
+      const double *r = &cs[(size_t)c * MCKPP_CS];
+      const int *q = &ci[(size_t)c * MCKPP_CI];
+      if (mask & MCKPP_F_SAVED) {
+        if (s->hmixd) { s->hmixd[i] = r[CS_HMIXD0]; s->hmixd[i + npts] = r[CS_HMIXD1]; }
+        if (s->old) s->old[i] = q[CI_OLD];
+        if (s->new_) s->new_[i] = q[CI_NEW];
+      }
+      if (mask & MCKPP_F_SCALARS) {
+        if (s->hmix) s->hmix[i] = r[CS_HMIX];
+        if (s->kmix) s->kmix[i] = r[CS_KMIX];
+        if (s->Tref) s->Tref[i] = r[CS_TREF];
+        if (s->uref) s->uref[i] = r[CS_UREF];
+        if (s->vref) s->vref[i] = r[CS_VREF];
+        if (s->Ssurf) s->Ssurf[i] = r[CS_SSURF];
+        if (s->reset_flag) s->reset_flag[i] = r[CS_RESET];
+        if (s->dampu_flag) s->dampu_flag[i] = r[CS_DAMPU];
+        if (s->dampv_flag) s->dampv_flag[i] = r[CS_DAMPV];
+        if (s->freeze_flag) s->freeze_flag[i] = r[CS_FREEZE];
+        if (s->l_initflag) s->l_initflag[i] = q[CI_INITFLAG];
+      }
+    }
+  }
+  if ((mask & MCKPP_F_DIAG)) {
+    const int n1 = h->c.nztmax + 1;        // extent of (0:nztmax)
+    const int n2 = h->c.nztmax + 2;        // extent of (0:nzp1tmax)
+    const size_t s1 = (size_t)npts * n1;
+    if (s->rho && down_rows(h, h->d_diag[D_RHO], 0, nzp1 + 1, s->rho)) return -1;
+    if (s->cp && down_rows(h, h->d_diag[D_CP], 0, nzp1 + 1, s->cp)) return -1;
+    (void)n2;
+    if (s->buoy && down_rows(h, h->d_diag[D_BUOY], 1, nzp1, s->buoy)) return -1;
+    if (s->difm && down_rows(h, h->d_diag[D_DIFM], 0, nzp1 + 1, s->difm)) return -1;
+    if (s->difs && down_rows(h, h->d_diag[D_DIFS], 0, nzp1 + 1, s->difs)) return -1;
+    if (s->dift && down_rows(h, h->d_diag[D_DIFT], 0, nzp1 + 1, s->dift)) return -1;
+    if (s->ghat && down_rows(h, h->d_diag[D_GHAT], 1, nz, s->ghat)) return -1;
+    if (s->wU) {
+      if (down_rows(h, h->d_diag[D_WU1], 0, nz + 1, s->wU)) return -1;
+      if (down_rows(h, h->d_diag[D_WU2], 0, nz + 1, s->wU + s1)) return -1;
+    }
+    if (s->wX) {
+      if (down_rows(h, h->d_diag[D_WX1], 0, nz + 1, s->wX)) return -1;
+      if (down_rows(h, h->d_diag[D_WX2], 0, nz + 1, s->wX + s1)) return -1;
+      if (down_rows(h, h->d_diag[D_WX3], 0, nz + 1, s->wX + 2 * s1)) return -1;
+    }
+    if (s->wXNT && down_rows(h, h->d_diag[D_WXNT1], 0, nz + 1, s->wXNT)) return -1;
+    if (s->Rig && down_rows(h, h->d_diag[D_RIG], 1, nz, s->Rig)) return -1;
+    if (s->Shsq && down_rows(h, h->d_diag[D_SHSQ], 1, nz, s->Shsq)) return -1;
+    if (s->dbloc && down_rows(h, h->d_diag[D_DBLOC], 1, nz, s->dbloc)) return -1;
+    if (s->swfrac || s->swdk_opt) {
+      std::vector<int> ci((size_t)ncol * MCKPP_CI);
+      HIPCHK(hipMemcpy(ci.data(), h->d_ci, ci.size() * sizeof(int), hipMemcpyDeviceToHost));
+      for (int64_t c = 0; c < ncol; ++c) {
+        const int64_t i = h->ipt[c];
+        const int jw = ci[(size_t)c * MCKPP_CI + CI_JERLOV];
+        if (s->swfrac) for (int l = 1; l <= nzp1; ++l) s->swfrac[i + npts * (l - 1)] = h->h_swfrac_tab[(size_t)jw * h->ldc + l];
+        if (s->swdk_opt) for (int k = 0; k <= nz; ++k) s->swdk_opt[i + npts * k] = h->h_swdk_tab[(size_t)jw * h->ldc + k];
+      }
+    }
+  }
+  return 0;
+}
+
+int mckpp_hip_status(mckpp_hip_handle h, int32_t *per_col, int64_t *n_flagged, int32_t *npasses)
+{
+  if (!h) return fail("null handle");
+  if (per_col) for (int64_t i = 0; i < h->npts; ++i) per_col[i] = 0;
+  if (npasses) for (int64_t i = 0; i < h->npts; ++i) npasses[i] = 0;
+  int64_t nf = 0;
+  if (h->ncol > 0) {
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<int> ci((size_t)h->ncol * MCKPP_CI);
+    HIPCHK(hipMemcpy(ci.data(), h->d_ci, ci.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int64_t c = 0; c < h->ncol; ++c) {
+      const int st = ci[(size_t)c * MCKPP_CI + CI_STATUS];
+      if (st) ++nf;
+      if (per_col) per_col[h->ipt[c]] = st;
+      if (npasses) npasses[h->ipt[c]] = ci[(size_t)c * MCKPP_CI + CI_NPASS];
+    }
+  }
+  if (n_flagged) *n_flagged = nf;
+  return 0;
+}
+
+int mckpp_hip_eos_batch(mckpp_hip_handle h, int64_t n, const double *s, const double *t, const double *p,
+                        double *alpha, double *beta, double *sig0, double *cp)
+{
+  if (!h) return fail("null handle");
+  if (n <= 0) return 0;
+  HIPCHK(hipSetDevice(h->device));
+  double *d = nullptr;
+  const size_t nb = (size_t)n * sizeof(double);
+  HIPCHK(hipMalloc(&d, 7 * nb));
+  HIPCHK(hipMemcpy(d, s, nb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d + n, t, nb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d + 2 * n, p, nb, hipMemcpyHostToDevice));
+  hipError_t e = mckpp_launch_eos_batch(n, d, d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 5 * n, d + 6 * n, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipMemcpy(alpha, d + 3 * n, nb, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(beta, d + 4 * n, nb, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(sig0, d + 5 * n, nb, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(cp, d + 6 * n, nb, hipMemcpyDeviceToHost);
+  hipFree(d);
+  HIPCHK(e);
+  return 0;
+}
+
+int mckpp_hip_exp_batch(mckpp_hip_handle h, int64_t n, const double *x, double *y)
+{
+  if (!h) return fail("null handle");
+  if (n <= 0) return 0;
+  HIPCHK(hipSetDevice(h->device));
+  double *d = nullptr;
+  const size_t nb = (size_t)n * sizeof(double);
+  HIPCHK(hipMalloc(&d, 2 * nb));
+  hipError_t e = hipMemcpy(d, x, nb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = mckpp_launch_exp_batch(n, d, d + n, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipMemcpy(y, d + n, nb, hipMemcpyDeviceToHost);
+  hipFree(d);
+  HIPCHK(e);
+  return 0;
+}
+
+}  // extern "C"

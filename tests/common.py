@@ -1,0 +1,146 @@
+"""Shared helpers for the parity tests: identical synthetic inputs for the HIP
+path (reference-layout Kpp3dFields over the C-ABI) and the CPU oracle."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from mckpp_f90_amd import synth  # noqa: E402
+from oracle import orc  # noqa: E402
+
+
+def grid_for(nz, kind="uniform"):
+    if kind == "uniform":
+        return synth.uniform_grid(nz, 200.0)
+    if kind == "stretched":
+        return synth.stretched_grid(nz, 1000.0, 4.0)
+    raise ValueError(kind)
+
+
+def make_oracle(ncol, nz, mix="bench", exp_mode=1, grid="uniform", dto=3600.0, nthreads=0, init=True, **sw):
+    """Oracle const + batch with synthetic columns; runs init_ocean unless init=False."""
+    zm, hm, dm = grid_for(nz, grid)
+    oc = orc.Const(nz, dto=dto, exp_mode=exp_mode, zm=zm, hm=hm, dm=dm, **sw)
+    col = synth.columns(ncol, nz, zm=zm)
+    ob = orc.Batch(ncol, nz)
+    for k in "UVTS":
+        ob.a[k][:, 1:nz + 2] = col[k]
+    ob["U_init"][:, 1:nz + 2] = col["U"]
+    ob["V_init"][:, 1:nz + 2] = col["V"]
+    for k in ("f", "Sref", "SSref", "Ssurf", "ocdepth", "jerlov"):
+        ob[k] = col[k]
+    ob["sflux"] = 1e-20      # mckpp_initialize_fluxes (src/mckpp_fluxes_mod.F90:19-32)
+    if init:
+        orc.init_ocean(oc, ob, ntime=0, nthreads=nthreads)
+        ob["sflux"] = synth.forcing(ncol, mix)
+    return oc, ob
+
+
+def make_hip_case(ncol, nz, grid="uniform", dto=3600.0, land_every=0):
+    """KppConstFields + Kpp3dFields with the same synthetic columns (HIP side)."""
+    import mckpp_f90_amd as mk
+
+    zm, hm, dm = grid_for(nz, grid)
+    kc = mk.KppConstFields(nz, dto=dto, zm=zm[1:nz + 2], hm=hm[1:nz + 2], dm=dm)
+    mk.mckpp_physics_lookup(kc)
+    col = synth.columns(ncol, nz, zm=zm)
+    k3 = mk.Kpp3dFields(ncol, kc)
+    k3.U[:, :, 0] = col["U"]
+    k3.U[:, :, 1] = col["V"]
+    k3.X[:, :, 0] = col["T"]
+    k3.X[:, :, 1] = col["S"]
+    k3.U_init[...] = k3.U
+    for k in ("f", "Sref", "SSref", "Ssurf", "ocdepth"):
+        getattr(k3, k)[:] = col[k]
+    k3.jerlov[:] = col["jerlov"]
+    k3.sflux[:, :, 4, 0] = 1e-20
+    if land_every:
+        k3.run_physics[::land_every] = 0
+        k3.l_ocean[::land_every] = 0
+    return kc, k3
+
+
+def set_forcing_3d(k3, sflux6):
+    k3.sflux[:, 0:6, 4, 0] = sflux6
+
+
+# (3d field name, component index tuple, batch field, first reference index, count)
+def _pairs(nz):
+    nzp1 = nz + 1
+    P = []
+    for nm, a, l in (("U", "U", 0), ("V", "U", 1), ("T", "X", 0), ("S", "X", 1)):
+        P.append((nm, a, (slice(None), slice(None), l), 1, nzp1))
+    for t in (0, 1):
+        for nm, a, l in (("Us", "Us", 0), ("Vs", "Us", 1), ("Ts", "Xs", 0), ("Ss", "Xs", 1)):
+            P.append((f"{nm}{t}", a, (slice(None), slice(None), l, t), 1, nzp1))
+    return P
+
+
+def batch_to_3d_view(ob, name, lo, n):
+    return ob.a[name][:, lo:lo + n]
+
+
+PROFILE_FIELDS = ["U", "V", "T", "S", "Us0", "Us1", "Vs0", "Vs1", "Ts0", "Ts1", "Ss0", "Ss1"]
+SCALAR_FIELDS = ["hmix", "kmix", "Tref", "uref", "vref", "Ssurf", "reset_flag"]
+DIAG_FIELDS = {  # batch name -> (3d array, component or None, first index, count(nz))
+    "rho": ("rho", None, 0, lambda nz: nz + 2), "cp": ("cp", None, 0, lambda nz: nz + 2),
+    "buoy": ("buoy", None, 1, lambda nz: nz + 1),
+    "difm": ("difm", None, 0, lambda nz: nz + 2), "difs": ("difs", None, 0, lambda nz: nz + 2),
+    "dift": ("dift", None, 0, lambda nz: nz + 2), "ghat": ("ghat", None, 1, lambda nz: nz),
+    "wU1": ("wU", 0, 0, lambda nz: nz + 1), "wU2": ("wU", 1, 0, lambda nz: nz + 1),
+    "wX1": ("wX", 0, 0, lambda nz: nz + 1), "wX2": ("wX", 1, 0, lambda nz: nz + 1),
+    "wX3": ("wX", 2, 0, lambda nz: nz + 1), "wXNT1": ("wXNT", 0, 0, lambda nz: nz + 1),
+    "Rig": ("Rig", None, 1, lambda nz: nz), "dbloc": ("dbloc", None, 1, lambda nz: nz),
+    "Shsq": ("Shsq", None, 1, lambda nz: nz),
+    "swfrac": ("swfrac", None, 1, lambda nz: nz + 1), "swdk_opt": ("swdk_opt", None, 0, lambda nz: nz + 1),
+}
+
+
+def hip_field(k3, name, nz):
+    """Return the HIP-side array matching oracle batch field `name`, shape (npts, count)."""
+    nzp1 = nz + 1
+    m = {"U": ("U", 0), "V": ("U", 1), "T": ("X", 0), "S": ("X", 1)}
+    if name in m:
+        a, l = m[name]
+        return getattr(k3, a)[:, :, l], 1, nzp1
+    ms = {"Us": ("Us", 0), "Vs": ("Us", 1), "Ts": ("Xs", 0), "Ss": ("Xs", 1)}
+    if name[:2] in ms and name[2:] in ("0", "1"):
+        a, l = ms[name[:2]]
+        return getattr(k3, a)[:, :, l, int(name[2:])], 1, nzp1
+    arr, comp, lo, cnt = DIAG_FIELDS[name]
+    a = getattr(k3, arr)
+    n = cnt(nz)
+    if comp is not None:
+        a = a[:, :, comp]
+    if lo == 0:
+        return a[:, 0:n], 0, n
+    return a[:, 0:n], lo, n      # 1-based arrays: python index 0 <-> reference index 1
+
+
+def compare(k3, ob, nz, fields, active=None):
+    """Per-field (max_abs, max_rel, n_bit_mismatch) between HIP results and oracle batch."""
+    out = {}
+    sel = slice(None) if active is None else active
+    for name in fields:
+        if name in SCALAR_FIELDS or name in ("hmixd0", "hmixd1"):
+            if name.startswith("hmixd"):
+                h = k3.hmixd[:, int(name[-1])]
+                o = ob["hmixd"][:, int(name[-1])]
+            else:
+                h = getattr(k3, name)
+                o = ob[name]
+        else:
+            h, lo, n = hip_field(k3, name, nz)
+            o = ob.a[name][:, lo:lo + n]
+        h = np.asarray(h)[sel]
+        o = np.asarray(o)[sel]
+        d = np.abs(h - o)
+        den = np.maximum(np.abs(o), 1e-300)
+        bits = int((np.ascontiguousarray(h).view(np.int64) != np.ascontiguousarray(o).view(np.int64)).sum()
+                   - ((h == 0) & (o == 0) & (np.signbit(h) != np.signbit(o))).sum())
+        out[name] = (float(d.max()) if d.size else 0.0, float((d / den).max()) if d.size else 0.0, bits)
+    return out
