@@ -63,7 +63,7 @@ def coriolis(dlat):
     return 2.0 * (twopi / 86164.0) * np.sin(lat_eff * twopi / 360.0)
 
 
-def forcing(ncol, mix="bench", t_seconds=None):
+def forcing(ncol, mix="bench", t_seconds=None, index=None):
     """sflux(1:6,5,0) per column, shape (ncol, 6).
 
     mix="baseline": the reference's constant forcing on every column.
@@ -76,7 +76,7 @@ def forcing(ncol, mix="bench", t_seconds=None):
     lhf = np.full(ncol, -150.0)
     rain = np.full(ncol, 6e-5)
     if mix == "bench":
-        cls = np.arange(ncol) % 3
+        cls = (np.arange(ncol) if index is None else np.asarray(index)) % 3
         swf[cls == 1] = 0.0
         lhf[cls == 1] = -400.0
         taux[cls == 2] = 0.3
@@ -95,14 +95,22 @@ def forcing(ncol, mix="bench", t_seconds=None):
     return sflux
 
 
-def columns(ncol, nz, dmax=200.0, zm=None):
-    """Initial T, S(minus Sref), U, V on the grid and the per-column scalars."""
+def columns(ncol, nz, dmax=200.0, zm=None, index=None, ntotal=None):
+    """Initial T, S(minus Sref), U, V on the grid and the per-column scalars.
+
+    index/ntotal select a subset of a larger closed-form set (column i of
+    ntotal), so ranks and CPU samples can take slices of one global workload."""
     if zm is None:
         zm, _, _ = uniform_grid(nz, dmax)
     nzp1 = nz + 1
     z = -zm[1:nzp1 + 1]                       # depth, positive down
-    i = np.arange(ncol, dtype=np.float64)
-    lat = -60.0 + 120.0 * i / max(ncol - 1, 1)
+    if index is None:
+        i = np.arange(ncol, dtype=np.float64)
+        ntotal = ncol
+    else:
+        i = np.asarray(index, dtype=np.float64)
+        assert len(i) == ncol and ntotal is not None
+    lat = -60.0 + 120.0 * i / max(ntotal - 1, 1)
     coslat = np.cos(np.deg2rad(lat))
     T = 10.0 + 18.0 * coslat[:, None] * np.exp(-np.maximum(z - 20.0, 0.0) / 80.0)[None, :]
     Sfull = np.broadcast_to(35.0 + 0.5 * z / 200.0, (ncol, nzp1)).copy()

@@ -21,11 +21,12 @@ def grid_for(nz, kind="uniform"):
     raise ValueError(kind)
 
 
-def make_oracle(ncol, nz, mix="bench", exp_mode=1, grid="uniform", dto=3600.0, nthreads=0, init=True, **sw):
+def make_oracle(ncol, nz, mix="bench", exp_mode=1, grid="uniform", dto=3600.0, nthreads=0, init=True,
+                index=None, ntotal=None, **sw):
     """Oracle const + batch with synthetic columns; runs init_ocean unless init=False."""
     zm, hm, dm = grid_for(nz, grid)
     oc = orc.Const(nz, dto=dto, exp_mode=exp_mode, zm=zm, hm=hm, dm=dm, **sw)
-    col = synth.columns(ncol, nz, zm=zm)
+    col = synth.columns(ncol, nz, zm=zm, index=index, ntotal=ntotal)
     ob = orc.Batch(ncol, nz)
     for k in "UVTS":
         ob.a[k][:, 1:nz + 2] = col[k]
@@ -36,18 +37,18 @@ def make_oracle(ncol, nz, mix="bench", exp_mode=1, grid="uniform", dto=3600.0, n
     ob["sflux"] = 1e-20      # mckpp_initialize_fluxes (src/mckpp_fluxes_mod.F90:19-32)
     if init:
         orc.init_ocean(oc, ob, ntime=0, nthreads=nthreads)
-        ob["sflux"] = synth.forcing(ncol, mix)
+        ob["sflux"] = synth.forcing(ncol, mix, index=index)
     return oc, ob
 
 
-def make_hip_case(ncol, nz, grid="uniform", dto=3600.0, land_every=0):
+def make_hip_case(ncol, nz, grid="uniform", dto=3600.0, land_every=0, index=None, ntotal=None):
     """KppConstFields + Kpp3dFields with the same synthetic columns (HIP side)."""
     import mckpp_f90_amd as mk
 
     zm, hm, dm = grid_for(nz, grid)
     kc = mk.KppConstFields(nz, dto=dto, zm=zm[1:nz + 2], hm=hm[1:nz + 2], dm=dm)
     mk.mckpp_physics_lookup(kc)
-    col = synth.columns(ncol, nz, zm=zm)
+    col = synth.columns(ncol, nz, zm=zm, index=index, ntotal=ntotal)
     k3 = mk.Kpp3dFields(ncol, kc)
     k3.U[:, :, 0] = col["U"]
     k3.U[:, :, 1] = col["V"]

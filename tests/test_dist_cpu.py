@@ -1,0 +1,75 @@
+"""world_size-2 gloo test of the multi-GPU path's host logic: round-robin column
+sharding, per-rank stepping, and the gather-to-root of diagnostics.  The column
+arithmetic is done by the CPU oracle here (no GPU in this container); the
+sharding / gather code is the same module bench.py uses with RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+import common as cm
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ntotal, nz, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    sys.path.insert(0, cm.ROOT)
+    from mckpp_f90_amd import sharding
+    from oracle import orc
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    idx = sharding.shard_indices(ntotal, rank, world)
+    oc, ob = cm.make_oracle(len(idx), nz, exp_mode=1, index=idx, ntotal=ntotal, nthreads=1)
+    for nt in (1, 2):
+        orc.physics_driver(oc, ob, nt, nthreads=1)
+    parts = sharding.gather_to_root(ob["hmix"], dist)
+    tparts = sharding.gather_to_root(ob["T"], dist)
+    if rank == 0:
+        q.put((sharding.unshard(parts, ntotal), sharding.unshard(tparts, ntotal)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_round_robin_shard_and_gather_gloo():
+    from oracle import orc
+
+    ntotal, nz, world = 37, 40, 2           # odd total: ranks own 19 and 18 columns
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ntotal, nz, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    hmix, T = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    oc, ob = cm.make_oracle(ntotal, nz, exp_mode=1, nthreads=1)
+    for nt in (1, 2):
+        orc.physics_driver(oc, ob, nt, nthreads=1)
+    assert np.array_equal(hmix, ob["hmix"])
+    assert np.array_equal(T, ob["T"])
+
+
+def test_shard_indices_partition():
+    from mckpp_f90_amd import sharding
+
+    for ntotal, world in ((100000, 8), (37, 2), (5, 8)):
+        parts = [sharding.shard_indices(ntotal, r, world) for r in range(world)]
+        allidx = np.sort(np.concatenate(parts))
+        assert np.array_equal(allidx, np.arange(ntotal))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+        vals = [p * 2.0 for p in parts]
+        assert np.array_equal(sharding.unshard(vals, ntotal), np.arange(ntotal) * 2.0)

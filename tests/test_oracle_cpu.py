@@ -1,0 +1,195 @@
+"""CPU tests of the oracle: pinned to the reference's own check values, to
+golden vectors produced by the compiled reference, and (when oracle/_ref is
+present) to the compiled reference itself on a million points."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import common as cm
+from oracle import orc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+
+
+def _abk(fn, S, T, P, kappa=1.0):
+    a, b, k, s0, s = (C.c_double(v) for v in (1.0, 1.0, kappa, 0.0, 0.0))
+    fn(S, T, P, C.byref(a), C.byref(b), C.byref(k), C.byref(s0), C.byref(s))
+    return a.value, b.value, k.value, s0.value, s.value
+
+
+def test_reference_check_values():
+    """Check values printed in the reference's comments:
+    src/mckpp_physics_state_equations.F90:24-25 (CPSW) and :105-111 (alpha, beta, kappa)."""
+    L = orc.lib()
+    assert abs(L.orc_cpsw(40.0, 40.0, 10000.0) - 3849.500) < 1e-3
+    a, b, k, _, _ = _abk(L.orc_abk80, 35.0, 15.0, 0.0)
+    assert abs(a / 2.14136e-4 - 1) < 5e-6 and abs(b / 7.51638e-4 - 1) < 5e-6 and abs(k / 4.32576e-5 - 1) < 5e-6
+    a, b, k, _, _ = _abk(L.orc_abk80, 40.0, 0.0, 10000.0)
+    assert abs(a / 2.69822e-4 - 1) < 5e-6 and abs(b / 6.88317e-4 - 1) < 5e-6 and abs(k / 3.55271e-5 - 1) < 5e-6
+
+
+def test_eos_golden_bitexact():
+    g = np.load(os.path.join(GOLD, "eos_ref.npz"))
+    n = len(g["s"])
+    L = orc.lib()
+    out = [np.zeros(n) for _ in range(5)]
+    L.orc_abk80_batch(n, dp(g["s"]), dp(g["t"]), dp(g["p"]), *[dp(o) for o in out[:4]])
+    L.orc_cpsw_batch(n, dp(g["s"]), dp(g["t"]), dp(g["p"]), dp(out[4]))
+    for o, nm in zip(out, ("alpha", "beta", "sig0", "sig", "cp")):
+        assert np.array_equal(o.view(np.int64), g[nm].view(np.int64)), nm
+
+
+def test_z121_golden_bitexact():
+    g = np.load(os.path.join(GOLD, "z121_ref.npz"))
+    L = orc.lib()
+    for km, vin, vout, wout in zip(g["km"], g["vin"], g["vout"], g["wout"]):
+        v = vin[: km + 2].copy()
+        w = np.full(km + 2, 7.0)
+        L.orc_z121(int(km) + 1, 0.0, 0.8, dp(v), dp(w))
+        assert np.array_equal(v.view(np.int64), vout[: km + 2].view(np.int64))
+        assert np.array_equal(w, wout[: km + 2])
+
+
+@pytest.mark.skipif(not os.path.exists(orc.REFLIB), reason="compiled reference (oracle/_ref) not built")
+def test_eos_vs_compiled_reference_1e6():
+    L, R = orc.lib(), orc.ref()
+    rng = np.random.default_rng(7)
+    n = 1_000_000
+    s, t, p = rng.uniform(0, 42, n), rng.uniform(-4, 35, n), rng.uniform(0.05, 6000, n)
+    o = [np.zeros(n) for _ in range(10)]
+    L.orc_abk80_batch(n, dp(s), dp(t), dp(p), *[dp(x) for x in o[:4]])
+    R.ref_abk80_batch(n, dp(s), dp(t), dp(p), *[dp(x) for x in o[4:8]])
+    L.orc_cpsw_batch(n, dp(s), dp(t), dp(p), dp(o[8]))
+    R.ref_cpsw_batch(n, dp(s), dp(t), dp(p), dp(o[9]))
+    for i in range(4):
+        assert np.array_equal(o[i].view(np.int64), o[4 + i].view(np.int64))
+    assert np.array_equal(o[8].view(np.int64), o[9].view(np.int64))
+
+
+@pytest.mark.skipif(not os.path.exists(orc.REFLIB), reason="compiled reference (oracle/_ref) not built")
+def test_abk80_flag_paths_vs_compiled_reference():
+    """P = 0 short-cuts and the kappa-only / alpha-only entry paths of mckpp_abk80."""
+    L, R = orc.lib(), orc.ref()
+    for S, T, P in ((35.0, 10.0, 0.0), (0.0, 4.0, 0.0), (35.0, 10.0, 500.0), (20.0, -5.0, 50.0)):
+        for a0, b0, k0 in ((1, 1, 1), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (0, 0, 0)):
+            res = []
+            for fn in (L.orc_abk80, R.ref_abk80):
+                a, b, k, s0, s = (C.c_double(v) for v in (a0, b0, k0, 9.0, 9.0))
+                fn(S, T, P, C.byref(a), C.byref(b), C.byref(k), C.byref(s0), C.byref(s))
+                res.append((a.value, b.value, k.value, s0.value, s.value))
+            assert res[0] == res[1], (S, T, P, a0, b0, k0, res)
+
+
+def test_portable_exp_accuracy():
+    L = orc.lib()
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-80, 10, 20000), [0.0, -80.0, 1e-300, -1e-300, 700.0, -740.0]])
+    y = np.array([L.orc_exp_portable(float(v)) for v in x])
+    ref = np.exp(x)
+    ulp = np.spacing(ref)
+    assert np.all(np.abs(y - ref) <= 1.0 * ulp)
+    assert L.orc_exp_portable(0.0) == 1.0
+
+
+def test_lookup_table_properties():
+    """wmt/wst (src/mckpp_physics_lookup_mod.F90:42-64): last row (zehat=0) is the neutral
+    value vonk*ustar; unstable entries exceed it; continuity across the zeta switch."""
+    oc = orc.Const(40)
+    wm, ws = oc.wmt, oc.wst          # [j, i]
+    du = 0.04 / 49
+    usta = du * np.arange(50)
+    assert np.allclose(wm[:, 891], 0.4 * usta, rtol=1e-13, atol=0)
+    assert np.all(wm[1:, :891] >= wm[1:, 891:892] * (1 - 1e-12))
+    assert np.all(np.isfinite(wm)) and np.all(np.isfinite(ws)) and np.all(wm >= 0) and np.all(ws >= 0)
+
+
+def test_tridiagonal_solver_residual():
+    """tridcof + tridmat (src/mckpp_physics_solvers.F90:14-44, 112-161) solve A y = rhs."""
+    L = orc.lib()
+    nz = 60
+    oc = orc.Const(nz)
+    rng = np.random.default_rng(5)
+    n = nz + 4
+    diff = np.zeros(n); diff[1:nz + 1] = rng.uniform(1e-5, 5e-2, nz)
+    cu, cc, cl, rhs, yo, yn, gam = (np.zeros(n) for _ in range(7))
+    L.orc_tridcof(oc.ptr, dp(diff), nz, dp(cu), dp(cc), dp(cl))
+    rhs[1:nz + 1] = rng.normal(size=nz)
+    yo[nz + 1] = 3.25
+    assert L.orc_tridmat(dp(cu), dp(cc), dp(cl), dp(rhs), dp(yo), nz, dp(yn), dp(gam)) == 0
+    assert cu[1] == 0.0 and cl[nz] == 0.0 and yn[nz + 1] == 3.25
+    res = cc[1:nz + 1] * yn[1:nz + 1]
+    res[1:] += cu[2:nz + 1] * yn[1:nz]
+    res[:-1] += cl[1:nz] * yn[2:nz + 1]
+    assert np.max(np.abs(res - rhs[1:nz + 1])) < 1e-12
+    # zero pivot is reported, not fatal
+    cc0 = cc.copy(); cc0[1] = 1.0; cl0 = cl.copy(); cu0 = cu.copy()
+    cc0[2] = cu0[2] * (cl0[1] / cc0[1])
+    assert L.orc_tridmat(dp(cu0), dp(cc0), dp(cl0), dp(rhs), dp(yo), nz, dp(yn), dp(gam)) == 1
+
+
+@pytest.mark.parametrize("nz,ncol", [(40, 64), (60, 96)])
+def test_step_invariants(nz, ncol):
+    """Heat and salt budgets of the implicit step, convergence bookkeeping, persistence contract."""
+    oc, ob = cm.make_oracle(ncol, nz, exp_mode=0)
+    f0 = ob["f"].copy()
+    hm = oc.hm
+    for nt in (1, 2):
+        before = ob.copy()
+        orc.physics_driver(oc, ob, nt)
+        assert np.array_equal(ob["f"], f0)                       # f is not written back
+        assert np.all(ob["npasses"] >= 6)                        # 3 compulsory + >=3 converged passes
+        assert np.all(ob["reset_flag"] == 0)
+        assert np.array_equal(ob["old"], before["newi"]) and np.array_equal(ob["newi"], 1 - ob["old"])
+        for c in range(ncol):
+            new = int(ob["newi"][c])
+            assert np.array_equal(ob[f"Ts{new}"][c], ob["T"][c])
+            assert ob["hmixd"][c, new] == ob["hmix"][c]
+            assert 2 <= ob["kmix"][c] <= nz
+        # heat budget: sum h (Tn-To) = dto*(-wX(0,1) + wXNT(nz) - wXNT(0)) + bottom diffusive flux
+        dT = ((ob["T"][:, 1:nz + 1] - before["T"][:, 1:nz + 1]) * hm[1:nz + 1]).sum(axis=1)
+        bot = hm[nz] * oc.tri1[nz] * ob["dift"][:, nz] * (before["T"][:, nz + 1] - ob["T"][:, nz])
+        src = oc.c.dto * (-ob["wX1"][:, 0] + ob["wXNT1"][:, nz] - ob["wXNT1"][:, 0]) + bot
+        assert np.max(np.abs(dT - src)) < 1e-9 * max(1.0, np.max(np.abs(src)))
+        dS = ((ob["S"][:, 1:nz + 1] - before["S"][:, 1:nz + 1]) * hm[1:nz + 1]).sum(axis=1)
+        botS = hm[nz] * oc.tri1[nz] * ob["difs"][:, nz] * (before["S"][:, nz + 1] - ob["S"][:, nz])
+        srcS = oc.c.dto * (-ob["wX2"][:, 0]) + botS
+        assert np.max(np.abs(dS - srcS)) < 1e-9 * max(1e-3, np.max(np.abs(srcS)))
+        assert np.array_equal(ob["T"][:, nz + 1], before["T"][:, nz + 1])   # yn(nz+1) = yo(nz+1)
+
+
+def test_threads_do_not_change_results():
+    oc, a = cm.make_oracle(200, 40, exp_mode=1, nthreads=1)
+    _, b = cm.make_oracle(200, 40, exp_mode=1, nthreads=4)
+    orc.physics_driver(oc, a, 1, nthreads=1)
+    orc.physics_driver(oc, b, 1, nthreads=4)
+    for k in ("U", "V", "T", "S", "hmix", "kmix", "difm", "ghat"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_instability_trap_and_reset():
+    """ocnstep_mod.F90:200-236 + overrides.F90:72-78: absurd currents trip the trap,
+    f is perturbed for the retries only, U falls back to U_init after ten failures."""
+    oc, ob = cm.make_oracle(8, 40, exp_mode=1)
+    ob["U"][:, 1:5] = 50.0              # the old profile itself is absurd: |U| >= 10 after every try
+    orc.physics_driver(oc, ob, 1)
+    st = ob["status"]
+    assert np.all(st & orc.ST_RETRIED) and np.all(st & orc.ST_FAILED)
+    assert np.all(ob["reset_flag"] == 0)             # overrides.F90:121-123
+    assert np.array_equal(ob["U"], ob["U_init"])
+    assert np.all(ob["npasses"] >= 11 * 6)
+
+
+def test_exp_mode_only_changes_last_bits():
+    oc0, a = cm.make_oracle(128, 60, exp_mode=0)
+    oc1, b = cm.make_oracle(128, 60, exp_mode=1)
+    for nt in (1, 2, 3):
+        orc.physics_driver(oc0, a, nt)
+        orc.physics_driver(oc1, b, nt)
+    same_path = a["npasses"] == b["npasses"]
+    assert same_path.mean() > 0.9
+    for k in ("T", "S", "U", "V"):
+        d = np.abs(a[k][same_path] - b[k][same_path])
+        assert d.max() < 1e-10, (k, d.max())

@@ -1,0 +1,281 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through
+the C-ABI, against the CPU oracle on identical inputs.
+
+Bars
+  * bit-exact against the oracle in portable-exp mode (the library's own exp is
+    the same arithmetic), on every prognostic, saved, scalar and diagnostic field;
+  * <= 1e-10 relative error on hmix, T, S, U, V against the oracle in faithful
+    (libm exp) mode - the tolerance BASELINE.json's north_star states;
+  * at BASELINE.json's full size (1e5 x 60): run-to-run determinism, heat budget,
+    bookkeeping invariants, and bit-exact agreement on a strided sample.
+"""
+import numpy as np
+import pytest
+
+import common as cm
+
+pytestmark = pytest.mark.gpu
+
+ALL_FIELDS = cm.PROFILE_FIELDS + cm.SCALAR_FIELDS + ["hmixd0", "hmixd1"] + list(cm.DIAG_FIELDS.keys())
+
+
+@pytest.fixture(scope="module")
+def mk(built):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X (no HIP device visible)")
+    import mckpp_f90_amd as m
+
+    m.load_library()
+    return m
+
+
+def _assert_bitexact(res, tag=""):
+    bad = {k: v for k, v in res.items() if v[2] != 0}
+    assert not bad, f"{tag}: fields differing from the oracle (max_abs, max_rel, n_values): {bad}"
+
+
+def _run_both(mk, ncol, nz, nsteps, grid="uniform", land_every=0, jerlov_mix=False, exp_mode=1, dto=3600.0,
+              mix="bench", nztmax=None):
+    from oracle import orc
+
+    oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=exp_mode, grid=grid, dto=dto)
+    kc, k3 = cm.make_hip_case(ncol, nz, grid=grid, dto=dto, land_every=land_every)
+    if jerlov_mix:
+        jer = 1 + (np.arange(ncol) % 5).astype(np.int32)
+        k3.jerlov[:] = jer
+        ob["jerlov"] = jer
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    orc.init_ocean(oc, ob, 0)
+    active = np.nonzero(k3.run_physics)[0]
+    out = [("init", cm.compare(k3, ob, nz, ALL_FIELDS, active))]
+    sf = cm.synth.forcing(ncol, mix)
+    ob["sflux"] = sf
+    cm.set_forcing_3d(k3, sf)
+    for nt in range(1, nsteps + 1):
+        ctx = mk.mckpp_physics_driver(k3, kc, nt)
+        orc.physics_driver(oc, ob, nt)
+        st, nf, npass = ctx.status()
+        assert np.array_equal(st[active], ob["status"][active])
+        assert np.array_equal(npass[active], ob["npasses"][active])
+        out.append((f"step{nt}", cm.compare(k3, ob, nz, ALL_FIELDS, active)))
+    return out, k3, ob, kc, oc
+
+
+def test_eos_and_exp_kernels_bitexact(mk):
+    import ctypes as C
+
+    from oracle import orc
+
+    kc = mk.KppConstFields(40)
+    mk.mckpp_physics_lookup(kc)
+    ctx = mk.MckppHip(kc)
+    rng = np.random.default_rng(11)
+    n = 200_000
+    s, t, p = rng.uniform(0, 42, n), rng.uniform(-4, 35, n), rng.uniform(0.05, 6000, n)
+    a, b, s0, cp = ctx.eos_batch(s, t, p)
+    L = orc.lib()
+    dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    o = [np.zeros(n) for _ in range(5)]
+    L.orc_abk80_batch(n, dp(s), dp(t), dp(p), *[dp(x) for x in o[:4]])
+    L.orc_cpsw_batch(n, dp(s), dp(t), dp(p), dp(o[4]))
+    assert np.array_equal(a, o[0]) and np.array_equal(b, o[1]) and np.array_equal(s0, o[2]) and np.array_equal(cp, o[4])
+    x = np.concatenate([rng.uniform(-80, 10, 100_000), [0.0, -80.0, -745.5, 700.0]])
+    y = ctx.exp_batch(x)
+    yo = np.array([L.orc_exp_portable(float(v)) for v in x])
+    assert np.array_equal(y, yo)
+    # the golden vectors of the compiled reference, straight through the GPU kernel
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "eos_ref.npz"))
+    a, b, s0, cp = ctx.eos_batch(g["s"], g["t"], g["p"])
+    assert np.array_equal(a, g["alpha"]) and np.array_equal(b, g["beta"])
+    assert np.array_equal(s0, g["sig0"]) and np.array_equal(cp, g["cp"])
+    ctx.close()
+
+
+@pytest.mark.parametrize("nz,ncol,nsteps", [(40, 64, 3), (60, 1000, 3), (100, 130, 2)])
+def test_step_bitexact_uniform_grid(mk, nz, ncol, nsteps):
+    """BASELINE configs[0] shape (64 x 40, single forced step) and the 60- and 100-level shapes."""
+    out, *_ = _run_both(mk, ncol, nz, nsteps)
+    for tag, res in out:
+        _assert_bitexact(res, f"nz={nz} {tag}")
+
+
+def test_step_bitexact_stretched_grid_69_levels_land_mask_jerlov(mk):
+    """The shipped namelist's vertical size (nz=69, nztmax=83: run/3D_ocn.nml:2-4) on the
+    reference's stretched grid, with a land mask (run_physics=.F.) and all five Jerlov types."""
+    out, k3, ob, kc, oc = _run_both(mk, 333, 69, 2, grid="stretched", land_every=3, jerlov_mix=True)
+    for tag, res in out:
+        _assert_bitexact(res, f"nz=69 {tag}")
+    land = np.nonzero(k3.run_physics == 0)[0]
+    assert np.all(k3.hmix[land] == 0.0) and np.all(k3.Us[land] == 0.0)   # land columns untouched
+
+
+def test_short_timestep_bitexact(mk):
+    out, *_ = _run_both(mk, 96, 60, 2, dto=1200.0)     # run/3D_ocn.nml:23 dtsec/ndtocn
+    for tag, res in out:
+        _assert_bitexact(res, f"dto=1200 {tag}")
+
+
+def test_tolerance_vs_faithful_oracle(mk):
+    """<= 1e-10 relative error on hmix and the T/S/U/V profiles against the oracle run with libm
+    exp (the reference's EXP); columns whose discrete path differs are counted, not hidden."""
+    out, k3, ob, kc, oc = _run_both(mk, 1500, 60, 3, exp_mode=0)
+    nz = 60
+    flips = int((np.asarray(k3.kmix) != ob["kmix"]).sum())
+    assert flips <= 0.002 * 1500, f"{flips} columns took a different kmix"
+    same = np.asarray(k3.kmix) == ob["kmix"]
+    rel = {}
+    for name in ("T", "S", "U", "V"):
+        h, lo, n = cm.hip_field(k3, name, nz)
+        o = ob.a[name][:, lo:lo + n]
+        scale = np.maximum(np.abs(o).max(axis=1, keepdims=True), 1e-30)   # profile-relative error
+        rel[name] = float((np.abs(h - o) / scale)[same].max())
+    rel["hmix"] = float((np.abs(k3.hmix - ob["hmix"]) / np.abs(ob["hmix"]))[same].max())
+    assert all(v <= 1e-10 for v in rel.values()), rel
+
+
+def test_config2_kppmix_tridiag_pass_bitexact(mk):
+    """BASELINE configs[1]: one vmix (kppmix stack) + ocnint (tridiagonal solves) pass, 1e4 x 60."""
+    from oracle import orc
+
+    ncol, nz = 10000, 60
+    oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1)
+    kc, k3 = cm.make_hip_case(ncol, nz)
+    sf = cm.synth.forcing(ncol, "bench")
+    ob["sflux"] = sf
+    cm.set_forcing_3d(k3, sf)
+    ctx = mk.MckppHip(kc)
+    ctx.upload(k3)
+    ctx.vmix_pass(1)
+    ctx.download(k3)
+    orc.vmix_batch(oc, ob, 1)
+    fields = ["U", "V", "T", "S", "hmix", "kmix", "uref", "vref", "rho", "cp", "buoy", "difm", "difs", "dift",
+              "ghat", "Rig", "dbloc", "Shsq", "wXNT1"]
+    _assert_bitexact(cm.compare(k3, ob, nz, fields), "config2 pass")
+    ctx.close()
+
+
+def test_instability_trap_retry_and_reset(mk):
+    """ocnstep_mod.F90:200-236 and overrides.F90:72-78 on the device: retries with perturbed f,
+    status bits, fall-back of the currents to U_init."""
+    from oracle import orc
+
+    ncol, nz = 70, 40
+    oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1)
+    kc, k3 = cm.make_hip_case(ncol, nz)
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    orc.init_ocean(oc, ob, 0)
+    bad = np.arange(0, ncol, 7)
+    k3.U[bad, 0:4, 0] = 50.0
+    ob["U"][bad, 1:5] = 50.0
+    ctx.upload(k3)
+    sf = cm.synth.forcing(ncol, "bench")
+    ob["sflux"] = sf
+    cm.set_forcing_3d(k3, sf)
+    mk.mckpp_physics_driver(k3, kc, 1)
+    orc.physics_driver(oc, ob, 1)
+    st, nf, npass = ctx.status()
+    assert nf == len(bad) and np.all(st[bad] & 12 == 12) and np.array_equal(st, ob["status"])
+    assert np.array_equal(npass, ob["npasses"])
+    _assert_bitexact(cm.compare(k3, ob, nz, cm.PROFILE_FIELDS + cm.SCALAR_FIELDS), "trap")
+    assert np.array_equal(k3.U[bad], k3.U_init[bad])
+
+
+def test_edge_sizes_and_errors(mk):
+    from oracle import orc
+
+    for ncol in (1, 63, 65):
+        out, *_ = _run_both(mk, ncol, 40, 1)
+        for tag, res in out:
+            _assert_bitexact(res, f"ncol={ncol} {tag}")
+    # all land: nothing resident, calls are no-ops
+    kc, k3 = cm.make_hip_case(5, 40)
+    k3.run_physics[:] = 0
+    ctx = mk.mckpp_physics_driver(k3, kc, 1)
+    assert ctx.ncolumns == 0 and np.all(k3.hmix == 0)
+    # unsupported switches and bad inputs are refused with a message, never computed on the CPU
+    kc2, k32 = cm.make_hip_case(4, 40)
+    kc2.LDD = 1
+    with pytest.raises(mk.MckppHipError, match="not implemented"):
+        mk.MckppHip(kc2)
+    kc3, k33 = cm.make_hip_case(4, 40)
+    k33.jerlov[2] = 9
+    with pytest.raises(mk.MckppHipError, match="jerlov"):
+        mk.mckpp_physics_driver(k33, kc3, 1)
+
+
+def test_diagnostics_off_same_state(mk):
+    kc, k3 = cm.make_hip_case(300, 60)
+    kc2, k3b = cm.make_hip_case(300, 60)
+    sf = cm.synth.forcing(300, "bench")
+    for kk, c, diag in ((k3, kc, 1), (k3b, kc2, 0)):
+        ctx = mk.MckppHip(c)
+        ctx.upload(kk)
+        ctx.set_diagnostics(diag)
+        ctx.init_ocean(0)
+        cm.set_forcing_3d(kk, sf)
+        ctx.set_forcing(kk.sflux)
+        ctx.step(1, 3)
+        ctx.download(kk, mk.api.F_RESTART)
+        ctx.close()
+    for n in ("U", "X", "Us", "Xs", "hmix", "kmix", "hmixd"):
+        assert np.array_equal(getattr(k3, n), getattr(k3b, n)), n
+
+
+def test_full_size_properties_1e5x60(mk):
+    """BASELINE configs[2] size.  Determinism, budgets, bookkeeping, and bit-exact agreement with
+    the oracle on every 97th column."""
+    from oracle import orc
+
+    ncol, nz, nsteps = 100_000, 60, 2
+    kc, k3 = cm.make_hip_case(ncol, nz)
+    ctx = mk.MckppHip(kc)
+    ctx.upload(k3)
+    ctx.init_ocean(0)
+    sf = cm.synth.forcing(ncol, "bench")
+    cm.set_forcing_3d(k3, sf)
+    ctx.set_forcing(k3.sflux)
+    ctx.download(k3)
+    T0 = k3.X[:, :, 0].copy()
+    ctx.step(1, 1)
+    ctx.download(k3)
+    hm = kc.hm
+    dT = ((k3.X[:, 0:nz, 0] - T0[:, 0:nz]) * hm[0:nz]).sum(axis=1)
+    tri1_nz = kc.tri[nz, 1, 0]
+    bot = hm[nz - 1] * tri1_nz * k3.dift[:, nz] * (T0[:, nz] - k3.X[:, nz - 1, 0])
+    src = kc.dto * (-k3.wX[:, 0, 0] + k3.wXNT[:, nz, 0] - k3.wXNT[:, 0, 0]) + bot
+    assert np.max(np.abs(dT - src)) < 1e-9 * np.max(np.abs(src))
+    assert np.array_equal(k3.X[:, nz, 0], T0[:, nz])
+    assert np.all((k3.kmix >= 2) & (k3.kmix <= nz)) and np.all(k3.hmix > 0) and np.all(np.isfinite(k3.X))
+    st, nf, npass = ctx.status()
+    assert nf == 0 and npass.min() >= 6
+    ctx.step(2, nsteps - 1)
+    ctx.download(k3)
+    # second, independent run: bitwise identical
+    kc2, k3b = cm.make_hip_case(ncol, nz)
+    ctx2 = mk.MckppHip(kc2)
+    ctx2.upload(k3b)
+    ctx2.init_ocean(0)
+    cm.set_forcing_3d(k3b, sf)
+    ctx2.set_forcing(k3b.sflux)
+    ctx2.step(1, nsteps)
+    ctx2.download(k3b)
+    for n in ("U", "X", "Us", "Xs", "hmix", "kmix", "difm", "ghat", "wX"):
+        assert np.array_equal(getattr(k3, n), getattr(k3b, n)), n
+    ctx.close()
+    ctx2.close()
+    # strided sample against the oracle
+    idx = np.arange(0, ncol, 97)
+    oc, ob = cm.make_oracle(len(idx), nz, exp_mode=1, index=idx, ntotal=ncol)
+    for nt in range(1, nsteps + 1):
+        orc.physics_driver(oc, ob, nt)
+
+    class _Sub:
+        pass
+
+    sub = _Sub()
+    for n in ("U", "X", "Us", "Xs", "hmixd", "hmix", "kmix", "Tref", "uref", "vref", "Ssurf", "reset_flag"):
+        setattr(sub, n, getattr(k3, n)[idx])
+    _assert_bitexact(cm.compare(sub, ob, nz, cm.PROFILE_FIELDS + cm.SCALAR_FIELDS + ["hmixd0", "hmixd1"]), "1e5 sample")
