@@ -1,0 +1,108 @@
+!> Forced column-physics run on the Fortran call surface, shaped like the
+!! reference's main program (src/mckpp_ocean_model_3D.F90:23-70) minus file I/O:
+!!   dimensions -> allocate -> grid -> lookup -> initial profiles ->
+!!   mckpp_initialize_ocean_model -> DO nt: ntime, forcing, mckpp_physics_driver
+!! Inputs come from a flat binary file written by the test harness so that the
+!! bits are identical to the ones the C-ABI tests use; results go to a second
+!! flat file.  Usage: kpp_driver <case.bin> <out.bin>
+program kpp_driver
+  use iso_c_binding
+  use mckpp_parameters
+  use mckpp_data_fields
+  use mckpp_time_control
+  use mckpp_physics_lookup_mod, only: mckpp_physics_lookup
+  use mckpp_initialize_ocean, only: mckpp_initialize_ocean_model
+  use mckpp_physics_driver_mod, only: mckpp_physics_driver, mckpp_physics_finalize
+  use mckpp_physics_ocnstep_mod, only: mckpp_physics_ocnstep
+  implicit none
+  character(len=512) :: fin, fout
+  integer :: u, nt, nsteps, ncol, nlev, use_1d, ipt
+  integer(c_int) :: hdr(8)
+  real(c_double), allocatable :: sf6(:,:), mask(:)
+  type(kpp_1d_type) :: q
+  real(c_double) :: t0, t1
+
+  call get_command_argument(1, fin)
+  call get_command_argument(2, fout)
+  open (newunit=u, file=trim(fin), access='stream', form='unformatted', status='old')
+  read (u) hdr
+  ncol = hdr(1); nlev = hdr(2); nsteps = hdr(3); use_1d = hdr(4)
+  call mckpp_set_dimensions(ncol, 1, nlev, hdr(5))
+  call mckpp_allocate_const_fields()
+  call mckpp_allocate_3d_fields()
+  read (u) kpp_const_fields%dto
+  read (u) kpp_const_fields%zm, kpp_const_fields%hm, kpp_const_fields%dm
+  read (u) kpp_3d_fields%U, kpp_3d_fields%X
+  read (u) kpp_3d_fields%f, kpp_3d_fields%Sref, kpp_3d_fields%SSref, kpp_3d_fields%Ssurf, kpp_3d_fields%ocdepth
+  read (u) kpp_3d_fields%jerlov
+  allocate (mask(ncol), sf6(ncol, 6))
+  read (u) mask
+  read (u) sf6
+  close (u)
+  kpp_3d_fields%run_physics = mask > 0.5_c_double
+  kpp_3d_fields%l_ocean = kpp_3d_fields%run_physics
+  kpp_3d_fields%U_init = kpp_3d_fields%U
+  kpp_3d_fields%sflux = 0
+  kpp_3d_fields%sflux(:, :, 5, 0) = 1e-20_c_double      ! mckpp_initialize_fluxes, src/mckpp_fluxes_mod.F90:19-32
+
+  call mckpp_physics_lookup(kpp_const_fields)
+  ntime = 0
+  call mckpp_initialize_ocean_model()
+
+  kpp_3d_fields%sflux(:, 1:6, 5, 0) = sf6
+  call cpu_time(t0)
+  do nt = 1, nsteps
+    call mckpp_update_time(nt)
+    if (use_1d == 0) then
+      call mckpp_physics_driver()
+    else
+      ! the reference's inner loop body, one column at a time (physics_driver_mod.F90:46-63)
+      do ipt = 1, npts
+        if (.not. kpp_3d_fields%run_physics(ipt)) cycle
+        call gather_1d(ipt, q)
+        call mckpp_physics_ocnstep(q, kpp_const_fields)
+        call scatter_1d(ipt, q)
+      end do
+    end if
+  end do
+  call cpu_time(t1)
+  write (*, '(a,i0,a,i0,a,i0,a,f8.3,a)') 'kpp_driver: ', ncol, ' columns x ', nlev, ' levels, ', nsteps, &
+        ' steps, ', t1 - t0, ' s host time'
+  write (*, '(a,3es14.6)') 'kpp_driver: hmix min/mean/max ', minval(kpp_3d_fields%hmix, kpp_3d_fields%run_physics), &
+        sum(kpp_3d_fields%hmix)/max(1, count(kpp_3d_fields%run_physics)), maxval(kpp_3d_fields%hmix)
+
+  open (newunit=u, file=trim(fout), access='stream', form='unformatted', status='replace')
+  write (u) kpp_3d_fields%U, kpp_3d_fields%X, kpp_3d_fields%Us, kpp_3d_fields%Xs
+  write (u) kpp_3d_fields%hmix, kpp_3d_fields%kmix, kpp_3d_fields%hmixd, kpp_3d_fields%Tref, kpp_3d_fields%Ssurf
+  write (u) kpp_3d_fields%old, kpp_3d_fields%new
+  write (u) kpp_3d_fields%difm, kpp_3d_fields%ghat, kpp_3d_fields%rho
+  close (u)
+  call mckpp_physics_finalize()
+
+contains
+
+  subroutine gather_1d(i, c)
+    integer, intent(in) :: i
+    type(kpp_1d_type), intent(inout) :: c
+    call mckpp_allocate_1d_fields(c)
+    c%U = kpp_3d_fields%U(i,:,:); c%X = kpp_3d_fields%X(i,:,:); c%U_init = kpp_3d_fields%U_init(i,:,:)
+    c%Us = kpp_3d_fields%Us(i,:,:,:); c%Xs = kpp_3d_fields%Xs(i,:,:,:); c%hmixd = kpp_3d_fields%hmixd(i,:)
+    c%sflux = kpp_3d_fields%sflux(i,:,:,:)
+    c%f = kpp_3d_fields%f(i); c%ocdepth = kpp_3d_fields%ocdepth(i); c%Sref = kpp_3d_fields%Sref(i)
+    c%SSref = kpp_3d_fields%SSref(i); c%Ssurf = kpp_3d_fields%Ssurf(i)
+    c%hmix = kpp_3d_fields%hmix(i); c%kmix = kpp_3d_fields%kmix(i)
+    c%old = kpp_3d_fields%old(i); c%new = kpp_3d_fields%new(i); c%jerlov = kpp_3d_fields%jerlov(i)
+    c%l_ocean = kpp_3d_fields%l_ocean(i); c%l_initflag = kpp_3d_fields%l_initflag(i); c%point = i
+  end subroutine gather_1d
+
+  subroutine scatter_1d(i, c)
+    integer, intent(in) :: i
+    type(kpp_1d_type), intent(in) :: c
+    kpp_3d_fields%U(i,:,:) = c%U; kpp_3d_fields%X(i,:,:) = c%X
+    kpp_3d_fields%Us(i,:,:,:) = c%Us; kpp_3d_fields%Xs(i,:,:,:) = c%Xs; kpp_3d_fields%hmixd(i,:) = c%hmixd
+    kpp_3d_fields%hmix(i) = c%hmix; kpp_3d_fields%kmix(i) = c%kmix; kpp_3d_fields%Tref(i) = c%Tref
+    kpp_3d_fields%Ssurf(i) = c%Ssurf; kpp_3d_fields%old(i) = c%old; kpp_3d_fields%new(i) = c%new
+    kpp_3d_fields%difm(i,:) = c%difm; kpp_3d_fields%ghat(i,:) = c%ghat; kpp_3d_fields%rho(i,:) = c%rho
+  end subroutine scatter_1d
+
+end program kpp_driver

@@ -1,0 +1,145 @@
+!> iso_c_binding view of include/mckpp_hip.h: the only place the Fortran host
+!! touches the HIP library.  Struct layouts mirror mckpp_const_c and
+!! mckpp_state_ptrs_c member for member.
+module mckpp_hip_binding
+  use iso_c_binding
+  implicit none
+
+  integer(c_int), parameter :: MCKPP_F_PROFILES = 1, MCKPP_F_SAVED = 2, MCKPP_F_SCALARS = 4, MCKPP_F_DIAG = 8
+  integer(c_int), parameter :: MCKPP_F_RESTART = 7, MCKPP_F_ALL = 15
+
+  type, bind(C) :: mckpp_const_c
+    integer(c_int32_t) :: nz, nztmax, nsflxs, njdt, itermax
+    integer(c_int32_t) :: LKPP, LRI, LDD, L_SSref
+    integer(c_int32_t) :: L_RELAX_SST, L_RELAX_CALCONLY, L_FCORR, L_FCORR_WITHZ
+    integer(c_int32_t) :: L_SFCORR, L_SFCORR_WITHZ, L_RELAX_SAL, L_RELAX_OCNT
+    integer(c_int32_t) :: L_NO_FREEZE, L_NO_ISOTHERM, L_DAMP_CURR
+    integer(c_int32_t) :: clim_present
+    integer(c_int32_t) :: iso_bot, dt_uvdamp
+    real(c_double) :: hmixtolfrac, dto, grav, vonk, sice, iso_thresh
+    type(c_ptr) :: zm, hm, dm, tri, wmt, wst
+  end type mckpp_const_c
+
+  type, bind(C) :: mckpp_state_ptrs_c
+    integer(c_int64_t) :: npts
+    type(c_ptr) :: U, X, Us, Xs, U_init, hmixd
+    type(c_ptr) :: f, ocdepth, Sref, SSref, Ssurf
+    type(c_ptr) :: hmix, kmix, Tref, uref, vref
+    type(c_ptr) :: reset_flag, dampu_flag, dampv_flag, freeze_flag
+    type(c_ptr) :: sflux
+    type(c_ptr) :: old, new_, jerlov
+    type(c_ptr) :: l_ocean, l_initflag, run_physics
+    type(c_ptr) :: rho, cp, buoy, difm, difs, dift, wU, wX, wXNT, ghat, Rig, Shsq, dbloc, swfrac, swdk_opt
+  end type mckpp_state_ptrs_c
+
+  interface
+    function mckpp_hip_last_error() bind(C, name="mckpp_hip_last_error") result(p)
+      import :: c_ptr
+      type(c_ptr) :: p
+    end function
+    function mckpp_hip_device_count() bind(C, name="mckpp_hip_device_count") result(n)
+      import :: c_int
+      integer(c_int) :: n
+    end function
+    function mckpp_hip_init(c, device, handle) bind(C, name="mckpp_hip_init") result(rc)
+      import :: c_int, c_ptr, mckpp_const_c
+      type(mckpp_const_c), intent(in) :: c
+      integer(c_int), value :: device
+      type(c_ptr), intent(out) :: handle
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_finalize(handle) bind(C, name="mckpp_hip_finalize") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int) :: rc
+    end function
+    subroutine mckpp_host_lookup(vonk, wmt, wst) bind(C, name="mckpp_host_lookup")
+      import :: c_double
+      real(c_double), value :: vonk
+      real(c_double), intent(out) :: wmt(*), wst(*)
+    end subroutine
+    subroutine mckpp_host_tri(nz, nztmax, dto, zm, hm, tri) bind(C, name="mckpp_host_tri")
+      import :: c_double, c_int32_t
+      integer(c_int32_t), value :: nz, nztmax
+      real(c_double), value :: dto
+      real(c_double), intent(in) :: zm(*), hm(*)
+      real(c_double), intent(out) :: tri(*)
+    end subroutine
+    function mckpp_hip_upload(handle, s) bind(C, name="mckpp_hip_upload") result(rc)
+      import :: c_int, c_ptr, mckpp_state_ptrs_c
+      type(c_ptr), value :: handle
+      type(mckpp_state_ptrs_c), intent(in) :: s
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_set_forcing(handle, sflux) bind(C, name="mckpp_hip_set_forcing") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: handle
+      real(c_double), intent(in) :: sflux(*)
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_set_diagnostics(handle, on) bind(C, name="mckpp_hip_set_diagnostics") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int), value :: on
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_init_ocean(handle, ntime) bind(C, name="mckpp_hip_init_ocean") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int), value :: ntime
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_step(handle, ntime, nsteps) bind(C, name="mckpp_hip_step") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int), value :: ntime, nsteps
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_synchronize(handle) bind(C, name="mckpp_hip_synchronize") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_download(handle, s, mask) bind(C, name="mckpp_hip_download") result(rc)
+      import :: c_int, c_ptr, c_int32_t, mckpp_state_ptrs_c
+      type(c_ptr), value :: handle
+      type(mckpp_state_ptrs_c), intent(inout) :: s
+      integer(c_int32_t), value :: mask
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_status(handle, per_col, n_flagged, npasses) bind(C, name="mckpp_hip_status") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle, per_col, n_flagged, npasses
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_last_kernel_ms(handle, ms, nlaunch) bind(C, name="mckpp_hip_last_kernel_ms") result(rc)
+      import :: c_int, c_ptr, c_double, c_int32_t
+      type(c_ptr), value :: handle
+      real(c_double), intent(out) :: ms
+      integer(c_int32_t), intent(out) :: nlaunch
+      integer(c_int) :: rc
+    end function
+  end interface
+
+contains
+
+  !> Text of the last error as a Fortran string.
+  function mckpp_hip_error_text() result(txt)
+    character(len=:), allocatable :: txt
+    character(kind=c_char), pointer :: p(:)
+    type(c_ptr) :: cp
+    integer :: n
+    cp = mckpp_hip_last_error()
+    txt = ''
+    if (.not. c_associated(cp)) return
+    call c_f_pointer(cp, p, [512])
+    n = 0
+    do while (n < 512)
+      if (p(n+1) == c_null_char) exit
+      n = n + 1
+    end do
+    allocate (character(len=n) :: txt)
+    txt = transfer(p(1:n), txt)
+  end function mckpp_hip_error_text
+
+end module mckpp_hip_binding

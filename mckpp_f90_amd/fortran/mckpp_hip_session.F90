@@ -1,0 +1,117 @@
+!> Device session behind the reference's call surface: owns the library handle,
+!! builds the C views of kpp_const_fields / kpp_3d_fields, and moves state
+!! between the Fortran arrays and HBM.  Errors from the library stop the run
+!! with the library's message (the reference's mckpp_abort convention,
+!! src/mckpp_abort_mod.F90:14) - there is no host fallback path.
+module mckpp_hip_session
+  use iso_c_binding
+  use mckpp_parameters
+  use mckpp_data_fields
+  use mckpp_hip_binding
+  implicit none
+  private
+  public :: mckpp_hip_attach, mckpp_hip_push_state, mckpp_hip_pull_state, mckpp_hip_detach
+  public :: mckpp_hip_handle, mckpp_hip_check, mckpp_hip_output_mask, mckpp_hip_device
+  public :: mckpp_hip_const_view, mckpp_hip_state_view, l2i
+
+  type(c_ptr), save :: mckpp_hip_handle = c_null_ptr
+  integer(c_int), save :: mckpp_hip_output_mask = MCKPP_F_ALL   !< fields copied back after each driver call
+  integer(c_int), save :: mckpp_hip_device = 0
+  logical, save :: resident = .false.
+
+contains
+
+  pure integer(c_int32_t) function l2i(l)
+    logical, intent(in) :: l
+    l2i = merge(1_c_int32_t, 0_c_int32_t, l)
+  end function l2i
+
+  subroutine mckpp_hip_check(rc, where)
+    integer(c_int), intent(in) :: rc
+    character(len=*), intent(in) :: where
+    if (rc /= 0) then
+      write (0, '(4a)') 'MCKPP-HIP ERROR in ', where, ': ', mckpp_hip_error_text()
+      error stop 1
+    end if
+  end subroutine mckpp_hip_check
+
+  subroutine mckpp_hip_const_view(k, c)
+    type(kpp_const_type), intent(in), target :: k
+    type(mckpp_const_c), intent(out) :: c
+    c%nz = nz; c%nztmax = nztmax; c%nsflxs = nsflxs; c%njdt = njdt; c%itermax = itermax
+    c%LKPP = l2i(k%LKPP); c%LRI = l2i(k%LRI); c%LDD = l2i(k%LDD); c%L_SSref = l2i(k%L_SSref)
+    c%L_RELAX_SST = l2i(k%L_RELAX_SST); c%L_RELAX_CALCONLY = l2i(k%L_RELAX_CALCONLY)
+    c%L_FCORR = l2i(k%L_FCORR); c%L_FCORR_WITHZ = l2i(k%L_FCORR_WITHZ)
+    c%L_SFCORR = l2i(k%L_SFCORR); c%L_SFCORR_WITHZ = l2i(k%L_SFCORR_WITHZ)
+    c%L_RELAX_SAL = l2i(k%L_RELAX_SAL); c%L_RELAX_OCNT = l2i(k%L_RELAX_OCNT)
+    c%L_NO_FREEZE = l2i(k%L_NO_FREEZE); c%L_NO_ISOTHERM = l2i(k%L_NO_ISOTHERM); c%L_DAMP_CURR = l2i(k%L_DAMP_CURR)
+    ! src/mckpp_physics_overrides.F90:57-58
+    c%clim_present = l2i(trim(k%ocnT_file) /= 'none' .and. trim(k%sal_file) /= 'none')
+    c%iso_bot = k%iso_bot; c%dt_uvdamp = k%dt_uvdamp
+    c%hmixtolfrac = hmixtolfrac; c%dto = k%dto; c%grav = k%grav; c%vonk = k%vonk; c%sice = k%sice
+    c%iso_thresh = k%iso_thresh
+    c%zm = c_loc(k%zm); c%hm = c_loc(k%hm); c%dm = c_loc(k%dm)
+    c%tri = c_loc(k%tri); c%wmt = c_loc(k%wmt); c%wst = c_loc(k%wst)
+  end subroutine mckpp_hip_const_view
+
+  subroutine mckpp_hip_state_view(f, n, s)
+    type(kpp_3d_type), intent(in), target :: f
+    integer, intent(in) :: n
+    type(mckpp_state_ptrs_c), intent(out) :: s
+    s%npts = n
+    s%U = c_loc(f%U); s%X = c_loc(f%X); s%Us = c_loc(f%Us); s%Xs = c_loc(f%Xs)
+    s%U_init = c_loc(f%U_init); s%hmixd = c_loc(f%hmixd)
+    s%f = c_loc(f%f); s%ocdepth = c_loc(f%ocdepth); s%Sref = c_loc(f%Sref); s%SSref = c_loc(f%SSref)
+    s%Ssurf = c_loc(f%Ssurf); s%hmix = c_loc(f%hmix); s%kmix = c_loc(f%kmix); s%Tref = c_loc(f%Tref)
+    s%uref = c_loc(f%uref); s%vref = c_loc(f%vref)
+    s%reset_flag = c_loc(f%reset_flag); s%dampu_flag = c_loc(f%dampu_flag)
+    s%dampv_flag = c_loc(f%dampv_flag); s%freeze_flag = c_loc(f%freeze_flag)
+    s%sflux = c_loc(f%sflux)
+    s%old = c_loc(f%old); s%new_ = c_loc(f%new); s%jerlov = c_loc(f%jerlov)
+    s%l_ocean = c_loc(f%l_ocean); s%l_initflag = c_loc(f%l_initflag); s%run_physics = c_loc(f%run_physics)
+    s%rho = c_loc(f%rho); s%cp = c_loc(f%cp); s%buoy = c_loc(f%buoy)
+    s%difm = c_loc(f%difm); s%difs = c_loc(f%difs); s%dift = c_loc(f%dift)
+    s%wU = c_loc(f%wU); s%wX = c_loc(f%wX); s%wXNT = c_loc(f%wXNT); s%ghat = c_loc(f%ghat)
+    s%Rig = c_loc(f%Rig); s%Shsq = c_loc(f%Shsq); s%dbloc = c_loc(f%dbloc)
+    s%swfrac = c_loc(f%swfrac); s%swdk_opt = c_loc(f%swdk_opt)
+  end subroutine mckpp_hip_state_view
+
+  !> Create the device context from kpp_const_fields (idempotent).
+  subroutine mckpp_hip_attach()
+    type(mckpp_const_c) :: c
+    if (c_associated(mckpp_hip_handle)) return
+    call mckpp_hip_const_view(kpp_const_fields, c)
+    call mckpp_hip_check(mckpp_hip_init(c, mckpp_hip_device, mckpp_hip_handle), 'mckpp_hip_init')
+  end subroutine mckpp_hip_attach
+
+  !> kpp_3d_fields -> HBM (once; afterwards the state lives on the device).
+  subroutine mckpp_hip_push_state(force)
+    logical, intent(in), optional :: force
+    type(mckpp_state_ptrs_c) :: s
+    logical :: doit
+    doit = .not. resident
+    if (present(force)) doit = doit .or. force
+    if (.not. doit) return
+    call mckpp_hip_attach()
+    call mckpp_hip_state_view(kpp_3d_fields, npts, s)
+    call mckpp_hip_check(mckpp_hip_upload(mckpp_hip_handle, s), 'mckpp_hip_upload')
+    resident = .true.
+  end subroutine mckpp_hip_push_state
+
+  !> HBM -> kpp_3d_fields for the selected field groups.
+  subroutine mckpp_hip_pull_state(mask)
+    integer(c_int), intent(in) :: mask
+    type(mckpp_state_ptrs_c) :: s
+    if (mask == 0) return
+    call mckpp_hip_state_view(kpp_3d_fields, npts, s)
+    call mckpp_hip_check(mckpp_hip_download(mckpp_hip_handle, s, int(mask, c_int32_t)), 'mckpp_hip_download')
+  end subroutine mckpp_hip_pull_state
+
+  subroutine mckpp_hip_detach()
+    integer(c_int) :: rc
+    if (c_associated(mckpp_hip_handle)) rc = mckpp_hip_finalize(mckpp_hip_handle)
+    mckpp_hip_handle = c_null_ptr
+    resident = .false.
+  end subroutine mckpp_hip_detach
+
+end module mckpp_hip_session

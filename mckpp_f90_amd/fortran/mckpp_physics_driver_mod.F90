@@ -1,0 +1,30 @@
+!> mckpp_physics_driver with the reference's interface: no arguments, works on
+!! the module globals kpp_3d_fields / kpp_const_fields and reads ntime
+!! (src/mckpp_physics_driver_mod.F90:15-73).  The OpenMP column loop with its
+!! per-column 3D<->1D copies is replaced by one kernel launch over all
+!! run_physics columns; state stays in HBM between calls and only the field
+!! groups in mckpp_hip_output_mask come back each step.
+module mckpp_physics_driver_mod
+  use iso_c_binding, only: c_int
+  use mckpp_data_fields, only: kpp_3d_fields, kpp_const_fields
+  use mckpp_hip_binding
+  use mckpp_hip_session
+  use mckpp_time_control, only: ntime
+  implicit none
+contains
+  subroutine mckpp_physics_driver()
+    call mckpp_hip_push_state()
+    ! forcing written by mckpp_fluxes into sflux(:,1:6,5,0) (src/mckpp_fluxes_mod.F90:62-69)
+    call mckpp_hip_check(mckpp_hip_set_forcing(mckpp_hip_handle, kpp_3d_fields%sflux), 'mckpp_hip_set_forcing')
+    call mckpp_hip_check(mckpp_hip_step(mckpp_hip_handle, int(ntime, c_int), 1_c_int), 'mckpp_hip_step')
+    call mckpp_hip_pull_state(mckpp_hip_output_mask)
+    if (kpp_const_fields%L_VARY_BOTTOM_TEMP) then
+      write (0, '(a)') 'MCKPP-HIP ERROR: L_VARY_BOTTOM_TEMP is not supported by the device path'
+      error stop 1
+    end if
+  end subroutine mckpp_physics_driver
+
+  subroutine mckpp_physics_finalize()
+    call mckpp_hip_detach()
+  end subroutine mckpp_physics_finalize
+end module mckpp_physics_driver_mod

@@ -1,0 +1,78 @@
+"""The Fortran host layer (mckpp_f90_amd/fortran): modules with the reference's
+names over the C-ABI, exercised by kpp_driver, a forced run shaped like the
+reference's main loop.  The GPU test feeds it the same bits as the C-ABI tests
+and requires bit-identical results; the CPU test checks that it builds and
+refuses to run without a device."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import common as cm
+
+DRIVER = os.path.join(cm.ROOT, "mckpp_f90_amd", "kpp_driver")
+
+
+def _write_case(path, kc, k3, sf6, nsteps, use_1d):
+    npts, nz = k3.npts, kc.nz
+    with open(path, "wb") as f:
+        np.array([npts, nz, nsteps, use_1d, kc.nztmax, 0, 0, 0], dtype=np.int32).tofile(f)
+        np.array([kc.dto]).tofile(f)
+        for a in (kc.zm, kc.hm, kc.dm):
+            np.asarray(a, dtype=np.float64).tofile(f)
+        for a in (k3.U, k3.X):
+            np.asarray(a).ravel(order="F").tofile(f)
+        for a in (k3.f, k3.Sref, k3.SSref, k3.Ssurf, k3.ocdepth):
+            np.asarray(a).tofile(f)
+        np.asarray(k3.jerlov, dtype=np.int32).tofile(f)
+        np.asarray(k3.run_physics, dtype=np.float64).tofile(f)
+        np.asarray(sf6).ravel(order="F").tofile(f)
+
+
+def _read_out(path, kc, npts):
+    nz, nzp1, nzt = kc.nz, kc.nzp1, kc.nztmax
+    out = {}
+    with open(path, "rb") as f:
+        def rd(shape, dt=np.float64):
+            n = int(np.prod(shape))
+            return np.fromfile(f, dtype=dt, count=n).reshape(shape, order="F")
+        out["U"] = rd((npts, nzp1, 2)); out["X"] = rd((npts, nzp1, 2))
+        out["Us"] = rd((npts, nzp1, 2, 2)); out["Xs"] = rd((npts, nzp1, 2, 2))
+        out["hmix"] = rd((npts,)); out["kmix"] = rd((npts,)); out["hmixd"] = rd((npts, 2))
+        out["Tref"] = rd((npts,)); out["Ssurf"] = rd((npts,))
+        out["old"] = rd((npts,), np.int32); out["new_"] = rd((npts,), np.int32)
+        out["difm"] = rd((npts, nzt + 1)); out["ghat"] = rd((npts, nzt)); out["rho"] = rd((npts, nzt + 2))
+    return out
+
+
+def test_fortran_layer_builds_and_fails_loudly_without_gpu(built, tmp_path):
+    import torch
+
+    assert os.path.exists(DRIVER), "kpp_driver not built (make -C mckpp_f90_amd/fortran)"
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    kc, k3 = cm.make_hip_case(8, 40)
+    _write_case(tmp_path / "case.bin", kc, k3, cm.synth.forcing(8), 1, 0)
+    r = subprocess.run([DRIVER, str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode != 0 and "MCKPP-HIP ERROR" in r.stderr
+    assert not os.path.exists(tmp_path / "out.bin")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ncol,nz,nsteps,use_1d,land", [(500, 60, 3, 0, 0), (96, 40, 2, 0, 4), (12, 40, 2, 1, 5)])
+def test_fortran_driver_matches_cabi_path(built, tmp_path, ncol, nz, nsteps, use_1d, land):
+    import mckpp_f90_amd as mk
+
+    kc, k3 = cm.make_hip_case(ncol, nz, land_every=land)
+    sf = cm.synth.forcing(ncol, "bench")
+    _write_case(tmp_path / "case.bin", kc, k3, sf, nsteps, use_1d)
+    r = subprocess.run([DRIVER, str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = _read_out(tmp_path / "out.bin", kc, ncol)
+    mk.mckpp_initialize_ocean_model(k3, kc)
+    cm.set_forcing_3d(k3, sf)
+    for nt in range(1, nsteps + 1):
+        mk.mckpp_physics_driver(k3, kc, nt)
+    for n in ("U", "X", "Us", "Xs", "hmix", "kmix", "hmixd", "Tref", "Ssurf", "old", "new_", "difm", "ghat", "rho"):
+        assert np.array_equal(got[n], getattr(k3, n)), n
