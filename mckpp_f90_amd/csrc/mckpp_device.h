@@ -46,6 +46,7 @@ struct mckpp_kparams {
   const double *U_init, *V_init;
   double *cs;
   int *ci;
+  int *qhead;   // column queue head for the persistent cooperative kernel (zeroed per launch)
   // diagnostics (all or none)
   double *rho, *cp, *buoy, *talpha, *sbeta, *difm, *difs, *dift, *ghat;
   double *wU1, *wU2, *wX1, *wX2, *wX3, *wXNT1, *Rig, *dbloc, *Shsq;
@@ -54,6 +55,8 @@ struct mckpp_kparams {
 // launchers (mckpp_kernels.hip)
 hipError_t mckpp_launch_column_kernel(const mckpp_kparams &p, hipStream_t stream);
 size_t mckpp_column_kernel_lds_bytes(int nzp1);
+// cooperative kernel (mckpp_kernels_wg.hip): W columns per workgroup, persistent grid
+hipError_t mckpp_launch_column_kernel_wg(const mckpp_kparams &p, int num_cu, hipStream_t stream);
 hipError_t mckpp_launch_eos_batch(int64_t n, const double *s, const double *t, const double *p,
                                   double *alpha, double *beta, double *sig0, double *cp,
                                   hipStream_t stream);

@@ -1,0 +1,882 @@
+// mckpp_kernels_wg.hip - cooperative column kernel.
+//
+// A workgroup of W wavefronts keeps W water columns in flight, one per wave
+// ("slot").  The level-parallel physics of a pass runs as in the one-wave
+// kernel (lane = grid level), but the serial recurrences of all W columns are
+// executed together by one wave with a lane per (column, system):
+//   * bulk-Ri running maximum (bldepth_mod.F90:137)      : W lanes
+//   * Thomas factorise + sweep for U, T, S (solvers.F90) : 3W lanes
+//   * Thomas sweep for V on the stored U factorisation   : W lanes
+// so their instruction stream is paid once per W columns instead of once per
+// column.  Tridiagonal coefficients are formed inside the sweep from the
+// diffusivity rows (tridcof, solvers.F90:14-44), which also removes nine LDS
+// rows per column.  Slots run in pass lock-step (six s_barriers per pass) but
+// are otherwise independent: each slot carries its own ocnstep iteration state
+// and, when its column has converged, stores it and pulls the next column
+// index from a global queue (persistent grid), so data-dependent pass counts
+// (6..200+) never leave a slot idle.
+//
+// Register diet: only the twelve profile values per level (iterate, old,
+// relaxation memory) plus talpha/sbeta live across phases; everything else
+// crosses phases through the slot's LDS rows or its LDS scalar record, and
+// per-column inputs are re-read with scalar loads where they are used.
+//
+// Arithmetic is identical, operation for operation, to k_column in
+// mckpp_kernels.hip; the tests require bit-identical results from both.
+#include "mckpp_colmath.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace {
+
+using namespace mckpp_dev;
+
+// per-slot LDS rows (each NA doubles, reference index = element index)
+enum { R_DM = 0, R_DT, R_DS, R_GH, R_YU, R_YT, R_YS, R_GM, R_GT, R_GS, R_BETM, R_YV, R_COUNT };
+// vmix scratch aliases (dead before the Thomas rows are built)
+enum { R_U = R_YU, R_V = R_YT, R_B = R_YS, R_R = R_GM, R_DB = R_GT, R_DMO = R_GS, R_T = R_BETM };
+
+enum { S_EMPTY = 0, S_ACTIVE = 1, S_DONE = 2 };
+
+// per-slot scalar record in LDS (wave-uniform values that cross phases)
+enum { C_B0 = 0, C_B0SOL, C_USTAR, C_WU01, C_WU02, C_WX01, C_WX02, C_WXNT0, C_UREFNZ, C_VREFNZ,
+       C_HBL, C_F, C_HMIXE, C_HMIXN, C_RHO0CP0, C_COUNT = 16 };
+
+template <int LPL>
+__host__ __device__ constexpr int wg_na() { return 64 * LPL + 3; }   // == 3 (mod 32): bank-spread rows
+template <int LPL>
+__host__ __device__ constexpr int wg_slot_stride()
+{
+  int s = R_COUNT * wg_na<LPL>();
+  while (s % 32 != 9) ++s;   // slot s, system m at offset 9s+3m (mod 32 doubles): all distinct
+  return s;
+}
+
+#define WAVE_LDS_SYNC()                                        \
+  do {                                                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");     \
+    __builtin_amdgcn_wave_barrier();                           \
+  } while (0)
+
+template <int LPL, int W, int MINW>
+__global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams p)
+{
+  extern __shared__ double lds[];
+  constexpr int NA = wg_na<LPL>();
+  constexpr int SS = wg_slot_stride<LPL>();
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nz = p.nz, nzp1 = p.nzp1;
+  double *c_zm = lds, *c_hm = lds + NA, *c_t0 = lds + 2 * NA, *c_t1 = lds + 3 * NA;
+  double *slots = lds + 4 * NA;
+  double *my = slots + wave * SS;
+  double *screc = slots + W * SS;   // [W][C_COUNT]
+  double *sc = screc + wave * C_COUNT;
+  int *sact = reinterpret_cast<int *>(screc + W * C_COUNT);
+  int *sbad = sact + W;
+  auto row = [&](int a) -> double * { return my + a * NA; };
+  double *aDm = row(R_DM), *aDs = row(R_DS), *aDt = row(R_DT), *aGh = row(R_GH);
+  double *aU = row(R_U), *aV = row(R_V), *aB = row(R_B), *aR = row(R_R), *aDb = row(R_DB),
+         *aDmo = row(R_DMO), *aT = row(R_T);
+
+  for (int i = threadIdx.x; i < NA; i += 64 * W) {
+    c_zm[i] = p.zm[i];
+    c_hm[i] = p.hm[i];
+    c_t0[i] = p.tri0[i];
+    c_t1[i] = p.tri1[i];
+  }
+  if (threadIdx.x < W) { sact[threadIdx.x] = 0; sbad[threadIdx.x] = 0; }
+  __syncthreads();
+
+  // ---- per-slot register state -------------------------------------------
+  double U[LPL], V[LPL], T[LPL], S[LPL];
+  double Uo[LPL], Vo[LPL], To[LPL], So[LPL];
+  double Ux[LPL], Vx[LPL], Tx[LPL], Sx[LPL];
+  double talpha[LPL], sbeta[LPL];
+  int kk[LPL];
+  bool act[LPL], actz[LPL];
+  FORJ {
+    int k = lane + 64 * j + 1;
+    kk[j] = k;
+    act[j] = k <= nzp1;
+    actz[j] = k <= nz;
+    U[j] = V[j] = T[j] = S[j] = 0.0;
+    Uo[j] = Vo[j] = To[j] = So[j] = 0.0;
+    Ux[j] = Vx[j] = Tx[j] = Sx[j] = 0.0;
+    talpha[j] = sbeta[j] = 0.0;
+  }
+  const int lane_nz = (nz - 1) & 63, j_nz = (nz - 1) >> 6;
+  const int lane_np = (nzp1 - 1) & 63, j_np = (nzp1 - 1) >> 6;
+  const int lane_v1 = nzp1 & 63, j_v1 = nzp1 >> 6;
+  const int lane_v2 = (nzp1 + 1) & 63, j_v2 = (nzp1 + 1) >> 6;
+
+  // wave-uniform column state (integers: scalar registers)
+  int state = S_EMPTY, col = 0;
+  int old = 0, newi = 1, jer = 3, l_initflag = 0, status = 0, npass = 0, npass_try = 0, iconv = 0;
+  int comp_flag = 0, kmixe = 0, kmixn = 0, kbl_pass = 0, nreset = 0;
+  const double lambda = 0.5;
+  const double epsln16 = 1.e-16, Ricr = 0.30, eps01 = 0.1, cekman = 0.7, cmonob = 1.0, epsln20 = 1.e-20;
+
+  auto bcast_level = [&](const double (&x)[LPL], int src_lane, int src_j) {
+    double v = 0;
+    FORJ { double a = bcast(x[j], src_lane); if (j == src_j) v = a; }
+    return v;
+  };
+  auto put = [&](int slot, double v) { if (lane == 0) sc[slot] = v; };
+  auto rowoff = [&]() -> size_t { return (size_t)col * p.ld; };
+  auto csrow = [&]() -> double * { return p.cs + (size_t)col * MCKPP_CS; };
+
+  // (re)start the semi-implicit iteration from the saved time levels, ocnstep_mod.F90:91-112
+  auto extrapolate = [&]() {
+    FORJ {
+      size_t o = rowoff() + lane + 64 * j;
+      double uo = act[j] ? p.Us[old][o] : 0.0, un = act[j] ? p.Us[newi][o] : 0.0;
+      double vo = act[j] ? p.Vs[old][o] : 0.0, vn = act[j] ? p.Vs[newi][o] : 0.0;
+      double to = act[j] ? p.Ts[old][o] : 0.0, tn = act[j] ? p.Ts[newi][o] : 0.0;
+      double so = act[j] ? p.Ss[old][o] : 0.0, sn = act[j] ? p.Ss[newi][o] : 0.0;
+      U[j] = 2. * un - uo; Ux[j] = U[j];
+      V[j] = 2. * vn - vo; Vx[j] = V[j];
+      T[j] = 2. * tn - to; Tx[j] = T[j];
+      S[j] = 2. * sn - so; Sx[j] = S[j];
+    }
+    npass_try = 0;
+    iconv = 0;
+  };
+
+  // pull the next column from the queue and load it
+  auto refill = [&]() {
+    int c = 0;
+    if (lane == 0) c = atomicAdd(p.qhead, 1);
+    c = __builtin_amdgcn_readfirstlane(c);
+    if (c >= p.ncol) { state = S_DONE; return; }
+    col = c;
+    state = S_ACTIVE;
+    const int *ci = p.ci + (size_t)col * MCKPP_CI;
+    old = ci[CI_OLD]; newi = ci[CI_NEW]; jer = ci[CI_JERLOV]; l_initflag = ci[CI_INITFLAG];
+    status = 0; npass = 0; comp_flag = 1; nreset = 0;
+    if (old < 0 || old > 1) { old = newi; status |= 16; }
+    if (newi < 0 || newi > 1) { newi = old; status |= 16; }
+    put(C_F, csrow()[CS_F]);
+    put(C_WXNT0, 0.0);
+    FORJ {
+      size_t o = rowoff() + lane + 64 * j;
+      U[j] = act[j] ? p.U[o] : 0.0; V[j] = act[j] ? p.V[o] : 0.0;
+      T[j] = act[j] ? p.T[o] : 0.0; S[j] = act[j] ? p.S[o] : 0.0;
+      Uo[j] = U[j]; Vo[j] = V[j]; To[j] = T[j]; So[j] = S[j];
+      Ux[j] = U[j]; Vx[j] = V[j]; Tx[j] = T[j]; Sx[j] = S[j];
+    }
+    if (p.mode == MCKPP_MODE_STEP) extrapolate();
+    if (p.mode == MCKPP_MODE_INIT) l_initflag = 1;   // initialize_ocean.F90:59
+  };
+
+  // is the coming pass possibly the last one of this column-step?  (diagnostics of the last
+  // vmix are what the reference leaves behind, so only such passes need to write them)
+  auto maybe_final = [&]() -> bool {
+    if (p.mode != MCKPP_MODE_STEP) return true;
+    return npass_try >= 3 && (iconv >= 2 || npass_try + 1 >= p.itermax);
+  };
+
+  // ---- phase A: EOS, surface fluxes, reference values, rimix, bulk-Ri pieces
+  auto phaseA = [&]() {
+    const double *cs = csrow();
+    const double Sref = cs[CS_SREF];
+    if (p.mode == MCKPP_MODE_STEP) {
+      FORJ {   // under-relaxation, ocnstep_mod.F90:123-132 / :142-151
+        U[j] = lambda * Ux[j] + (1 - lambda) * U[j]; Ux[j] = U[j];
+        V[j] = lambda * Vx[j] + (1 - lambda) * V[j]; Vx[j] = V[j];
+        T[j] = lambda * Tx[j] + (1 - lambda) * T[j]; Tx[j] = T[j];
+        S[j] = lambda * Sx[j] + (1 - lambda) * S[j]; Sx[j] = S[j];
+      }
+    }
+    const double zm1 = c_zm[1], zm_kmp1 = c_zm[nzp1];
+    double zmk[LPL], rho[LPL], cp[LPL], buoy[LPL];
+    const double T1 = first_lane(T[0]);
+    FORJ {
+      int k = kk[j];
+      zmk[j] = c_zm[k];
+      double Sin = S[j] + Sref, Tin = T[j], Pin = -zmk[j];
+      if (k == nzp1 + 1) { Sin = 0.0; Tin = T1; Pin = -zm1; }
+      if (k == nzp1 + 2) { Sin = p.sice; Tin = T1; Pin = -zm1; }
+      double al, be, s0;
+      abk80_dev(Sin, Tin, Pin, al, be, s0);
+      rho[j] = 1000. + s0;
+      cp[j] = cpsw_dev(Sin, Tin, Pin);
+      talpha[j] = al;
+      sbeta[j] = be;
+      buoy[j] = -p.grav * s0 / 1000.;
+    }
+    const double rhoh2o = bcast_level(rho, lane_v1, j_v1), rhob = bcast_level(rho, lane_v2, j_v2);
+    const double rho0 = first_lane(rho[0]), cp0 = first_lane(cp[0]);
+    const double talpha0 = first_lane(talpha[0]), sbeta0 = first_lane(sbeta[0]);
+    const double sflux1 = cs[CS_SFLUX1], sflux2 = cs[CS_SFLUX2], sflux3 = cs[CS_SFLUX3],
+                 sflux4 = cs[CS_SFLUX4], sflux5 = cs[CS_SFLUX5], sflux6 = cs[CS_SFLUX6];
+    const double Ssurf = cs[CS_SSURF];
+    const double wU0_1 = -sflux1 / rho0;   // verticalmixing_mod.F90:81-100
+    const double wU0_2 = -sflux2 / rho0;
+    const double tau = __builtin_sqrt(sflux1 * sflux1 + sflux2 * sflux2) + 1.e-16;
+    const double ustar = __builtin_sqrt(tau / rho0);
+    const double wX0_1 = -sflux4 / rho0 / cp0;
+    const double wX0_2 = Ssurf * sflux6 / rhoh2o + (Ssurf - p.sice) * sflux5 / rhob;
+    const double B0 = -p.grav * (talpha0 * wX0_1 - sbeta0 * wX0_2);
+    const double B0sol = p.grav * talpha0 * sflux3 / (rho0 * cp0);
+    const wscale_u wu = wscale_prepare(ustar);
+    if (lane == 0) {
+      sc[C_B0] = B0; sc[C_B0SOL] = B0sol; sc[C_USTAR] = ustar; sc[C_WU01] = wU0_1; sc[C_WU02] = wU0_2;
+      sc[C_WX01] = wX0_1; sc[C_WX02] = wX0_2; sc[C_RHO0CP0] = rho0 * cp0;
+      if (p.ntime >= 1)   // wXNT(0,1), fluxes_mod.F90:110-116
+        sc[C_WXNT0] = -sflux3 * p.swdk_tab[jer * p.ldc] / (rho0 * cp0);
+    }
+
+    FORJ if (act[j]) { aU[kk[j]] = U[j]; aV[kk[j]] = V[j]; aB[kk[j]] = buoy[j]; }
+    WAVE_LDS_SYNC();
+    double Ritop[LPL], dVsq[LPL], dbloc[LPL], shsq[LPL], Rig[LPL], zdiff[LPL];
+    {   // surface-layer reference values, verticalmixing_mod.F90:111-137
+      const double U1 = aU[1], V1 = aV[1], Bu1 = aB[1];
+      double zref[LPL], ur[LPL], vr[LPL], br[LPL];
+      bool live[LPL];
+      FORJ {
+        zref[j] = eps01 * zmk[j];
+        double wz = dmax2(zm1, zref[j]);
+        ur[j] = U1 * wz / zref[j];
+        vr[j] = V1 * wz / zref[j];
+        br[j] = Bu1 * wz / zref[j];
+        live[j] = actz[j];
+      }
+      double zk = zm1, Uk = U1, Vk = V1, Bk = Bu1;
+      for (int kl = 1; kl <= nz; ++kl) {
+        const double zk1 = c_zm[kl + 1], Uk1 = aU[kl + 1], Vk1 = aV[kl + 1], Bk1 = aB[kl + 1];
+        bool any = false;
+        FORJ {
+          live[j] = live[j] && !(zref[j] >= zk);
+          any = any || live[j];
+        }
+        if (!__any(any)) break;
+        FORJ if (live[j]) {
+          double wz = dmin2(zk - zk1, zk - zref[j]);
+          double del = 0.5 * wz / (zk - zk1);
+          ur[j] = ur[j] - wz * (Uk + del * (Uk1 - Uk)) / zref[j];
+          vr[j] = vr[j] - wz * (Vk + del * (Vk1 - Vk)) / zref[j];
+          br[j] = br[j] - wz * (Bk + del * (Bk1 - Bk)) / zref[j];
+        }
+        zk = zk1; Uk = Uk1; Vk = Vk1; Bk = Bk1;
+      }
+      FORJ {
+        int k = kk[j];
+        double bk1 = aB[k + 1], uk1 = aU[k + 1], vk1 = aV[k + 1];
+        Ritop[j] = (zref[j] - zmk[j]) * (br[j] - buoy[j]);
+        dbloc[j] = buoy[j] - bk1;
+        dVsq[j] = (ur[j] - U[j]) * (ur[j] - U[j]) + (vr[j] - V[j]) * (vr[j] - V[j]);
+        shsq[j] = (U[j] - uk1) * (U[j] - uk1) + (V[j] - vk1) * (V[j] - vk1);
+      }
+      if (p.mode != MCKPP_MODE_STEP) {
+        put(C_UREFNZ, bcast_level(ur, lane_nz, j_nz));
+        put(C_VREFNZ, bcast_level(vr, lane_nz, j_nz));
+      }
+    }
+    // rimix + z121 (rimix_mod.F90:13-106, z121_mod.F90:7-45)
+    FORJ {
+      int k = kk[j];
+      zdiff[j] = zmk[j] - c_zm[k + 1];
+      Rig[j] = dbloc[j] * zdiff[j] / (shsq[j] + 1.e-16);
+      if (actz[j]) { aR[k] = Rig[j]; aDb[k] = dbloc[j]; }
+      if (k == 1) aR[0] = 0.0;
+      if (k == nzp1) aR[k] = 0.0;
+    }
+    if (p.diag && maybe_final()) {   // what the last vmix leaves behind (types_transfer.F90:199-327)
+      FORJ {
+        int k = kk[j];
+        size_t o = rowoff() + k;
+        if (act[j]) { p.rho[o] = rho[j]; p.cp[o] = cp[j]; p.buoy[o] = buoy[j]; p.talpha[o] = talpha[j]; p.sbeta[o] = sbeta[j]; }
+        if (actz[j]) { p.Rig[o] = Rig[j]; p.dbloc[o] = dbloc[j]; p.Shsq[o] = shsq[j]; }
+        if (k == 1) { p.rho[o - 1] = rho[j]; p.cp[o - 1] = cp[j]; p.talpha[o - 1] = talpha[j]; p.sbeta[o - 1] = sbeta[j]; }
+      }
+    }
+    WAVE_LDS_SYNC();
+    double dm_i[LPL], ds_i[LPL];
+    FORJ {
+      int k = kk[j];
+      const double Riinfty = 0.8;
+      double vm1 = aR[k - 1], vp1 = aR[k + 1];
+      double wm1 = (k - 1 >= 1 && !((vm1 < 0.0) || (vm1 > Riinfty))) ? 1.0 : 0.0;
+      double wp1 = (k + 1 <= nz && !((vp1 < 0.0) || (vp1 > Riinfty))) ? 1.0 : 0.0;
+      double sm = wm1 * vm1 + 2. * Rig[j] + wp1 * vp1;
+      double wait = wm1 + 2.0 + wp1;
+      sm = sm / wait;
+      double Rigg = dmax2(sm, 0.0);
+      double ratio = dmin2(Rigg / Riinfty, 1.0);
+      double fri = (1.0 - ratio * ratio);
+      fri = fri * fri * fri;
+      dm_i[j] = (0.0001 + fri * 0.005);
+      ds_i[j] = (0.00001 + fri * 0.005);
+    }
+    WAVE_LDS_SYNC();
+    FORJ {   // interior diffusivities; dift == difs (rimix_mod.F90:95-97)
+      int k = kk[j];
+      if (actz[j]) { aDm[k] = dm_i[j]; aDs[k] = ds_i[j]; aDt[k] = ds_i[j]; }
+      if (k == nz) { aDm[k + 1] = dm_i[j]; aDs[k + 1] = ds_i[j]; aDt[k + 1] = ds_i[j]; }   // kppmix_mod.F90:82-84
+      if (k == 1) { aDm[0] = 0.0; aDs[0] = 0.0; aDt[0] = 0.0; }
+    }
+    // bldepth, level-parallel part (bldepth_mod.F90:105-147)
+    FORJ {
+      int k = kk[j];
+      double swf = p.swfrac_tab[jer * p.ldc + k];
+      double bf = B0 + B0sol * (1. - swf);
+      double st = 0.5 + dsign(0.5, bf + epsln16);
+      double sg = st * 1. + (1. - st) * eps01;
+      double wm, ws;
+      wscale_dev(p, wu, sg, -zmk[j], bf, wm, ws);
+      double dbm1 = aDb[k - 1];
+      double bvsq = 0.5 * (dbm1 / (c_zm[k - 1] - zmk[j]) + dbloc[j] / zdiff[j]);
+      double Vtsq = -zmk[j] * ws * __builtin_sqrt(__builtin_fabs(bvsq)) * p.Vtc;
+      double raw = Ritop[j] / (dVsq[j] + Vtsq + epsln16);
+      double dmo = cmonob * ustar * ustar * ustar / p.vonk / (__builtin_fabs(bf) + epsln16);
+      dmo = st * dmo - (1. - st) * zm_kmp1;
+      if (k >= 2 && actz[j]) { aR[k] = raw; aDmo[k] = dmo; }
+      if (k == 1) { aR[1] = 0.0; aDmo[1] = -zm_kmp1; }
+    }
+  };
+
+  // ---- phase C: hbl/kbl, blmix, enhance, combine, right-hand sides ---------
+  auto phaseC = [&](bool do_ocnint) {
+    const double *cs = csrow();
+    const double B0 = sc[C_B0], B0sol = sc[C_B0SOL], ustar = sc[C_USTAR], f = sc[C_F];
+    const double ocdepth = cs[CS_OCDEPTH];
+    const double zm_kmp1 = c_zm[nzp1];
+    const wscale_u wu = wscale_prepare(ustar);
+    const double hek = cekman * ustar / (__builtin_fabs(f) + epsln16);
+    double zmk[LPL];
+    FORJ zmk[j] = c_zm[kk[j]];
+    int kbl = nz;
+    double hbl = -c_zm[nz];
+    {
+      bool found = false;
+      FORJ {
+        int k = kk[j];
+        double swf = p.swfrac_tab[jer * p.ldc + k];
+        double bf = B0 + B0sol * (1. - swf);
+        double stab = 0.5 + dsign(0.5, bf + epsln16);
+        double Rka = aR[k - 1], Rku = aR[k], dmoa = aDmo[k - 1], dmou = aDmo[k];
+        double zkm1 = c_zm[k - 1];
+        double hri = -zkm1 + (zkm1 - zmk[j]) * (Ricr - Rka) / (Rku - Rka);
+        double hmonob;
+        if (dmou <= (-zmk[j])) {
+          hmonob = (dmou - dmoa) / (zkm1 - zmk[j]);
+          hmonob = (dmou + hmonob * zmk[j]) / (1. - hmonob);
+        } else {
+          hmonob = -zm_kmp1;
+        }
+        double hekman = stab * hek - (1. - stab) * zm_kmp1;
+        double hmin = dmin2(dmin2(dmin2(hri, hmonob), hekman), -ocdepth);
+        bool hit = (k >= 2) && actz[j] && (hmin < -zmk[j]);
+        if (hit && !l_initflag && (hmin < -zkm1)) {
+          double hmin2 = dmin2(dmin2(hri, hmonob), -ocdepth);
+          if (hmin2 < -zmk[j]) hmin = hmin2;
+        }
+        unsigned long long m = __ballot(hit);
+        if (!found && m != 0ull) {
+          int src = __ffsll((long long)m) - 1;
+          found = true;
+          kbl = src + 64 * j + 1;
+          hbl = bcast(hmin, src);
+        }
+      }
+    }
+    double bfsfc = swfrac_dev(-1.0, hbl, jer);
+    bfsfc = B0 + B0sol * (1. - bfsfc);
+    const double stable = 0.5 + dsign(0.5, bfsfc);
+    bfsfc = bfsfc + stable * epsln16;
+    const double caseA = 0.5 + dsign(0.5, -c_zm[kbl] - 0.5 * c_hm[kbl] - hbl);
+    double gat1[3], dat1[3], dkm1[3];
+    {
+      double wm, ws;
+      double sigma = stable * 1.0 + (1. - stable) * eps01;
+      wscale_dev(p, wu, sigma, hbl, bfsfc, wm, ws);
+      int ifx = (int)(caseA + epsln20);
+      int kn = ifx * (kbl - 1) + (1 - ifx) * kbl;
+      double hmkn = c_hm[kn], hmkn1 = c_hm[kn + 1];
+      double delhat = 0.5 * hmkn - c_zm[kn] - hbl;
+      double R = 1.0 - delhat / hmkn;
+      const double *dd[3] = {aDm, aDs, aDt};
+      double dp[3], dh[3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        double dvdzup = (dd[m][kn - 1] - dd[m][kn]) / hmkn;
+        double dvdzdn = (dd[m][kn] - dd[m][kn + 1]) / hmkn1;
+        dp[m] = 0.5 * ((1. - R) * (dvdzup + __builtin_fabs(dvdzup)) + R * (dvdzdn + __builtin_fabs(dvdzdn)));
+        dh[m] = dd[m][kn] + dp[m] * delhat;
+      }
+      double u4 = ((ustar * ustar) * ustar) * ustar;
+      double f1 = stable * 5.0 * bfsfc / (u4 + epsln20);
+      gat1[0] = dh[0] / hbl / (wm + epsln20);
+      dat1[0] = -dp[0] / (wm + epsln20) + f1 * dh[0];
+      dat1[0] = dmin2(dat1[0], 0.);
+      gat1[1] = dh[1] / hbl / (ws + epsln20);
+      dat1[1] = -dp[1] / (ws + epsln20) + f1 * dh[1];
+      dat1[1] = dmin2(dat1[1], 0.);
+      gat1[2] = dh[2] / hbl / (ws + epsln20);
+      dat1[2] = -dp[2] / (ws + epsln20) + f1 * dh[2];
+      dat1[2] = dmin2(dat1[2], 0.);
+    }
+    {
+      double wm, ws;
+      double sig = -c_zm[kbl - 1] / hbl;
+      double sigma = stable * sig + (1. - stable) * dmin2(sig, eps01);
+      wscale_dev(p, wu, sigma, hbl, bfsfc, wm, ws);
+      double a1 = sig - 2.;
+      double a2 = 3. - 2. * sig;
+      double a3 = sig - 1.;
+      double Gm = a1 + a2 * gat1[0] + a3 * dat1[0];
+      double Gs = a1 + a2 * gat1[1] + a3 * dat1[1];
+      double Gt = a1 + a2 * gat1[2] + a3 * dat1[2];
+      dkm1[0] = hbl * wm * sig * (1. + sig * Gm);
+      dkm1[1] = hbl * ws * sig * (1. + sig * Gs);
+      dkm1[2] = hbl * ws * sig * (1. + sig * Gt);
+    }
+    double difm[LPL], difs[LPL], dift[LPL], ghat[LPL];
+    FORJ {
+      int k = kk[j];
+      const double hk = c_hm[k];
+      const double dm_i = aDm[k], ds_i = aDs[k], dt_i = aDt[k];   // interior values of phase A
+      double wm, ws;
+      double sig = (-zmk[j] + 0.5 * hk) / hbl;
+      double sigma = stable * sig + (1. - stable) * dmin2(sig, eps01);
+      wscale_dev(p, wu, sigma, hbl, bfsfc, wm, ws);
+      double a1 = sig - 2.;
+      double a2 = 3. - 2. * sig;
+      double a3 = sig - 1.;
+      double Gm = a1 + a2 * gat1[0] + a3 * dat1[0];
+      double Gs = a1 + a2 * gat1[1] + a3 * dat1[1];
+      double Gt = a1 + a2 * gat1[2] + a3 * dat1[2];
+      double b0 = hbl * wm * sig * (1. + sig * Gm);
+      double b1 = hbl * ws * sig * (1. + sig * Gs);
+      double b2 = hbl * ws * sig * (1. + sig * Gt);
+      double gh = (1. - stable) * p.cg / (ws * hbl + epsln20);
+      if (k == kbl - 1 && k <= nz - 1) {   // enhance_mod.F90:10-51
+        double delta = (hbl + zmk[j]) / (zmk[j] - c_zm[k + 1]);
+        double omd = 1. - delta;
+        double dkmp5 = caseA * dm_i + (1. - caseA) * b0;
+        double dstar = (omd * omd) * dkm1[0] + (delta * delta) * dkmp5;
+        b0 = omd * dm_i + delta * dstar;
+        dkmp5 = caseA * ds_i + (1. - caseA) * b1;
+        dstar = (omd * omd) * dkm1[1] + (delta * delta) * dkmp5;
+        b1 = omd * ds_i + delta * dstar;
+        dkmp5 = caseA * dt_i + (1. - caseA) * b2;
+        dstar = (omd * omd) * dkm1[2] + (delta * delta) * dkmp5;
+        b2 = omd * dt_i + delta * dstar;
+        gh = (1. - caseA) * gh;
+      }
+      if (k < kbl) {   // kppmix_mod.F90:103-111
+        difm[j] = b0; difs[j] = b1; dift[j] = b2; ghat[j] = gh;
+      } else {
+        difm[j] = dm_i; difs[j] = ds_i; dift[j] = dt_i; ghat[j] = 0.;
+      }
+      if (k >= nz) {   // verticalmixing_mod.F90:151-159
+        difm[j] = 0.0001; difs[j] = 0.00001; dift[j] = 0.00001; ghat[j] = 0.0;
+      }
+    }
+    put(C_HBL, hbl);
+    kbl_pass = kbl;
+    // final diffusivities into the rows the Thomas lanes (and finalize) read
+    WAVE_LDS_SYNC();
+    FORJ if (act[j]) {
+      int k = kk[j];
+      aDm[k] = difm[j]; aDs[k] = difs[j]; aDt[k] = dift[j]; aGh[k] = ghat[j];
+    }
+    if (!do_ocnint) return;
+    WAVE_LDS_SYNC();
+    const double Uo_np = bcast_level(Uo, lane_np, j_np), To_np = bcast_level(To, lane_np, j_np),
+                 So_np = bcast_level(So, lane_np, j_np);
+    const double dto = p.dto, tri1_nz = c_t1[nz], hm1 = c_hm[1];
+    const double wU0_1 = sc[C_WU01], wX0_1 = sc[C_WX01], wX0_2 = sc[C_WX02], wXNT0 = sc[C_WXNT0];
+    const double rho0cp0 = sc[C_RHO0CP0], sflux3 = cs[CS_SFLUX3];
+    double *yU = row(R_YU), *yT = row(R_YT), *yS = row(R_YS);
+    FORJ {
+      int k = kk[j];
+      if (!actz[j]) continue;
+      const double dt_m1 = aDt[k - 1], ds_m1 = aDs[k - 1];
+      const double gh_m1 = (k >= 2) ? aGh[k - 1] : 0.0;
+      double wxnt = 0.0, wxnt_m1 = 0.0;   // wXNT(k,1), wXNT(k-1,1), fluxes_mod.F90:110-116
+      if (p.ntime >= 1) {
+        wxnt = -sflux3 * p.swdk_tab[jer * p.ldc + k] / rho0cp0;
+        wxnt_m1 = -sflux3 * p.swdk_tab[jer * p.ldc + k - 1] / rho0cp0;
+      }
+      double rhsU;   // ocnint_mod.F90:51-58
+      if (k == 1) rhsU = Uo[j] + dto * (f * .5 * (Vo[j] + V[j]) - wU0_1 / hm1);
+      else rhsU = Uo[j] + dto * f * .5 * (Vo[j] + V[j]);
+      if (k == nz) rhsU = rhsU + tri1_nz * difm[j] * Uo_np;
+      double rhsT;   // tridrhs, solvers.F90:53-107 (npd = 1)
+      const double hk = c_hm[k];
+      if (k == 1)
+        rhsT = To[j] + dto / hk * (wX0_1 * dift[j] * ghat[j] - wX0_1 * 1.0 + wxnt - wXNT0);
+      else
+        rhsT = To[j] + dto / hk * (wX0_1 * (dift[j] * ghat[j] - dt_m1 * gh_m1) + wxnt - wxnt_m1);
+      if (k == nz && nz > 1) rhsT = rhsT + To_np * tri1_nz * dift[j];
+      double rhsS;
+      if (k == 1)
+        rhsS = So[j] + dto / hk * (wX0_2 * difs[j] * ghat[j] - wX0_2 * 1.0 + 0.0 - 0.0);
+      else
+        rhsS = So[j] + dto / hk * (wX0_2 * (difs[j] * ghat[j] - ds_m1 * gh_m1) + 0.0 - 0.0);
+      if (k == nz && nz > 1) rhsS = rhsS + So_np * tri1_nz * difs[j];
+      yU[k] = rhsU; yT[k] = rhsT; yS[k] = rhsS;
+    }
+  };
+
+  // ---- phase E: collect U,T,S; V right-hand side (ocnint_mod.F90:62-69) ----
+  auto phaseE = [&]() {
+    const double *yU = row(R_YU), *yT = row(R_YT), *yS = row(R_YS);
+    double *yV = row(R_YV);
+    const double Vo_np = bcast_level(Vo, lane_np, j_np);
+    const double dto = p.dto, tri1_nz = c_t1[nz], hm1 = c_hm[1], f = sc[C_F], wU0_2 = sc[C_WU02];
+    FORJ {
+      int k = kk[j];
+      if (actz[j]) {
+        U[j] = yU[k]; T[j] = yT[k]; S[j] = yS[k];
+        double rhsV;
+        if (k == 1) rhsV = Vo[j] - dto * (f * .5 * (Uo[j] + U[j]) + wU0_2 / hm1);
+        else rhsV = Vo[j] - dto * f * .5 * (Uo[j] + U[j]);
+        if (k == nz) rhsV = rhsV + tri1_nz * aDm[k] * Vo_np;
+        yV[k] = rhsV;
+      } else if (act[j]) {   // yn(nzi+1) = yo(nzi+1), solvers.F90:159
+        U[j] = Uo[j]; T[j] = To[j]; S[j] = So[j];
+      }
+    }
+  };
+
+  // diagnostic fluxes (ocnstep_mod.F90:242-256 / initialize_ocean.F90:66-81) and stores
+  auto finalize = [&]() {
+    double *cs = csrow();
+    int *ci = p.ci + (size_t)col * MCKPP_CI;
+    const size_t ro = rowoff();
+    if (p.diag) {
+      const double wX0_1 = sc[C_WX01], wX0_2 = sc[C_WX02];
+      double *tU = row(R_YU), *tV = row(R_YT), *tT = row(R_YS), *tS = row(R_GM);
+      if (p.mode != MCKPP_MODE_PASS) {
+        WAVE_LDS_SYNC();
+        FORJ if (act[j]) { int k = kk[j]; tU[k] = U[j]; tV[k] = V[j]; tT[k] = T[j]; tS[k] = S[j]; }
+        WAVE_LDS_SYNC();
+      }
+      const double rho0cp0 = sc[C_RHO0CP0], sflux3 = cs[CS_SFLUX3];
+      FORJ {
+        int k = kk[j];
+        size_t o = ro + k;
+        const double dfm = aDm[k], dfs = aDs[k], dft = aDt[k], gh = aGh[k];
+        if (act[j]) { p.difm[o] = dfm; p.difs[o] = dfs; p.dift[o] = dft; }
+        if (actz[j]) {
+          p.ghat[o] = gh;
+          p.wXNT1[o] = (p.ntime >= 1) ? -sflux3 * p.swdk_tab[jer * p.ldc + k] / rho0cp0 : 0.0;
+          if (p.mode != MCKPP_MODE_PASS) {
+            double deltaz = 0.5 * (c_hm[k] + c_hm[k + 1]);
+            double uk1 = tU[k + 1], vk1 = tV[k + 1], tk1 = tT[k + 1], sk1 = tS[k + 1];
+            double wX1 = -dfs * ((T[j] - tk1) / deltaz - gh * wX0_1);
+            double wX2 = -dfs * ((S[j] - sk1) / deltaz - gh * wX0_2);
+            if (p.LDD) wX1 = -dft * ((T[j] - tk1) / deltaz - gh * wX0_1);
+            p.wX1[o] = wX1; p.wX2[o] = wX2;
+            p.wX3[o] = p.grav * (talpha[j] * wX1 - sbeta[j] * wX2);
+            p.wU1[o] = -dfm * (U[j] - uk1) / deltaz;
+            p.wU2[o] = -dfm * (V[j] - vk1) / deltaz;
+          }
+        }
+        if (k == 1) {   // index-0 entries
+          p.difm[ro] = 0.0; p.difs[ro] = 0.0; p.dift[ro] = 0.0;
+          p.wU1[ro] = sc[C_WU01]; p.wU2[ro] = sc[C_WU02];
+          p.wX1[ro] = wX0_1; p.wX2[ro] = wX0_2; p.wX3[ro] = -sc[C_B0];
+          p.wXNT1[ro] = sc[C_WXNT0];
+        }
+      }
+    }
+    if (p.mode == MCKPP_MODE_STEP) {
+      const double uref = first_lane(U[0]), vref = first_lane(V[0]), Tref = first_lane(T[0]);
+      double Ssurf;
+      if (p.L_SSref) Ssurf = cs[CS_SSREF];
+      else Ssurf = first_lane(S[0]) + cs[CS_SREF];
+      old = newi;
+      newi = 1 - old;
+      FORJ if (act[j]) {
+        size_t o = ro + lane + 64 * j;
+        p.Us[newi][o] = U[j]; p.Vs[newi][o] = V[j]; p.Ts[newi][o] = T[j]; p.Ss[newi][o] = S[j];
+      }
+      if (comp_flag) {   // overrides.F90:72-78
+        FORJ if (act[j]) {
+          size_t o = ro + lane + 64 * j;
+          U[j] = p.U_init[o];
+          V[j] = p.V_init[o];
+        }
+      }
+      FORJ if (act[j]) {
+        size_t o = ro + lane + 64 * j;
+        p.U[o] = U[j]; p.V[o] = V[j]; p.T[o] = T[j]; p.S[o] = S[j];
+      }
+      if (lane == 0) {
+        const double hmixn = sc[C_HMIXN];
+        cs[CS_HMIX] = hmixn;
+        cs[CS_KMIX] = (double)kmixn;
+        cs[CS_UREF] = uref; cs[CS_VREF] = vref; cs[CS_TREF] = Tref;
+        cs[CS_SSURF] = Ssurf;
+        cs[newi ? CS_HMIXD1 : CS_HMIXD0] = hmixn;
+        cs[CS_RESET] = 0.0;   // overrides.F90:121-123
+        cs[CS_DAMPU] = 0.0; cs[CS_DAMPV] = 0.0;
+        ci[CI_OLD] = old; ci[CI_NEW] = newi;
+        ci[CI_STATUS] = status; ci[CI_NPASS] = npass;
+      }
+    } else if (p.mode == MCKPP_MODE_INIT) {
+      const double Tref = first_lane(T[0]);
+      FORJ if (act[j]) {
+        size_t o = ro + lane + 64 * j;
+        p.Us[0][o] = U[j]; p.Us[1][o] = U[j]; p.Vs[0][o] = V[j]; p.Vs[1][o] = V[j];
+        p.Ts[0][o] = T[j]; p.Ts[1][o] = T[j]; p.Ss[0][o] = S[j]; p.Ss[1][o] = S[j];
+      }
+      if (lane == 0) {
+        const double hbl = sc[C_HBL];
+        cs[CS_HMIX] = hbl;
+        cs[CS_KMIX] = (double)kbl_pass;
+        cs[CS_TREF] = Tref;
+        cs[CS_UREF] = sc[C_UREFNZ]; cs[CS_VREF] = sc[C_VREFNZ];
+        cs[CS_HMIXD0] = hbl; cs[CS_HMIXD1] = hbl;
+        ci[CI_OLD] = 0; ci[CI_NEW] = 1; ci[CI_INITFLAG] = 0;
+        ci[CI_STATUS] = status; ci[CI_NPASS] = npass;
+      }
+    } else {
+      FORJ if (act[j]) {
+        size_t o = ro + lane + 64 * j;
+        p.U[o] = U[j]; p.V[o] = V[j]; p.T[o] = T[j]; p.S[o] = S[j];
+      }
+      if (lane == 0) {
+        cs[CS_HMIX] = sc[C_HBL];
+        cs[CS_KMIX] = (double)kbl_pass;
+        cs[CS_UREF] = sc[C_UREFNZ]; cs[CS_VREF] = sc[C_VREFNZ];
+        ci[CI_STATUS] = status; ci[CI_NPASS] = npass;
+      }
+    }
+    state = S_EMPTY;
+  };
+
+  // ---- phase G: collect V; ocnstep control (ocnstep_mod.F90:122-236) ----
+  auto phaseG = [&]() {
+    if (p.mode != MCKPP_MODE_INIT) {
+      const double *yV = row(R_YV);
+      FORJ {
+        if (actz[j]) V[j] = yV[kk[j]];
+        else if (act[j]) V[j] = Vo[j];
+      }
+      if (sbad[wave]) status |= 1;
+    }
+    ++npass;
+    if (p.mode != MCKPP_MODE_STEP) { finalize(); return; }
+    ++npass_try;
+    const double hbl = sc[C_HBL];
+    if (npass_try <= 3) {   // compulsory passes
+      put(C_HMIXE, hbl);
+      kmixe = kbl_pass;
+      return;
+    }
+    const double hmixn = hbl, hmixe = sc[C_HMIXE];
+    kmixn = kbl_pass;
+    put(C_HMIXN, hmixn);
+    double tol = p.hmixtolfrac * c_hm[kmixn];
+    if (kmixn == nzp1) tol = p.hmixtolfrac * c_hm[nz];
+    if (__builtin_fabs(hmixn - hmixe) > tol) iconv = 0;
+    else iconv = iconv + 1;
+    if (iconv < 3) {
+      if (npass_try < p.itermax) { put(C_HMIXE, hmixn); kmixe = kmixn; return; }
+      else if (hmixn > hmixe) { put(C_HMIXE, hmixn); kmixe = kmixn; return; }
+    }
+    if (npass_try > (p.itermax + 1)) status |= 2;
+    // instability trap
+    comp_flag = 0;
+    double f = sc[C_F];
+    WAVE_LDS_SYNC();
+    FORJ if (act[j]) aT[kk[j]] = T[j];
+    WAVE_LDS_SYNC();
+    int nviol = 0;
+    FORJ {
+      int k = kk[j];
+      double tk1 = aT[k + 1];
+      bool v = actz[j] && (__builtin_fabs(U[j]) >= 10 || __builtin_fabs(V[j]) >= 10 ||
+                           __builtin_fabs(T[j] - tk1) >= 10);
+      nviol += __popcll(__ballot(v));
+    }
+    if (nviol > 0) {
+      comp_flag = 1;
+      for (int i = 0; i < nviol; ++i) f = f * 1.01;
+    }
+    if (!comp_flag) {
+      double *t0 = row(R_YU), *t1 = row(R_YT), *t2 = row(R_YS), *t3 = row(R_GM);
+      WAVE_LDS_SYNC();
+      FORJ if (act[j]) {
+        int k = kk[j];
+        const double hk = c_hm[k];
+        t0[k] = (U[j] - Uo[j]) * (U[j] - Uo[j]) * hk / p.dm_nz;
+        t1[k] = (V[j] - Vo[j]) * (V[j] - Vo[j]) * hk / p.dm_nz;
+        t2[k] = (T[j] - To[j]) * (T[j] - To[j]) * hk / p.dm_nz;
+        t3[k] = (S[j] - So[j]) * (S[j] - So[j]) * hk / p.dm_nz;
+      }
+      WAVE_LDS_SYNC();
+      bool over = false;
+      if (lane < 4) {
+        const double *t = row(R_YU + lane);
+        double sum = 0.;
+        for (int k = 1; k <= nzp1; ++k) sum = sum + t[k];
+        sum = __builtin_sqrt(sum);
+        over = sum >= 1.0;
+      }
+      int nover = __popcll(__ballot(over));
+      if (nover > 0) {
+        comp_flag = 1;
+        for (int i = 0; i < nover; ++i) f = f * 1.01;
+      }
+    }
+    if (comp_flag) { status |= 4; put(C_F, f); }
+    nreset = nreset + 1;
+    if (nreset > 10) status |= 8;
+    if (comp_flag && nreset <= 10) { extrapolate(); return; }   // retry, ocnstep_mod.F90:89
+    finalize();
+  };
+
+  // ---- serial phases, one lane per (slot[, system]) ------------------------
+  auto scan_rib = [&]() {   // Rib(ku) = MAX(Rib(ku), Rib(ka)+epsln), bldepth_mod.F90:137
+    if (wave == 0 && lane < W && sact[lane]) {
+      double *r = slots + lane * SS + R_R * NA;
+      double rb = 0.0;
+      for (int k = 2; k <= nz; ++k) {
+        rb = dmax2(r[k], rb + epsln16);
+        r[k] = rb;
+      }
+    }
+  };
+  auto thomas_uts = [&]() {   // tridcof + tridmat, solvers.F90:14-44, 112-161
+    if (wave == 0 && lane < 3 * W) {
+      const int sl = lane / 3, sys = lane - 3 * sl;
+      if (sact[sl]) {
+        double *base = slots + sl * SS;
+        const double *d = base + (R_DM + sys) * NA;
+        double *y = base + (R_YU + sys) * NA, *gm = base + (R_GM + sys) * NA, *betm = base + R_BETM * NA;
+        int bad = 0;
+        double dm1 = d[1];
+        double bet = 1. + c_t1[1] * dm1;
+        double yy = y[1] / bet;
+        y[1] = yy;
+        if (sys == 0) betm[1] = bet;
+        for (int i = 2; i <= nz; ++i) {
+          const double di = d[i], t0 = c_t0[i], t1 = c_t1[i];
+          const double clm1 = -c_t1[i - 1] * dm1;
+          const double cu = -t0 * dm1;
+          const double cc = 1. + t1 * di + t0 * dm1;
+          double g = clm1 / bet;
+          bet = cc - cu * g;
+          if (bet == 0.) { bad = 1; bet = 1.E-12; }
+          yy = (y[i] - cu * yy) / bet;
+          gm[i] = g;
+          y[i] = yy;
+          if (sys == 0) betm[i] = bet;
+          dm1 = di;
+        }
+        for (int i = nz - 1; i >= 1; --i) {
+          yy = y[i] - gm[i + 1] * yy;
+          y[i] = yy;
+        }
+        if (bad) sbad[sl] = 1;
+      }
+    }
+  };
+  auto thomas_v = [&]() {
+    if (wave == 0 && lane < W && sact[lane]) {
+      double *base = slots + lane * SS;
+      const double *d = base + R_DM * NA, *gm = base + R_GM * NA, *betm = base + R_BETM * NA;
+      double *y = base + R_YV * NA;
+      double yy = y[1] / betm[1];
+      y[1] = yy;
+      double dm1 = d[1];
+      for (int i = 2; i <= nz; ++i) {
+        const double cu = -c_t0[i] * dm1;
+        yy = (y[i] - cu * yy) / betm[i];
+        y[i] = yy;
+        dm1 = d[i];
+      }
+      for (int i = nz - 1; i >= 1; --i) {
+        yy = y[i] - gm[i + 1] * yy;
+        y[i] = yy;
+      }
+    }
+  };
+
+  // ---- persistent pass loop -------------------------------------------------
+  const bool do_ocnint = p.mode != MCKPP_MODE_INIT;
+  for (;;) {
+    if (state == S_EMPTY) refill();
+    const bool active = state == S_ACTIVE;
+    if (lane == 0) { sact[wave] = active ? 1 : 0; sbad[wave] = 0; }
+    if (!__syncthreads_or(active ? 1 : 0)) break;
+    if (active) phaseA();
+    __syncthreads();
+    scan_rib();
+    __syncthreads();
+    if (active) phaseC(do_ocnint);
+    __syncthreads();
+    if (do_ocnint) thomas_uts();
+    __syncthreads();
+    if (active && do_ocnint) phaseE();
+    __syncthreads();
+    if (do_ocnint) thomas_v();
+    __syncthreads();
+    if (active) phaseG();
+  }
+}
+
+template <int LPL, int W>
+size_t wg_lds_bytes()
+{
+  return (size_t)(4 * wg_na<LPL>() + W * wg_slot_stride<LPL>() + W * C_COUNT) * sizeof(double) + 2 * W * sizeof(int);
+}
+
+template <int LPL, int W, int MINW>
+hipError_t launch_wg(const mckpp_kparams &p, int nblocks, hipStream_t stream)
+{
+  const size_t lds = wg_lds_bytes<LPL, W>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_column_wg<LPL, W, MINW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_column_wg<LPL, W, MINW>), dim3((unsigned)nblocks), dim3(64 * W), lds, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// Persistent grid: enough workgroups to fill every CU at the occupancy LDS and
+// registers allow, never more than there are W-column groups.
+// MCKPP_WG=<W>[x<blocks per CU>] overrides the geometry (experiments).
+hipError_t mckpp_launch_column_kernel_wg(const mckpp_kparams &p, int num_cu, hipStream_t stream)
+{
+  if (p.ncol <= 0) return hipSuccess;
+  const int lpl = (p.nzp1 + 2 + 63) / 64;
+  static int envW = -1, envB = 0;
+  if (envW < 0) {
+    envW = 0;
+    if (const char *e = getenv("MCKPP_WG")) {
+      int w = 0, b = 0;
+      if (sscanf(e, "%dx%d", &w, &b) >= 1) { envW = w; envB = b; }
+    }
+  }
+  int W, per_cu;
+  switch (lpl) {
+    case 1: W = 4; per_cu = 2; break;
+    case 2: W = 4; per_cu = 2; break;
+    default: W = 4; per_cu = 1; break;
+  }
+  if (lpl == 1 && (envW == 4 || envW == 8)) { W = envW; per_cu = (W == 8) ? 1 : 2; }
+  if (envB > 0) per_cu = envB;
+  int nblocks = num_cu * per_cu;
+  const int groups = (p.ncol + W - 1) / W;
+  if (nblocks > groups) nblocks = groups;
+  if (nblocks < 1) nblocks = 1;
+  switch (lpl) {
+    case 1: return (W == 8) ? launch_wg<1, 8, 2>(p, nblocks, stream) : launch_wg<1, 4, 2>(p, nblocks, stream);
+    case 2: return launch_wg<2, 4, 2>(p, nblocks, stream);
+    case 3: return launch_wg<3, 4, 1>(p, nblocks, stream);
+    default: return hipErrorInvalidValue;
+  }
+}

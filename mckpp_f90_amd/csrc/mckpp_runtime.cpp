@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -70,6 +71,9 @@ struct mckpp_hip_ctx {
   double *d_diag[D_COUNT] = {};
   double *d_cs = nullptr;
   int *d_ci = nullptr;
+  int *d_qhead = nullptr;
+  int num_cu = 256;
+  int kernel_variant = 2;   // 2: cooperative workgroup kernel, 1: one wave per column (MCKPP_KERNEL=v1)
   double *d_stage = nullptr;
   size_t stage_elems = 0;
   int diag = 1;
@@ -166,7 +170,10 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   h->lpl = lpl;
   h->ld = 64 * lpl;
   h->ldc = 64 * lpl + 8;
+  h->num_cu = prop.multiProcessorCount;
+  if (const char *kv = getenv("MCKPP_KERNEL")) h->kernel_variant = (strcmp(kv, "v1") == 0) ? 1 : 2;
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIPCHK(hipMalloc(&h->d_qhead, sizeof(int)));
   HIPCHK(hipEventCreate(&h->ev0));
   HIPCHK(hipEventCreate(&h->ev1));
 
@@ -239,7 +246,7 @@ int mckpp_hip_finalize(mckpp_hip_handle h)
   if (h->stream) hipStreamSynchronize(h->stream);
   free_state(h);
   hipFree(h->d_zm); hipFree(h->d_hm); hipFree(h->d_tri0); hipFree(h->d_tri1);
-  hipFree(h->d_swfrac_tab); hipFree(h->d_swdk_tab); hipFree(h->d_wtab);
+  hipFree(h->d_swfrac_tab); hipFree(h->d_swdk_tab); hipFree(h->d_wtab); hipFree(h->d_qhead);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -410,7 +417,7 @@ static void fill_params(mckpp_hip_ctx *h, mckpp_kparams &p, int ntime, int mode)
   p.Us[0] = h->d_prof[P_US0]; p.Us[1] = h->d_prof[P_US1]; p.Vs[0] = h->d_prof[P_VS0]; p.Vs[1] = h->d_prof[P_VS1];
   p.Ts[0] = h->d_prof[P_TS0]; p.Ts[1] = h->d_prof[P_TS1]; p.Ss[0] = h->d_prof[P_SS0]; p.Ss[1] = h->d_prof[P_SS1];
   p.U_init = h->d_prof[P_UINIT]; p.V_init = h->d_prof[P_VINIT];
-  p.cs = h->d_cs; p.ci = h->d_ci;
+  p.cs = h->d_cs; p.ci = h->d_ci; p.qhead = h->d_qhead;
   p.rho = h->d_diag[D_RHO]; p.cp = h->d_diag[D_CP]; p.buoy = h->d_diag[D_BUOY];
   p.talpha = h->d_diag[D_TALPHA]; p.sbeta = h->d_diag[D_SBETA];
   p.difm = h->d_diag[D_DIFM]; p.difs = h->d_diag[D_DIFS]; p.dift = h->d_diag[D_DIFT]; p.ghat = h->d_diag[D_GHAT];
@@ -428,7 +435,12 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode)
   for (int i = 0; i < nsteps; ++i) {
     mckpp_kparams p;
     fill_params(h, p, ntime + i, mode);
-    HIPCHK(mckpp_launch_column_kernel(p, h->stream));
+    if (h->kernel_variant == 1) {
+      HIPCHK(mckpp_launch_column_kernel(p, h->stream));
+    } else {
+      HIPCHK(hipMemsetAsync(h->d_qhead, 0, sizeof(int), h->stream));
+      HIPCHK(mckpp_launch_column_kernel_wg(p, h->num_cu, h->stream));
+    }
   }
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   h->nlaunch = nsteps;
