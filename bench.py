@@ -36,6 +36,29 @@ def alg_bytes_per_column_step(nz, diag):
     return b
 
 
+def host_cores():
+    """CPU cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(ncol_total, nz, warmup, nsteps, stride):
     """Oracle (CPU restatement, OpenMP over columns) on every `stride`-th column
     of the same workload: the same `warmup` untimed steps, then the same
@@ -46,10 +69,7 @@ def cpu_baseline(ncol_total, nz, warmup, nsteps, stride):
     idx = np.arange(0, ncol_total, stride)
     n = len(idx)
     oc, ob = cm.make_oracle(n, nz, mix="bench", exp_mode=1, index=idx, ntotal=ncol_total)
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        cores = os.cpu_count() or 1
+    cores = host_cores()
     for nt in range(1, warmup + 1):
         orc.physics_driver(oc, ob, nt, nthreads=cores)
     t0 = time.perf_counter()
@@ -90,13 +110,21 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     dist = None
+    # Rehearsal knobs (never set by the driver): MCKPP_BENCH_BACKEND=gloo runs the collectives on
+    # the CPU and MCKPP_BENCH_SHARE_GPU=1 puts every rank on device 0, so the N>1 code path can be
+    # exercised on a one-GPU box.
+    backend = os.environ.get("MCKPP_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("MCKPP_BENCH_SHARE_GPU") else local_rank
+    coll_dev = torch.device("cuda", dev_index) if backend == "nccl" else None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import common as cm
     import mckpp_f90_amd as mk
@@ -107,7 +135,7 @@ def main():
 
     idx = sharding.shard_indices(ntotal, rank, world)   # round-robin shard of one global closed-form set
     kc, k3 = cm.make_hip_case(ncol, nz, index=idx, ntotal=ntotal)
-    ctx = mk.MckppHip(kc, device=local_rank)
+    ctx = mk.MckppHip(kc, device=dev_index)
     ctx.upload(k3)
     ctx.set_diagnostics(a.diag)
     ctx.init_ocean(0)
@@ -132,12 +160,12 @@ def main():
 
     st, nflag, npass = ctx.status()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # diagnostics gather (not timed): hmix of every rank's columns to rank 0 over RCCL
         ctx.download(k3, mk.api.F_SCALARS)
-        parts = sharding.gather_to_root(k3.hmix, dist, device=torch.device("cuda", local_rank))
+        parts = sharding.gather_to_root(k3.hmix, dist, device=coll_dev)
         if rank == 0:
             hmix_all = sharding.unshard(parts, ntotal)
             assert np.isfinite(hmix_all).all() and hmix_all.shape == (ntotal,)
@@ -175,7 +203,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "k_column<1>" if nz + 3 <= 64 else "k_column<2>",
+                "kernel": "k_column_wg<LPL=%d> (cooperative, persistent)" % ((nz + 3 + 63) // 64),
                 "kernel_avg_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": balg * ncol,
             },
         }

@@ -135,6 +135,23 @@ __device__ __forceinline__ wscale_u wscale_prepare(double ustar)
   return w;
 }
 
+// same, with the (wave-uniform) results moved to scalar registers
+__device__ __forceinline__ double first_lane_d(double x)
+{
+  int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+  int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ wscale_u wscale_prepare_uniform(double ustar)
+{
+  wscale_u w = wscale_prepare(ustar);
+  w.ju = __builtin_amdgcn_readfirstlane(w.ju);
+  w.ufrac = first_lane_d(w.ufrac);
+  w.ustar = first_lane_d(w.ustar);
+  w.ucube = first_lane_d(w.ucube);
+  return w;
+}
+
 __device__ __forceinline__ void wscale_dev(const mckpp_kparams &p, const wscale_u &w, double sigma,
                                            double hbl, double bfsfc, double &wm, double &ws)
 {
@@ -175,5 +192,37 @@ __device__ __forceinline__ double swfrac_dev(double fact, double z, int jw)
   return rfac[jw] * mckpp_exp(r1) + (1. - rfac[jw]) * mckpp_exp(r2);
 }
 
+
+// ---------------------------------------------------------------------------
+// IEEE-754 correctly rounded fp64 division with the reciprocal refinement
+// factored out, so two quotients over one denominator (or a quotient whose
+// denominator is known long before its numerator) pay for it once and keep it
+// off the dependent chain.  This is the same instruction sequence the compiler
+// emits for `n / d` (v_div_scale, v_rcp, 4 fma, mul, fma, v_div_fmas,
+// v_div_fixup) split in two; when v_div_scale would rescale either operand
+// (never for the magnitudes on this path) it falls back to `n / d`, so the
+// result is the correctly rounded quotient in every case.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double rcp_refine(double d)
+{
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+
+__device__ __forceinline__ double div_by_refined(double n, double d, double r)
+{
+  bool f0, f1;
+  const double ds = __builtin_amdgcn_div_scale(n, d, false, &f0);
+  const double ns = __builtin_amdgcn_div_scale(n, d, true, &f1);
+  if (__builtin_expect(!(ds == d && ns == n), 0)) return n / d;
+  const double q = ns * r;
+  const double e = __builtin_fma(-d, q, ns);
+  const double res = __builtin_amdgcn_div_fmas(e, r, q, f1);
+  return __builtin_amdgcn_div_fixup(res, d, n);
+}
 
 }  // namespace mckpp_dev

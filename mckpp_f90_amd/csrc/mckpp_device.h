@@ -47,6 +47,7 @@ struct mckpp_kparams {
   double *cs;
   int *ci;
   int *qhead;   // column queue head for the persistent cooperative kernel (zeroed per launch)
+  unsigned long long *dbg;   // optional [16] phase-cycle accumulators (diagnostic builds of a run only)
   // diagnostics (all or none)
   double *rho, *cp, *buoy, *talpha, *sbeta, *difm, *difs, *dift, *ghat;
   double *wU1, *wU2, *wX1, *wX2, *wX3, *wXNT1, *Rig, *dbloc, *Shsq;

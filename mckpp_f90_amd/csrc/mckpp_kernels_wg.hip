@@ -33,7 +33,7 @@ namespace {
 using namespace mckpp_dev;
 
 // per-slot LDS rows (each NA doubles, reference index = element index)
-enum { R_DM = 0, R_DT, R_DS, R_GH, R_YU, R_YT, R_YS, R_GM, R_GT, R_GS, R_BETM, R_YV, R_COUNT };
+enum { R_DM = 0, R_DT, R_DS, R_GH, R_YU, R_YT, R_YS, R_GM, R_GT, R_GS, R_BETM, R_YV, R_RB, R_COUNT };
 // vmix scratch aliases (dead before the Thomas rows are built)
 enum { R_U = R_YU, R_V = R_YT, R_B = R_YS, R_R = R_GM, R_DB = R_GT, R_DMO = R_GS, R_T = R_BETM };
 
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
         S[j] = lambda * Sx[j] + (1 - lambda) * S[j]; Sx[j] = S[j];
       }
     }
-    const double zm1 = c_zm[1], zm_kmp1 = c_zm[nzp1];
+    const double zm1 = first_lane(c_zm[1]), zm_kmp1 = first_lane(c_zm[nzp1]);
     double zmk[LPL], rho[LPL], cp[LPL], buoy[LPL];
     const double T1 = first_lane(T[0]);
     FORJ {
@@ -206,21 +206,21 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       sbeta[j] = be;
       buoy[j] = -p.grav * s0 / 1000.;
     }
-    const double rhoh2o = bcast_level(rho, lane_v1, j_v1), rhob = bcast_level(rho, lane_v2, j_v2);
+    const double rhoh2o = first_lane(bcast_level(rho, lane_v1, j_v1)), rhob = first_lane(bcast_level(rho, lane_v2, j_v2));
     const double rho0 = first_lane(rho[0]), cp0 = first_lane(cp[0]);
     const double talpha0 = first_lane(talpha[0]), sbeta0 = first_lane(sbeta[0]);
     const double sflux1 = cs[CS_SFLUX1], sflux2 = cs[CS_SFLUX2], sflux3 = cs[CS_SFLUX3],
                  sflux4 = cs[CS_SFLUX4], sflux5 = cs[CS_SFLUX5], sflux6 = cs[CS_SFLUX6];
     const double Ssurf = cs[CS_SSURF];
-    const double wU0_1 = -sflux1 / rho0;   // verticalmixing_mod.F90:81-100
-    const double wU0_2 = -sflux2 / rho0;
+    const double wU0_1 = first_lane(-sflux1 / rho0);   // verticalmixing_mod.F90:81-100
+    const double wU0_2 = first_lane(-sflux2 / rho0);
     const double tau = __builtin_sqrt(sflux1 * sflux1 + sflux2 * sflux2) + 1.e-16;
-    const double ustar = __builtin_sqrt(tau / rho0);
-    const double wX0_1 = -sflux4 / rho0 / cp0;
-    const double wX0_2 = Ssurf * sflux6 / rhoh2o + (Ssurf - p.sice) * sflux5 / rhob;
-    const double B0 = -p.grav * (talpha0 * wX0_1 - sbeta0 * wX0_2);
-    const double B0sol = p.grav * talpha0 * sflux3 / (rho0 * cp0);
-    const wscale_u wu = wscale_prepare(ustar);
+    const double ustar = first_lane(__builtin_sqrt(tau / rho0));
+    const double wX0_1 = first_lane(-sflux4 / rho0 / cp0);
+    const double wX0_2 = first_lane(Ssurf * sflux6 / rhoh2o + (Ssurf - p.sice) * sflux5 / rhob);
+    const double B0 = first_lane(-p.grav * (talpha0 * wX0_1 - sbeta0 * wX0_2));
+    const double B0sol = first_lane(p.grav * talpha0 * sflux3 / (rho0 * cp0));
+    const wscale_u wu = wscale_prepare_uniform(ustar);
     if (lane == 0) {
       sc[C_B0] = B0; sc[C_B0SOL] = B0sol; sc[C_USTAR] = ustar; sc[C_WU01] = wU0_1; sc[C_WU02] = wU0_2;
       sc[C_WX01] = wX0_1; sc[C_WX02] = wX0_2; sc[C_RHO0CP0] = rho0 * cp0;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     WAVE_LDS_SYNC();
     double Ritop[LPL], dVsq[LPL], dbloc[LPL], shsq[LPL], Rig[LPL], zdiff[LPL];
     {   // surface-layer reference values, verticalmixing_mod.F90:111-137
-      const double U1 = aU[1], V1 = aV[1], Bu1 = aB[1];
+      const double U1 = first_lane(aU[1]), V1 = first_lane(aV[1]), Bu1 = first_lane(aB[1]);
       double zref[LPL], ur[LPL], vr[LPL], br[LPL];
       bool live[LPL];
       FORJ {
@@ -245,7 +245,8 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       }
       double zk = zm1, Uk = U1, Vk = V1, Bk = Bu1;
       for (int kl = 1; kl <= nz; ++kl) {
-        const double zk1 = c_zm[kl + 1], Uk1 = aU[kl + 1], Vk1 = aV[kl + 1], Bk1 = aB[kl + 1];
+        const double zk1 = first_lane(c_zm[kl + 1]), Uk1 = first_lane(aU[kl + 1]), Vk1 = first_lane(aV[kl + 1]),
+                     Bk1 = first_lane(aB[kl + 1]);
         bool any = false;
         FORJ {
           live[j] = live[j] && !(zref[j] >= zk);
@@ -340,15 +341,16 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
   // ---- phase C: hbl/kbl, blmix, enhance, combine, right-hand sides ---------
   auto phaseC = [&](bool do_ocnint) {
     const double *cs = csrow();
-    const double B0 = sc[C_B0], B0sol = sc[C_B0SOL], ustar = sc[C_USTAR], f = sc[C_F];
+    const double B0 = first_lane(sc[C_B0]), B0sol = first_lane(sc[C_B0SOL]), ustar = first_lane(sc[C_USTAR]),
+                 f = first_lane(sc[C_F]);
     const double ocdepth = cs[CS_OCDEPTH];
-    const double zm_kmp1 = c_zm[nzp1];
-    const wscale_u wu = wscale_prepare(ustar);
-    const double hek = cekman * ustar / (__builtin_fabs(f) + epsln16);
+    const double zm_kmp1 = first_lane(c_zm[nzp1]);
+    const wscale_u wu = wscale_prepare_uniform(ustar);
+    const double hek = first_lane(cekman * ustar / (__builtin_fabs(f) + epsln16));
     double zmk[LPL];
     FORJ zmk[j] = c_zm[kk[j]];
     int kbl = nz;
-    double hbl = -c_zm[nz];
+    double hbl = first_lane(-c_zm[nz]);
     {
       bool found = false;
       FORJ {
@@ -378,15 +380,15 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
           int src = __ffsll((long long)m) - 1;
           found = true;
           kbl = src + 64 * j + 1;
-          hbl = bcast(hmin, src);
+          hbl = first_lane(bcast(hmin, src));
         }
       }
     }
     double bfsfc = swfrac_dev(-1.0, hbl, jer);
     bfsfc = B0 + B0sol * (1. - bfsfc);
-    const double stable = 0.5 + dsign(0.5, bfsfc);
-    bfsfc = bfsfc + stable * epsln16;
-    const double caseA = 0.5 + dsign(0.5, -c_zm[kbl] - 0.5 * c_hm[kbl] - hbl);
+    const double stable = first_lane(0.5 + dsign(0.5, bfsfc));
+    bfsfc = first_lane(bfsfc + stable * epsln16);
+    const double caseA = first_lane(0.5 + dsign(0.5, -c_zm[kbl] - 0.5 * c_hm[kbl] - hbl));
     double gat1[3], dat1[3], dkm1[3];
     {
       double wm, ws;
@@ -417,6 +419,8 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       gat1[2] = dh[2] / hbl / (ws + epsln20);
       dat1[2] = -dp[2] / (ws + epsln20) + f1 * dh[2];
       dat1[2] = dmin2(dat1[2], 0.);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) { gat1[m] = first_lane(gat1[m]); dat1[m] = first_lane(dat1[m]); }
     }
     {
       double wm, ws;
@@ -429,9 +433,9 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       double Gm = a1 + a2 * gat1[0] + a3 * dat1[0];
       double Gs = a1 + a2 * gat1[1] + a3 * dat1[1];
       double Gt = a1 + a2 * gat1[2] + a3 * dat1[2];
-      dkm1[0] = hbl * wm * sig * (1. + sig * Gm);
-      dkm1[1] = hbl * ws * sig * (1. + sig * Gs);
-      dkm1[2] = hbl * ws * sig * (1. + sig * Gt);
+      dkm1[0] = first_lane(hbl * wm * sig * (1. + sig * Gm));
+      dkm1[1] = first_lane(hbl * ws * sig * (1. + sig * Gs));
+      dkm1[2] = first_lane(hbl * ws * sig * (1. + sig * Gt));
     }
     double difm[LPL], difs[LPL], dift[LPL], ghat[LPL];
     FORJ {
@@ -485,11 +489,12 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     }
     if (!do_ocnint) return;
     WAVE_LDS_SYNC();
-    const double Uo_np = bcast_level(Uo, lane_np, j_np), To_np = bcast_level(To, lane_np, j_np),
-                 So_np = bcast_level(So, lane_np, j_np);
-    const double dto = p.dto, tri1_nz = c_t1[nz], hm1 = c_hm[1];
-    const double wU0_1 = sc[C_WU01], wX0_1 = sc[C_WX01], wX0_2 = sc[C_WX02], wXNT0 = sc[C_WXNT0];
-    const double rho0cp0 = sc[C_RHO0CP0], sflux3 = cs[CS_SFLUX3];
+    const double Uo_np = first_lane(bcast_level(Uo, lane_np, j_np)), To_np = first_lane(bcast_level(To, lane_np, j_np)),
+                 So_np = first_lane(bcast_level(So, lane_np, j_np));
+    const double dto = p.dto, tri1_nz = first_lane(c_t1[nz]), hm1 = first_lane(c_hm[1]);
+    const double wU0_1 = first_lane(sc[C_WU01]), wX0_1 = first_lane(sc[C_WX01]), wX0_2 = first_lane(sc[C_WX02]),
+                 wXNT0 = first_lane(sc[C_WXNT0]);
+    const double rho0cp0 = first_lane(sc[C_RHO0CP0]), sflux3 = cs[CS_SFLUX3];
     double *yU = row(R_YU), *yT = row(R_YT), *yS = row(R_YS);
     FORJ {
       int k = kk[j];
@@ -526,8 +531,9 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
   auto phaseE = [&]() {
     const double *yU = row(R_YU), *yT = row(R_YT), *yS = row(R_YS);
     double *yV = row(R_YV);
-    const double Vo_np = bcast_level(Vo, lane_np, j_np);
-    const double dto = p.dto, tri1_nz = c_t1[nz], hm1 = c_hm[1], f = sc[C_F], wU0_2 = sc[C_WU02];
+    const double Vo_np = first_lane(bcast_level(Vo, lane_np, j_np));
+    const double dto = p.dto, tri1_nz = first_lane(c_t1[nz]), hm1 = first_lane(c_hm[1]), f = first_lane(sc[C_F]),
+                 wU0_2 = first_lane(sc[C_WU02]);
     FORJ {
       int k = kk[j];
       if (actz[j]) {
@@ -734,44 +740,76 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
   };
 
   // ---- serial phases, one lane per (slot[, system]) ------------------------
+  // The recurrences are latency chains, so operands are fetched one step ahead
+  // (loads never wait behind the chain) and every division uses a reciprocal
+  // refined off the chain (div_by_refined: same correctly rounded quotient).
   auto scan_rib = [&]() {   // Rib(ku) = MAX(Rib(ku), Rib(ka)+epsln), bldepth_mod.F90:137
     if (wave == 0 && lane < W && sact[lane]) {
       double *r = slots + lane * SS + R_R * NA;
       double rb = 0.0;
-      for (int k = 2; k <= nz; ++k) {
+      int k = 2;
+      for (; k + 3 <= nz; k += 4) {
+        const double a0 = r[k], a1 = r[k + 1], a2 = r[k + 2], a3 = r[k + 3];
+        rb = dmax2(a0, rb + epsln16); const double b0 = rb;
+        rb = dmax2(a1, rb + epsln16); const double b1 = rb;
+        rb = dmax2(a2, rb + epsln16); const double b2 = rb;
+        rb = dmax2(a3, rb + epsln16);
+        r[k] = b0; r[k + 1] = b1; r[k + 2] = b2; r[k + 3] = rb;
+      }
+      for (; k <= nz; ++k) {
         rb = dmax2(r[k], rb + epsln16);
         r[k] = rb;
       }
     }
   };
-  auto thomas_uts = [&]() {   // tridcof + tridmat, solvers.F90:14-44, 112-161
+  // tridcof + tridmat (solvers.F90:14-44, 112-161), skewed by one level: iteration i forms
+  // gam(i) = cl(i-1)/bet(i-1) and y(i-1) = num(i-1)/bet(i-1) over the same denominator.
+  auto thomas_uts = [&]() {
     if (wave == 0 && lane < 3 * W) {
       const int sl = lane / 3, sys = lane - 3 * sl;
       if (sact[sl]) {
         double *base = slots + sl * SS;
         const double *d = base + (R_DM + sys) * NA;
-        double *y = base + (R_YU + sys) * NA, *gm = base + (R_GM + sys) * NA, *betm = base + R_BETM * NA;
+        double *y = base + (R_YU + sys) * NA, *gm = base + (R_GM + sys) * NA;
+        double *betm = base + R_BETM * NA, *rbm = base + R_RB * NA;
         int bad = 0;
-        double dm1 = d[1];
-        double bet = 1. + c_t1[1] * dm1;
-        double yy = y[1] / bet;
-        y[1] = yy;
-        if (sys == 0) betm[1] = bet;
+        double dm1 = d[1], t1m1 = c_t1[1];
+        double bet = 1. + t1m1 * dm1;   // cc(1)
+        double ynum = y[1];             // y(1) = rhs(1)/bet, formed in the next iteration
+        double di_n = d[2], t0_n = c_t0[2], t1_n = c_t1[2], rhs_n = y[2];
         for (int i = 2; i <= nz; ++i) {
-          const double di = d[i], t0 = c_t0[i], t1 = c_t1[i];
-          const double clm1 = -c_t1[i - 1] * dm1;
+          const double di = di_n, t0 = t0_n, t1 = t1_n, rhs = rhs_n;
+          if (i < nz) { di_n = d[i + 1]; t0_n = c_t0[i + 1]; t1_n = c_t1[i + 1]; rhs_n = y[i + 1]; }
+          const double clm1 = -t1m1 * dm1;
           const double cu = -t0 * dm1;
           const double cc = 1. + t1 * di + t0 * dm1;
-          double g = clm1 / bet;
+          const double rb = rcp_refine(bet);
+          const double g = div_by_refined(clm1, bet, rb);
+          const double yprev = div_by_refined(ynum, bet, rb);
+          if (sys == 0) { betm[i - 1] = bet; rbm[i - 1] = rb; }
+          y[i - 1] = yprev;
+          gm[i] = g;
           bet = cc - cu * g;
           if (bet == 0.) { bad = 1; bet = 1.E-12; }
-          yy = (y[i] - cu * yy) / bet;
-          gm[i] = g;
-          y[i] = yy;
-          if (sys == 0) betm[i] = bet;
-          dm1 = di;
+          ynum = rhs - cu * yprev;
+          dm1 = di; t1m1 = t1;
         }
-        for (int i = nz - 1; i >= 1; --i) {
+        const double rbl = rcp_refine(bet);
+        double yy = div_by_refined(ynum, bet, rbl);
+        y[nz] = yy;
+        if (sys == 0) { betm[nz] = bet; rbm[nz] = rbl; }
+        // back substitution, operands fetched four levels ahead
+        int i = nz - 1;
+        for (; i >= 4; i -= 4) {
+          const double y0 = y[i], y1 = y[i - 1], y2 = y[i - 2], y3 = y[i - 3];
+          const double g0 = gm[i + 1], g1 = gm[i], g2 = gm[i - 1], g3 = gm[i - 2];
+          yy = y0 - g0 * yy; const double r0 = yy;
+          yy = y1 - g1 * yy; const double r1 = yy;
+          yy = y2 - g2 * yy; const double r2 = yy;
+          yy = y3 - g3 * yy;
+          y[i] = r0; y[i - 1] = r1; y[i - 2] = r2; y[i - 3] = yy;
+        }
+        for (; i >= 1; --i) {
           yy = y[i] - gm[i + 1] * yy;
           y[i] = yy;
         }
@@ -779,21 +817,35 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       }
     }
   };
-  auto thomas_v = [&]() {
+  auto thomas_v = [&]() {   // V on the stored momentum factorisation (bet, refined 1/bet, gam)
     if (wave == 0 && lane < W && sact[lane]) {
       double *base = slots + lane * SS;
-      const double *d = base + R_DM * NA, *gm = base + R_GM * NA, *betm = base + R_BETM * NA;
+      const double *d = base + R_DM * NA, *gm = base + R_GM * NA, *betm = base + R_BETM * NA,
+                   *rbm = base + R_RB * NA;
       double *y = base + R_YV * NA;
-      double yy = y[1] / betm[1];
+      double yy = div_by_refined(y[1], betm[1], rbm[1]);
       y[1] = yy;
       double dm1 = d[1];
+      double rhs_n = y[2], t0_n = c_t0[2], b_n = betm[2], r_n = rbm[2], d_n = d[2];
       for (int i = 2; i <= nz; ++i) {
-        const double cu = -c_t0[i] * dm1;
-        yy = (y[i] - cu * yy) / betm[i];
+        const double rhs = rhs_n, t0 = t0_n, b = b_n, r = r_n, di = d_n;
+        if (i < nz) { rhs_n = y[i + 1]; t0_n = c_t0[i + 1]; b_n = betm[i + 1]; r_n = rbm[i + 1]; d_n = d[i + 1]; }
+        const double cu = -t0 * dm1;
+        yy = div_by_refined(rhs - cu * yy, b, r);
         y[i] = yy;
-        dm1 = d[i];
+        dm1 = di;
       }
-      for (int i = nz - 1; i >= 1; --i) {
+      int i = nz - 1;
+      for (; i >= 4; i -= 4) {
+        const double y0 = y[i], y1 = y[i - 1], y2 = y[i - 2], y3 = y[i - 3];
+        const double g0 = gm[i + 1], g1 = gm[i], g2 = gm[i - 1], g3 = gm[i - 2];
+        yy = y0 - g0 * yy; const double r0 = yy;
+        yy = y1 - g1 * yy; const double r1 = yy;
+        yy = y2 - g2 * yy; const double r2 = yy;
+        yy = y3 - g3 * yy;
+        y[i] = r0; y[i - 1] = r1; y[i - 2] = r2; y[i - 3] = yy;
+      }
+      for (; i >= 1; --i) {
         yy = y[i] - gm[i + 1] * yy;
         y[i] = yy;
       }
@@ -801,26 +853,53 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
   };
 
   // ---- persistent pass loop -------------------------------------------------
+  // p.dbg != nullptr: wave 1 of every workgroup accumulates shader cycles per segment
+  // (0 refill, 1 A, 2 wait, 3 scan+wait, 4 C, 5 wait, 6 UTS+wait, 7 E, 8 wait, 9 V+wait, 10 G, 11 passes)
+  unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = p.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+#define STAMP(i)                                              \
+  do {                                                        \
+    if (p.dbg) {                                              \
+      unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+      tacc[i] += t_ - tlast;                                  \
+      tlast = t_;                                             \
+    }                                                         \
+  } while (0)
   const bool do_ocnint = p.mode != MCKPP_MODE_INIT;
   for (;;) {
     if (state == S_EMPTY) refill();
     const bool active = state == S_ACTIVE;
     if (lane == 0) { sact[wave] = active ? 1 : 0; sbad[wave] = 0; }
     if (!__syncthreads_or(active ? 1 : 0)) break;
+    STAMP(0);
     if (active) phaseA();
+    STAMP(1);
     __syncthreads();
+    STAMP(2);
     scan_rib();
     __syncthreads();
+    STAMP(3);
     if (active) phaseC(do_ocnint);
+    STAMP(4);
     __syncthreads();
+    STAMP(5);
     if (do_ocnint) thomas_uts();
     __syncthreads();
+    STAMP(6);
     if (active && do_ocnint) phaseE();
+    STAMP(7);
     __syncthreads();
+    STAMP(8);
     if (do_ocnint) thomas_v();
     __syncthreads();
+    STAMP(9);
     if (active) phaseG();
+    STAMP(10);
+    tacc[11] += 1;
   }
+  if (p.dbg && wave == 1 && lane == 0)
+    for (int i = 0; i < 12; ++i) atomicAdd(p.dbg + i, tacc[i]);
+#undef STAMP
 }
 
 template <int LPL, int W>
@@ -863,18 +942,23 @@ hipError_t mckpp_launch_column_kernel_wg(const mckpp_kparams &p, int num_cu, hip
   }
   int W, per_cu;
   switch (lpl) {
-    case 1: W = 4; per_cu = 2; break;
+    case 1: W = 4; per_cu = 5; break;   // 30.6 KB LDS and <=96 VGPRs per wave: 20 waves per CU
     case 2: W = 4; per_cu = 2; break;
     default: W = 4; per_cu = 1; break;
   }
-  if (lpl == 1 && (envW == 4 || envW == 8)) { W = envW; per_cu = (W == 8) ? 1 : 2; }
+  if (lpl == 1 && (envW == 4 || envW == 8)) { W = envW; per_cu = (W == 8) ? 2 : 5; }
   if (envB > 0) per_cu = envB;
   int nblocks = num_cu * per_cu;
   const int groups = (p.ncol + W - 1) / W;
   if (nblocks > groups) nblocks = groups;
   if (nblocks < 1) nblocks = 1;
   switch (lpl) {
-    case 1: return (W == 8) ? launch_wg<1, 8, 2>(p, nblocks, stream) : launch_wg<1, 4, 2>(p, nblocks, stream);
+    case 1:
+      if (W == 8) return (per_cu >= 2) ? launch_wg<1, 8, 4>(p, nblocks, stream) : launch_wg<1, 8, 2>(p, nblocks, stream);
+      if (per_cu >= 5) return launch_wg<1, 4, 5>(p, nblocks, stream);   // 96-VGPR build
+      if (per_cu >= 4) return launch_wg<1, 4, 4>(p, nblocks, stream);   // 128-VGPR build
+      if (per_cu == 3) return launch_wg<1, 4, 3>(p, nblocks, stream);   // 168-VGPR build
+      return launch_wg<1, 4, 2>(p, nblocks, stream);
     case 2: return launch_wg<2, 4, 2>(p, nblocks, stream);
     case 3: return launch_wg<3, 4, 1>(p, nblocks, stream);
     default: return hipErrorInvalidValue;

@@ -72,6 +72,7 @@ struct mckpp_hip_ctx {
   double *d_cs = nullptr;
   int *d_ci = nullptr;
   int *d_qhead = nullptr;
+  unsigned long long *d_dbg = nullptr;
   int num_cu = 256;
   int kernel_variant = 2;   // 2: cooperative workgroup kernel, 1: one wave per column (MCKPP_KERNEL=v1)
   double *d_stage = nullptr;
@@ -174,6 +175,10 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   if (const char *kv = getenv("MCKPP_KERNEL")) h->kernel_variant = (strcmp(kv, "v1") == 0) ? 1 : 2;
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipMalloc(&h->d_qhead, sizeof(int)));
+  if (getenv("MCKPP_STAMP")) {
+    HIPCHK(hipMalloc(&h->d_dbg, 16 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(h->d_dbg, 0, 16 * sizeof(unsigned long long)));
+  }
   HIPCHK(hipEventCreate(&h->ev0));
   HIPCHK(hipEventCreate(&h->ev1));
 
@@ -417,7 +422,7 @@ static void fill_params(mckpp_hip_ctx *h, mckpp_kparams &p, int ntime, int mode)
   p.Us[0] = h->d_prof[P_US0]; p.Us[1] = h->d_prof[P_US1]; p.Vs[0] = h->d_prof[P_VS0]; p.Vs[1] = h->d_prof[P_VS1];
   p.Ts[0] = h->d_prof[P_TS0]; p.Ts[1] = h->d_prof[P_TS1]; p.Ss[0] = h->d_prof[P_SS0]; p.Ss[1] = h->d_prof[P_SS1];
   p.U_init = h->d_prof[P_UINIT]; p.V_init = h->d_prof[P_VINIT];
-  p.cs = h->d_cs; p.ci = h->d_ci; p.qhead = h->d_qhead;
+  p.cs = h->d_cs; p.ci = h->d_ci; p.qhead = h->d_qhead; p.dbg = h->d_dbg;
   p.rho = h->d_diag[D_RHO]; p.cp = h->d_diag[D_CP]; p.buoy = h->d_diag[D_BUOY];
   p.talpha = h->d_diag[D_TALPHA]; p.sbeta = h->d_diag[D_SBETA];
   p.difm = h->d_diag[D_DIFM]; p.difs = h->d_diag[D_DIFS]; p.dift = h->d_diag[D_DIFT]; p.ghat = h->d_diag[D_GHAT];
@@ -461,6 +466,17 @@ int mckpp_hip_synchronize(mckpp_hip_handle h)
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->d_dbg) {   // MCKPP_STAMP=1: print and reset the per-segment cycle sums of wave 1 of every workgroup
+    unsigned long long t[16];
+    HIPCHK(hipMemcpy(t, h->d_dbg, sizeof t, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->d_dbg, 0, sizeof t));
+    if (t[11]) {
+      const char *nm[11] = {"refill", "A", "waitA", "scan", "C", "waitC", "UTS", "E", "waitE", "V", "G"};
+      fprintf(stderr, "[mckpp stamps] wave-passes %llu; cycles per wave-pass:", t[11]);
+      for (int i = 0; i < 11; ++i) fprintf(stderr, " %s=%.0f", nm[i], (double)t[i] / (double)t[11]);
+      fprintf(stderr, "\n");
+    }
+  }
   return 0;
 }
 
