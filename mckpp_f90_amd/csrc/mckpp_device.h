@@ -57,7 +57,9 @@ struct mckpp_kparams {
 hipError_t mckpp_launch_column_kernel(const mckpp_kparams &p, hipStream_t stream);
 size_t mckpp_column_kernel_lds_bytes(int nzp1);
 // cooperative kernel (mckpp_kernels_wg.hip): W columns per workgroup, persistent grid
-hipError_t mckpp_launch_column_kernel_wg(const mckpp_kparams &p, int num_cu, hipStream_t stream);
+// `dp` is a device copy of `p` (every field but ntime is read from it; ntime is passed by value)
+hipError_t mckpp_launch_column_kernel_wg(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu,
+                                         hipStream_t stream);
 hipError_t mckpp_launch_eos_batch(int64_t n, const double *s, const double *t, const double *p,
                                   double *alpha, double *beta, double *sig0, double *cp,
                                   hipStream_t stream);

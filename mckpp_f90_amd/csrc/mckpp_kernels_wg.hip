@@ -60,8 +60,11 @@ __host__ __device__ constexpr int wg_slot_stride()
   } while (0)
 
 template <int LPL, int W, int MINW>
-__global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams p)
+__global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams *__restrict__ pp, const int ntime)
 {
+  // the parameter block is read through the scalar cache where it is used: passing its ~60
+  // pointers by value pins >100 SGPRs for the whole kernel and turns into v_readlane traffic
+  const mckpp_kparams &p = *pp;
   extern __shared__ double lds[];
   constexpr int NA = wg_na<LPL>();
   constexpr int SS = wg_slot_stride<LPL>();
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     if (lane == 0) {
       sc[C_B0] = B0; sc[C_B0SOL] = B0sol; sc[C_USTAR] = ustar; sc[C_WU01] = wU0_1; sc[C_WU02] = wU0_2;
       sc[C_WX01] = wX0_1; sc[C_WX02] = wX0_2; sc[C_RHO0CP0] = rho0 * cp0;
-      if (p.ntime >= 1)   // wXNT(0,1), fluxes_mod.F90:110-116
+      if (ntime >= 1)   // wXNT(0,1), fluxes_mod.F90:110-116
         sc[C_WXNT0] = -sflux3 * p.swdk_tab[jer * p.ldc] / (rho0 * cp0);
     }
 
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       const double dt_m1 = aDt[k - 1], ds_m1 = aDs[k - 1];
       const double gh_m1 = (k >= 2) ? aGh[k - 1] : 0.0;
       double wxnt = 0.0, wxnt_m1 = 0.0;   // wXNT(k,1), wXNT(k-1,1), fluxes_mod.F90:110-116
-      if (p.ntime >= 1) {
+      if (ntime >= 1) {
         wxnt = -sflux3 * p.swdk_tab[jer * p.ldc + k] / rho0cp0;
         wxnt_m1 = -sflux3 * p.swdk_tab[jer * p.ldc + k - 1] / rho0cp0;
       }
@@ -570,7 +573,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
         if (act[j]) { p.difm[o] = dfm; p.difs[o] = dfs; p.dift[o] = dft; }
         if (actz[j]) {
           p.ghat[o] = gh;
-          p.wXNT1[o] = (p.ntime >= 1) ? -sflux3 * p.swdk_tab[jer * p.ldc + k] / rho0cp0 : 0.0;
+          p.wXNT1[o] = (ntime >= 1) ? -sflux3 * p.swdk_tab[jer * p.ldc + k] / rho0cp0 : 0.0;
           if (p.mode != MCKPP_MODE_PASS) {
             double deltaz = 0.5 * (c_hm[k] + c_hm[k + 1]);
             double uk1 = tU[k + 1], vk1 = tV[k + 1], tk1 = tT[k + 1], sk1 = tS[k + 1];
@@ -909,7 +912,7 @@ size_t wg_lds_bytes()
 }
 
 template <int LPL, int W, int MINW>
-hipError_t launch_wg(const mckpp_kparams &p, int nblocks, hipStream_t stream)
+hipError_t launch_wg(const mckpp_kparams &p, const mckpp_kparams *dp, int nblocks, hipStream_t stream)
 {
   const size_t lds = wg_lds_bytes<LPL, W>();
   static bool attr_set = false;
@@ -919,7 +922,7 @@ hipError_t launch_wg(const mckpp_kparams &p, int nblocks, hipStream_t stream)
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_column_wg<LPL, W, MINW>), dim3((unsigned)nblocks), dim3(64 * W), lds, stream, p);
+  hipLaunchKernelGGL((k_column_wg<LPL, W, MINW>), dim3((unsigned)nblocks), dim3(64 * W), lds, stream, dp, p.ntime);
   return hipGetLastError();
 }
 
@@ -928,7 +931,7 @@ hipError_t launch_wg(const mckpp_kparams &p, int nblocks, hipStream_t stream)
 // Persistent grid: enough workgroups to fill every CU at the occupancy LDS and
 // registers allow, never more than there are W-column groups.
 // MCKPP_WG=<W>[x<blocks per CU>] overrides the geometry (experiments).
-hipError_t mckpp_launch_column_kernel_wg(const mckpp_kparams &p, int num_cu, hipStream_t stream)
+hipError_t mckpp_launch_column_kernel_wg(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu, hipStream_t stream)
 {
   if (p.ncol <= 0) return hipSuccess;
   const int lpl = (p.nzp1 + 2 + 63) / 64;
@@ -954,13 +957,13 @@ hipError_t mckpp_launch_column_kernel_wg(const mckpp_kparams &p, int num_cu, hip
   if (nblocks < 1) nblocks = 1;
   switch (lpl) {
     case 1:
-      if (W == 8) return (per_cu >= 2) ? launch_wg<1, 8, 4>(p, nblocks, stream) : launch_wg<1, 8, 2>(p, nblocks, stream);
-      if (per_cu >= 5) return launch_wg<1, 4, 5>(p, nblocks, stream);   // 96-VGPR build
-      if (per_cu >= 4) return launch_wg<1, 4, 4>(p, nblocks, stream);   // 128-VGPR build
-      if (per_cu == 3) return launch_wg<1, 4, 3>(p, nblocks, stream);   // 168-VGPR build
-      return launch_wg<1, 4, 2>(p, nblocks, stream);
-    case 2: return launch_wg<2, 4, 2>(p, nblocks, stream);
-    case 3: return launch_wg<3, 4, 1>(p, nblocks, stream);
+      if (W == 8) return (per_cu >= 2) ? launch_wg<1, 8, 4>(p, dp, nblocks, stream) : launch_wg<1, 8, 2>(p, dp, nblocks, stream);
+      if (per_cu >= 5) return launch_wg<1, 4, 5>(p, dp, nblocks, stream);   // 96-VGPR build
+      if (per_cu >= 4) return launch_wg<1, 4, 4>(p, dp, nblocks, stream);   // 128-VGPR build
+      if (per_cu == 3) return launch_wg<1, 4, 3>(p, dp, nblocks, stream);   // 168-VGPR build
+      return launch_wg<1, 4, 2>(p, dp, nblocks, stream);
+    case 2: return launch_wg<2, 4, 2>(p, dp, nblocks, stream);
+    case 3: return launch_wg<3, 4, 1>(p, dp, nblocks, stream);
     default: return hipErrorInvalidValue;
   }
 }

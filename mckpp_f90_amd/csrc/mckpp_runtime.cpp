@@ -73,6 +73,7 @@ struct mckpp_hip_ctx {
   int *d_ci = nullptr;
   int *d_qhead = nullptr;
   unsigned long long *d_dbg = nullptr;
+  mckpp_kparams *d_params = nullptr;   // device copy of the kernel parameter block
   int num_cu = 256;
   int kernel_variant = 2;   // 2: cooperative workgroup kernel, 1: one wave per column (MCKPP_KERNEL=v1)
   double *d_stage = nullptr;
@@ -175,6 +176,7 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   if (const char *kv = getenv("MCKPP_KERNEL")) h->kernel_variant = (strcmp(kv, "v1") == 0) ? 1 : 2;
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipMalloc(&h->d_qhead, sizeof(int)));
+  HIPCHK(hipMalloc(&h->d_params, sizeof(mckpp_kparams)));
   if (getenv("MCKPP_STAMP")) {
     HIPCHK(hipMalloc(&h->d_dbg, 16 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(h->d_dbg, 0, 16 * sizeof(unsigned long long)));
@@ -251,7 +253,7 @@ int mckpp_hip_finalize(mckpp_hip_handle h)
   if (h->stream) hipStreamSynchronize(h->stream);
   free_state(h);
   hipFree(h->d_zm); hipFree(h->d_hm); hipFree(h->d_tri0); hipFree(h->d_tri1);
-  hipFree(h->d_swfrac_tab); hipFree(h->d_swdk_tab); hipFree(h->d_wtab); hipFree(h->d_qhead);
+  hipFree(h->d_swfrac_tab); hipFree(h->d_swdk_tab); hipFree(h->d_wtab); hipFree(h->d_qhead); hipFree(h->d_params);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -436,6 +438,12 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode)
   if (!h) return fail("null handle");
   if (h->ncol == 0) { h->nlaunch = 0; h->timed = false; return 0; }
   HIPCHK(hipSetDevice(h->device));
+  if (h->kernel_variant != 1) {   // parameter block (identical for every launch of this call but ntime)
+    mckpp_kparams p0;
+    fill_params(h, p0, ntime, mode);
+    HIPCHK(hipMemcpyAsync(h->d_params, &p0, sizeof p0, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));   // p0 is a stack object
+  }
   HIPCHK(hipEventRecord(h->ev0, h->stream));
   for (int i = 0; i < nsteps; ++i) {
     mckpp_kparams p;
@@ -444,7 +452,7 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode)
       HIPCHK(mckpp_launch_column_kernel(p, h->stream));
     } else {
       HIPCHK(hipMemsetAsync(h->d_qhead, 0, sizeof(int), h->stream));
-      HIPCHK(mckpp_launch_column_kernel_wg(p, h->num_cu, h->stream));
+      HIPCHK(mckpp_launch_column_kernel_wg(p, h->d_params, h->num_cu, h->stream));
     }
   }
   HIPCHK(hipEventRecord(h->ev1, h->stream));
