@@ -139,6 +139,16 @@ int mckpp_hip_upload(mckpp_hip_handle h, const mckpp_state_ptrs_c *s);
  * (src/mckpp_fluxes_mod.F90:62-69).  `sflux` is the full Fortran array. */
 int mckpp_hip_set_forcing(mckpp_hip_handle h, const double *sflux);
 
+/* mckpp_fluxes (src/mckpp_fluxes_mod.F90:35-89) on the device: assembles
+ * sflux(:,1:6,5,0) from the eight surface forcing fields (each npts, 3D
+ * ordering: taux,tauy,swf,lwf,lhf,shf,rain,snow; kpp_3d_type components of
+ * the same names, src/mckpp_data_fields.F90:76-83) for every l_ocean column
+ * and refreshes wXNT(:,1) like its mckpp_fluxes_ntflux call (:93-118).
+ * l_rest, flsn, el: kpp_const_fields%L_REST, %FLSN, %EL. */
+int mckpp_hip_fluxes(mckpp_hip_handle h, int ntime, const double *taux, const double *tauy,
+                     const double *swf, const double *lwf, const double *lhf, const double *shf,
+                     const double *rain, const double *snow, int l_rest, double flsn, double el);
+
 /* Enable/disable writing of the MCKPP_F_DIAG fields by step/init (default on). */
 int mckpp_hip_set_diagnostics(mckpp_hip_handle h, int on);
 
@@ -161,6 +171,14 @@ int mckpp_hip_synchronize(mckpp_hip_handle h);
 /* device -> 3D: scatter half of mckpp_fields_1dto3d
  * (src/mckpp_types_transfer.F90:199-327) for the fields selected. */
 int mckpp_hip_download(mckpp_hip_handle h, mckpp_state_ptrs_c *s, uint32_t field_mask);
+
+/* Restart set (reference: XIOS restart context, src/mckpp_xios_io.F90:368-387
+ * write list, :436-465 read path, cadence src/mckpp_xios_control.F90:61-83):
+ * U,V,T,S,CP,rho,hmix,kmix,Sref,SSref,Ssurf,Tref,old,new,Us,Vs,Ts,Ss,hmixd (and
+ * the column map) straight between HBM and a flat binary file.  load needs a
+ * context created with the same vertical grid; it replaces any resident state. */
+int mckpp_hip_save_restart(mckpp_hip_handle h, const char *path);
+int mckpp_hip_load_restart(mckpp_hip_handle h, const char *path);
 
 /* Per-column status words (npts entries in 3D ordering; land = 0), number of
  * columns with a non-zero word, and (optional) vmix+ocnint passes per column

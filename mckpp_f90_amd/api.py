@@ -85,6 +85,9 @@ def _bind(lib):
     lib.mckpp_hip_upload.argtypes = [C.c_void_p, C.POINTER(_StateC)]
     lib.mckpp_hip_set_forcing.argtypes = [C.c_void_p, _dp]
     lib.mckpp_hip_set_diagnostics.argtypes = [C.c_void_p, C.c_int]
+    lib.mckpp_hip_save_restart.argtypes = [C.c_void_p, C.c_char_p]
+    lib.mckpp_hip_load_restart.argtypes = [C.c_void_p, C.c_char_p]
+    lib.mckpp_hip_fluxes.argtypes = [C.c_void_p, C.c_int] + [_dp] * 8 + [C.c_int, C.c_double, C.c_double]
     lib.mckpp_hip_init_ocean.argtypes = [C.c_void_p, C.c_int]
     lib.mckpp_hip_step.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.mckpp_hip_vmix_pass.argtypes = [C.c_void_p, C.c_int]
@@ -248,6 +251,18 @@ class MckppHip:
     def set_forcing(self, sflux):
         assert sflux.flags["F_CONTIGUOUS"]
         _chk(_lib().mckpp_hip_set_forcing(self._h, sflux.ctypes.data_as(_dp)))
+
+    def fluxes(self, ntime, taux, tauy, swf, lwf, lhf, shf, rain, snow, l_rest=0, flsn=334000.0, el=2.5e6):
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (taux, tauy, swf, lwf, lhf, shf, rain, snow)]
+        _chk(_lib().mckpp_hip_fluxes(self._h, int(ntime), *[a.ctypes.data_as(_dp) for a in arrs], int(l_rest),
+                                     float(flsn), float(el)))
+
+    def save_restart(self, path):
+        _chk(_lib().mckpp_hip_save_restart(self._h, str(path).encode()))
+
+    def load_restart(self, path, npts):
+        _chk(_lib().mckpp_hip_load_restart(self._h, str(path).encode()))
+        self._npts_cache = npts
 
     def set_diagnostics(self, on):
         _chk(_lib().mckpp_hip_set_diagnostics(self._h, int(on)))

@@ -64,6 +64,8 @@ hipError_t mckpp_launch_eos_batch(int64_t n, const double *s, const double *t, c
                                   double *alpha, double *beta, double *sig0, double *cp,
                                   hipStream_t stream);
 hipError_t mckpp_launch_exp_batch(int64_t n, const double *x, double *y, hipStream_t stream);
+hipError_t mckpp_launch_fluxes(const mckpp_kparams &p, int ntime, const double *f8, int l_rest, double flsn,
+                               double el, hipStream_t stream);
 // layout kernels: Fortran (npts-fastest) <-> device rows
 hipError_t mckpp_launch_gather_rows(const double *src3d, int64_t npts, int nlev, int lev_off,
                                     const int *ipt, int64_t ncol, double *dst, int ld, int dst_off,

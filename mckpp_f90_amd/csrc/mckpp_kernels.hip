@@ -855,6 +855,43 @@ __global__ __launch_bounds__(256) void k_scatter_rows(const double *__restrict__
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Surface-flux assembly + non-turbulent flux: mckpp_fluxes,
+// src/mckpp_fluxes_mod.F90:35-89, and its ntflux call (:93-118).  One thread
+// per column; inputs are the eight forcing fields compacted to resident columns.
+// ---------------------------------------------------------------------------
+__global__ void k_fluxes(mckpp_kparams p, int ntime, const double *__restrict__ f8, int l_rest, double flsn,
+                         double el)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= p.ncol) return;
+  double *cs = p.cs + (size_t)c * MCKPP_CS;
+  const int *ci = p.ci + (size_t)c * MCKPP_CI;
+  if (!ci[CI_LOCEAN]) return;                                   // fluxes_mod.F90:55
+  const size_t n = (size_t)p.ncol;
+  double taux = f8[c], tauy = f8[n + c], swf = f8[2 * n + c], lwf = f8[3 * n + c], lhf = f8[4 * n + c],
+         shf = f8[5 * n + c], rain = f8[6 * n + c], snow = f8[7 * n + c];
+  if ((taux == 0.0) && (tauy == 0.0)) taux = 1.e-10;            // :57-58
+  double s1, s2, s3, s4, s5, s6;
+  if (!l_rest) {                                                // :60-69
+    s1 = taux; s2 = tauy; s3 = swf;
+    s4 = lwf + lhf + shf - snow * flsn;
+    s5 = 1e-10;
+    s6 = rain + snow + (lhf / el);
+  } else {                                                      // :70-77
+    s1 = 1.e-10; s2 = 0.00; s3 = 300.00; s4 = -300.00; s5 = 0.00; s6 = 0.00;
+  }
+  cs[CS_SFLUX1] = s1; cs[CS_SFLUX2] = s2; cs[CS_SFLUX3] = s3;
+  cs[CS_SFLUX4] = s4; cs[CS_SFLUX5] = s5; cs[CS_SFLUX6] = s6;
+  if (p.diag && ntime >= 1) {                                   // ntflux, :110-116
+    const size_t ro = (size_t)c * p.ld;
+    const double rho0 = p.rho[ro], cp0 = p.cp[ro];
+    const int jer = ci[CI_JERLOV];
+    for (int k = 0; k <= p.nz; ++k) p.wXNT1[ro + k] = -s3 * p.swdk_tab[jer * p.ldc + k] / (rho0 * cp0);
+  }
+}
+
 }  // namespace
 
 size_t mckpp_column_kernel_lds_bytes(int nzp1)
@@ -914,5 +951,14 @@ hipError_t mckpp_launch_scatter_rows(const double *src, int ld, int src_off, con
   dim3 grid((unsigned)((ncol + 63) / 64), (unsigned)((nlev + 63) / 64));
   hipLaunchKernelGGL(k_scatter_rows, grid, dim3(256), 0, stream, src, ld, src_off, ipt, ncol, dst3d,
                      npts, nlev, lev_off);
+  return hipGetLastError();
+}
+
+hipError_t mckpp_launch_fluxes(const mckpp_kparams &p, int ntime, const double *f8, int l_rest, double flsn,
+                               double el, hipStream_t stream)
+{
+  if (p.ncol <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_fluxes, dim3((unsigned)((p.ncol + 255) / 256)), dim3(256), 0, stream, p, ntime, f8, l_rest,
+                     flsn, el);
   return hipGetLastError();
 }

@@ -298,6 +298,8 @@ static int down_rows(mckpp_hip_ctx *h, const double *src, int src_off, int nlev,
   return 0;
 }
 
+static void fill_params(mckpp_hip_ctx *h, mckpp_kparams &p, int ntime, int mode);
+
 int mckpp_hip_upload(mckpp_hip_handle h, const mckpp_state_ptrs_c *s)
 {
   if (!h || !s) return fail("mckpp_hip_upload: null argument");
@@ -399,6 +401,29 @@ int mckpp_hip_set_forcing(mckpp_hip_handle h, const double *sflux)
     for (int m = 0; m < 6; ++m) f6[(size_t)c * 6 + m] = sflux[h->ipt[c] + fl_i * m + fl_5];
   HIPCHK(hipMemcpy2DAsync(h->d_cs + CS_SFLUX1, MCKPP_CS * sizeof(double), f6.data(), 6 * sizeof(double),
                           6 * sizeof(double), (size_t)h->ncol, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// mckpp_fluxes (src/mckpp_fluxes_mod.F90:35-89) on the device: eight forcing fields (npts each, 3D
+// ordering) -> sflux(:,1:6,5,0) of every resident l_ocean column, plus the ntflux refresh of wXNT(:,1).
+int mckpp_hip_fluxes(mckpp_hip_handle h, int ntime, const double *taux, const double *tauy, const double *swf,
+                     const double *lwf, const double *lhf, const double *shf, const double *rain,
+                     const double *snow, int l_rest, double flsn, double el)
+{
+  if (!h || !taux || !tauy || !swf || !lwf || !lhf || !shf || !rain || !snow)
+    return fail("mckpp_hip_fluxes: null argument");
+  if (h->ncol == 0) return 0;
+  HIPCHK(hipSetDevice(h->device));
+  const double *src[8] = {taux, tauy, swf, lwf, lhf, shf, rain, snow};
+  std::vector<double> f8((size_t)8 * h->ncol);
+  for (int m = 0; m < 8; ++m)
+    for (int64_t c = 0; c < h->ncol; ++c) f8[(size_t)m * h->ncol + c] = src[m][h->ipt[c]];
+  if (ensure_stage(h, f8.size())) return -1;
+  HIPCHK(hipMemcpyAsync(h->d_stage, f8.data(), f8.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  mckpp_kparams p;
+  fill_params(h, p, ntime, MCKPP_MODE_STEP);
+  HIPCHK(mckpp_launch_fluxes(p, ntime, h->d_stage, l_rest, flsn, el, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -561,6 +586,8 @@ int mckpp_hip_download(mckpp_hip_handle h, mckpp_state_ptrs_c *s, uint32_t mask)
         if (s->dampv_flag) s->dampv_flag[i] = r[CS_DAMPV];
         if (s->freeze_flag) s->freeze_flag[i] = r[CS_FREEZE];
         if (s->l_initflag) s->l_initflag[i] = q[CI_INITFLAG];
+        if (s->sflux)   // sflux(:,1:6,5,0) as assembled by mckpp_hip_fluxes / set_forcing
+          for (int m = 0; m < 6; ++m) s->sflux[i + npts * m + npts * (int64_t)h->c.nsflxs * 4] = r[CS_SFLUX1 + m];
       }
     }
   }
@@ -600,6 +627,102 @@ int mckpp_hip_download(mckpp_hip_handle h, mckpp_state_ptrs_c *s, uint32_t mask)
       }
     }
   }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Restart set.  The reference writes U,V,T,S,CP,rho,hmix,kmix,Sref,SSref,Ssurf,
+// Tref,old,new,Us,Vs,Ts,Ss,hmixd through XIOS (src/mckpp_xios_io.F90:368-387, 413-431) and reads
+// them back at :436-465; here the same set (the device-resident state) goes to a flat binary file.
+// ---------------------------------------------------------------------------
+namespace {
+struct restart_header {
+  char magic[8];
+  int32_t version, nz, ld, cs, ci, nprof;
+  int64_t npts, ncol;
+};
+const char kRestartMagic[8] = {'M', 'C', 'K', 'P', 'P', 'R', 'S', '1'};
+}  // namespace
+
+int mckpp_hip_save_restart(mckpp_hip_handle h, const char *path)
+{
+  if (!h || !path) return fail("mckpp_hip_save_restart: null argument");
+  if (h->ncol <= 0) return fail("mckpp_hip_save_restart: no resident columns");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  FILE *f = fopen(path, "wb");
+  if (!f) return fail("mckpp_hip_save_restart: cannot open %s", path);
+  restart_header hd{};
+  memcpy(hd.magic, kRestartMagic, 8);
+  hd.version = 1; hd.nz = h->nz; hd.ld = h->ld; hd.cs = MCKPP_CS; hd.ci = MCKPP_CI; hd.nprof = P_COUNT + 2;
+  hd.npts = h->npts; hd.ncol = h->ncol;
+  bool ok = fwrite(&hd, sizeof hd, 1, f) == 1;
+  ok = ok && fwrite(h->ipt.data(), sizeof(int), (size_t)h->ncol, f) == (size_t)h->ncol;
+  const size_t rowelems = (size_t)h->ncol * h->ld;
+  std::vector<double> buf(rowelems);
+  auto dump = [&](const double *d, size_t n) -> int {
+    if (n > buf.size()) buf.resize(n);
+    if (hipMemcpy(buf.data(), d, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return fwrite(buf.data(), sizeof(double), n, f) == n ? 0 : -1;
+  };
+  for (int i = 0; i < P_COUNT && ok; ++i) ok = dump(h->d_prof[i], rowelems) == 0;
+  ok = ok && dump(h->d_diag[D_CP], rowelems) == 0 && dump(h->d_diag[D_RHO], rowelems) == 0;
+  ok = ok && dump(h->d_cs, (size_t)h->ncol * MCKPP_CS) == 0;
+  std::vector<int> ci((size_t)h->ncol * MCKPP_CI);
+  ok = ok && hipMemcpy(ci.data(), h->d_ci, ci.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+  ok = ok && fwrite(ci.data(), sizeof(int), ci.size(), f) == ci.size();
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) return fail("mckpp_hip_save_restart: write to %s failed", path);
+  return 0;
+}
+
+int mckpp_hip_load_restart(mckpp_hip_handle h, const char *path)
+{
+  if (!h || !path) return fail("mckpp_hip_load_restart: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  FILE *f = fopen(path, "rb");
+  if (!f) return fail("mckpp_hip_load_restart: cannot open %s", path);
+  restart_header hd{};
+  if (fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, kRestartMagic, 8) != 0 || hd.version != 1) {
+    fclose(f);
+    return fail("mckpp_hip_load_restart: %s is not a restart file of this library", path);
+  }
+  if (hd.nz != h->nz || hd.ld != h->ld || hd.cs != MCKPP_CS || hd.ci != MCKPP_CI || hd.nprof != P_COUNT + 2 ||
+      hd.ncol <= 0 || hd.ncol > hd.npts) {
+    fclose(f);
+    return fail("mckpp_hip_load_restart: %s was written for nz=%d (context has nz=%d) or another layout", path,
+                hd.nz, h->nz);
+  }
+  std::vector<int> ipt((size_t)hd.ncol);
+  bool ok = fread(ipt.data(), sizeof(int), ipt.size(), f) == ipt.size();
+  if (ok && (hd.ncol != h->ncol || hd.npts != h->npts)) {
+    free_state(h);
+    h->npts = hd.npts;
+    h->ncol = hd.ncol;
+    const size_t rowbytes = (size_t)h->ncol * h->ld * sizeof(double);
+    for (auto &p : h->d_prof) { HIPCHK(hipMalloc(&p, rowbytes)); }
+    for (auto &p : h->d_diag) { HIPCHK(hipMalloc(&p, rowbytes)); HIPCHK(hipMemset(p, 0, rowbytes)); }
+    HIPCHK(hipMalloc(&h->d_cs, (size_t)h->ncol * MCKPP_CS * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_ci, (size_t)h->ncol * MCKPP_CI * sizeof(int)));
+    HIPCHK(hipMalloc(&h->d_ipt, (size_t)h->ncol * sizeof(int)));
+  }
+  h->ipt = ipt;
+  const size_t rowelems = (size_t)h->ncol * h->ld;
+  std::vector<double> buf(rowelems);
+  auto slurp = [&](double *d, size_t n) -> int {
+    if (n > buf.size()) buf.resize(n);
+    if (fread(buf.data(), sizeof(double), n, f) != n) return -1;
+    return hipMemcpy(d, buf.data(), n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+  };
+  ok = ok && hipMemcpy(h->d_ipt, ipt.data(), ipt.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+  for (int i = 0; i < P_COUNT && ok; ++i) ok = slurp(h->d_prof[i], rowelems) == 0;
+  ok = ok && slurp(h->d_diag[D_CP], rowelems) == 0 && slurp(h->d_diag[D_RHO], rowelems) == 0;
+  ok = ok && slurp(h->d_cs, (size_t)h->ncol * MCKPP_CS) == 0;
+  std::vector<int> ci((size_t)h->ncol * MCKPP_CI);
+  ok = ok && fread(ci.data(), sizeof(int), ci.size(), f) == ci.size();
+  ok = ok && hipMemcpy(h->d_ci, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+  fclose(f);
+  if (!ok) return fail("mckpp_hip_load_restart: %s is truncated or unreadable", path);
   return 0;
 }
 

@@ -20,6 +20,8 @@ module mckpp_data_fields
     real(c_double), allocatable :: reset_flag(:), dampu_flag(:), dampv_flag(:), freeze_flag(:)
     real(c_double), allocatable :: dlat(:), dlon(:)
     real(c_double), allocatable :: sflux(:,:,:,:)
+    ! surface forcing fields consumed by mckpp_fluxes (reference :76-83)
+    real(c_double), allocatable :: taux(:), tauy(:), swf(:), lwf(:), lhf(:), shf(:), rain(:), snow(:)
     integer(c_int), allocatable :: old(:), new(:), jerlov(:)
     logical(c_int), allocatable :: l_ocean(:), l_initflag(:), run_physics(:)
     ! what the last vmix / ocnint pass of a step leaves behind
@@ -53,6 +55,7 @@ module mckpp_data_fields
     logical :: L_SFCORR = .false., L_SFCORR_WITHZ = .false., L_RELAX_SAL = .false., L_RELAX_OCNT = .false.
     logical :: L_NO_FREEZE = .false., L_NO_ISOTHERM = .false., L_DAMP_CURR = .false.
     logical :: L_VARY_BOTTOM_TEMP = .false., L_RESTART = .false., L_STRETCHGRID = .false.
+    logical :: L_FLUXDATA = .false., L_REST = .false.
     character(len=200) :: ocnT_file = 'none', sal_file = 'none'
   end type kpp_const_type
 
@@ -69,6 +72,8 @@ contains
       allocate (s%hmix(npts), s%kmix(npts), s%Tref(npts), s%uref(npts), s%vref(npts))
       allocate (s%reset_flag(npts), s%dampu_flag(npts), s%dampv_flag(npts), s%freeze_flag(npts))
       allocate (s%dlat(npts), s%dlon(npts), s%sflux(npts,nsflxs,5,0:njdt))
+      allocate (s%taux(npts), s%tauy(npts), s%swf(npts), s%lwf(npts), s%lhf(npts), s%shf(npts), s%rain(npts), s%snow(npts))
+      s%taux = 0; s%tauy = 0; s%swf = 0; s%lwf = 0; s%lhf = 0; s%shf = 0; s%rain = 0; s%snow = 0
       allocate (s%old(npts), s%new(npts), s%jerlov(npts))
       allocate (s%l_ocean(npts), s%l_initflag(npts), s%run_physics(npts))
       allocate (s%rho(npts,0:nzp1tmax), s%cp(npts,0:nzp1tmax), s%buoy(npts,nzp1tmax))

@@ -77,6 +77,27 @@ module mckpp_hip_binding
       real(c_double), intent(in) :: sflux(*)
       integer(c_int) :: rc
     end function
+    function mckpp_hip_fluxes(handle, ntime, taux, tauy, swf, lwf, lhf, shf, rain, snow, l_rest, flsn, el) &
+        bind(C, name="mckpp_hip_fluxes") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: handle
+      integer(c_int), value :: ntime, l_rest
+      real(c_double), intent(in) :: taux(*), tauy(*), swf(*), lwf(*), lhf(*), shf(*), rain(*), snow(*)
+      real(c_double), value :: flsn, el
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_save_restart(handle, path) bind(C, name="mckpp_hip_save_restart") result(rc)
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value :: handle
+      character(kind=c_char), intent(in) :: path(*)
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_load_restart(handle, path) bind(C, name="mckpp_hip_load_restart") result(rc)
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value :: handle
+      character(kind=c_char), intent(in) :: path(*)
+      integer(c_int) :: rc
+    end function
     function mckpp_hip_set_diagnostics(handle, on) bind(C, name="mckpp_hip_set_diagnostics") result(rc)
       import :: c_int, c_ptr
       type(c_ptr), value :: handle

@@ -1494,3 +1494,31 @@ void orc_vmix_batch(const orc_const *c, orc_batch *b, int ntime, int nthreads)
     col_free(q);
   }
 }
+
+/* mckpp_fluxes.  mckpp_fluxes_mod.F90:35-89 (forcing arrays given, l_fluxdata semantics left to the caller) */
+void orc_fluxes(const orc_const *c, orc_batch *b, int ntime, const double *taux_in, const double *tauy,
+                const double *swf, const double *lwf, const double *lhf, const double *shf, const double *rain,
+                const double *snow, int l_rest, double flsn, double el)
+{
+  orc_col *q = col_new(c->nz);
+  for (long col = 0; col < b->ncol; col++) {
+    if (b->l_ocean && !b->l_ocean[col]) continue;            /* :55 */
+    double taux = taux_in[col];
+    if ((taux == 0.0) && (tauy[col] == 0.0)) taux = 1.e-10;  /* :57-58 */
+    double *sf = b->sflux + col * 6;
+    if (!l_rest) {                                           /* :60-69 */
+      sf[0] = taux;
+      sf[1] = tauy[col];
+      sf[2] = swf[col];
+      sf[3] = lwf[col] + lhf[col] + shf[col] - snow[col] * flsn;
+      sf[4] = 1e-10;
+      sf[5] = rain[col] + snow[col] + (lhf[col] / el);
+    } else {                                                 /* :70-77 */
+      sf[0] = 1.e-10; sf[1] = 0.00; sf[2] = 300.00; sf[3] = -300.00; sf[4] = 0.00; sf[5] = 0.00;
+    }
+    gather(c, b, col, q);                                    /* :80-82 */
+    ntflux(c, q, ntime);
+    scatter(c, b, col, q);
+  }
+  col_free(q);
+}

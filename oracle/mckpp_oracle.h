@@ -136,6 +136,10 @@ int orc_batch_set(orc_batch *b, const char *name, void *ptr);
 void orc_init_ocean(const orc_const *c, orc_batch *b, int ntime, int nthreads);
 /* mckpp_physics_driver (physics_driver_mod.F90:15-73): ocnstep + check_profile */
 void orc_physics_driver(const orc_const *c, orc_batch *b, int ntime, int nthreads);
+/* mckpp_fluxes (fluxes_mod.F90:35-89): sflux assembly + ntflux */
+void orc_fluxes(const orc_const *c, orc_batch *b, int ntime, const double *taux, const double *tauy,
+                const double *swf, const double *lwf, const double *lhf, const double *shf, const double *rain,
+                const double *snow, int l_rest, double flsn, double el);
 /* one vmix + ocnint pass on every column (config-2 style kernel-level check) */
 void orc_vmix_batch(const orc_const *c, orc_batch *b, int ntime, int nthreads);
 

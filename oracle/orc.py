@@ -88,6 +88,7 @@ def lib():
         L.orc_batch_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
         for fn in ("orc_init_ocean", "orc_physics_driver", "orc_vmix_batch"):
             getattr(L, fn).argtypes = [C.POINTER(OrcConst), C.c_void_p, C.c_int, C.c_int]
+        L.orc_fluxes.argtypes = [C.POINTER(OrcConst), C.c_void_p, C.c_int] + [C.POINTER(C.c_double)] * 8 + [C.c_int, C.c_double, C.c_double]
         _lib = L
     return _lib
 
@@ -244,3 +245,13 @@ def physics_driver(const, batch, ntime, nthreads=0):
 
 def vmix_batch(const, batch, ntime, nthreads=0):
     _run("orc_vmix_batch", const, batch, ntime, nthreads)
+
+
+def fluxes(const, batch, ntime, taux, tauy, swf, lwf, lhf, shf, rain, snow, l_rest=0, flsn=334000.0, el=2.5e6):
+    L = lib()
+    h = batch.handle()
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (taux, tauy, swf, lwf, lhf, shf, rain, snow)]
+    try:
+        L.orc_fluxes(const.ptr, h, int(ntime), *[_dp(a) for a in arrs], int(l_rest), float(flsn), float(el))
+    finally:
+        L.orc_batch_free(h)

@@ -193,3 +193,18 @@ def test_exp_mode_only_changes_last_bits():
     for k in ("T", "S", "U", "V"):
         d = np.abs(a[k][same_path] - b[k][same_path])
         assert d.max() < 1e-10, (k, d.max())
+
+
+def test_fluxes_assembly():
+    """mckpp_fluxes restatement: defaults of the no-flux-file branch (fluxes_mod.F90:41-49) reproduce
+    synth.forcing("baseline"); calm points get taux=1e-10; wXNT follows swdk_opt."""
+    n, nz = 5, 40
+    oc, ob = cm.make_oracle(n, nz, exp_mode=0)
+    one = np.ones(n)
+    orc.fluxes(oc, ob, 1, 0.01 * one, 0 * one, 200 * one, 0 * one, -150 * one, 0 * one, 6e-5 * one, 0 * one)
+    assert np.array_equal(ob["sflux"], cm.synth.forcing(n, "baseline"))
+    w = ob["wXNT1"][:, 0:nz + 1]
+    assert np.all(w[:, 0] < 0) and np.all(np.diff(np.abs(w), axis=1) < 0)       # decays with depth
+    assert np.allclose(w[:, 0], -200.0 / (ob["rho"][:, 0] * ob["cp"][:, 0]), rtol=1e-15)
+    orc.fluxes(oc, ob, 2, 0 * one, 0 * one, 200 * one, 0 * one, -150 * one, 0 * one, 6e-5 * one, 0 * one)
+    assert np.all(ob["sflux"][:, 0] == 1e-10)

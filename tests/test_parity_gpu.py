@@ -279,3 +279,67 @@ def test_full_size_properties_1e5x60(mk):
     for n in ("U", "X", "Us", "Xs", "hmixd", "hmix", "kmix", "Tref", "uref", "vref", "Ssurf", "reset_flag"):
         setattr(sub, n, getattr(k3, n)[idx])
     _assert_bitexact(cm.compare(sub, ob, nz, cm.PROFILE_FIELDS + cm.SCALAR_FIELDS + ["hmixd0", "hmixd1"]), "1e5 sample")
+
+
+def test_fluxes_on_device_n1(mk):
+    """mckpp_fluxes (src/mckpp_fluxes_mod.F90:35-89) assembled on the device, then a
+    step driven by those fluxes - bit-exact against the oracle's restatement of the same routine."""
+    from oracle import orc
+
+    ncol, nz = 600, 60
+    oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1)
+    kc, k3 = cm.make_hip_case(ncol, nz)
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    orc.init_ocean(oc, ob, 0)
+    rng = np.random.default_rng(20261003)
+    f = dict(taux=rng.uniform(-0.2, 0.3, ncol), tauy=rng.uniform(-0.1, 0.1, ncol), swf=rng.uniform(0, 800, ncol),
+             lwf=rng.uniform(-80, -20, ncol), lhf=rng.uniform(-300, 0, ncol), shf=rng.uniform(-40, 10, ncol),
+             rain=rng.uniform(0, 1e-4, ncol), snow=np.zeros(ncol))
+    f["taux"][:7] = 0.0
+    f["tauy"][:7] = 0.0                      # calm points get taux = 1e-10 (:57-58)
+    for nt in (1, 2):
+        ctx.fluxes(nt, **f)
+        orc.fluxes(oc, ob, nt, **f)
+        ctx.step(nt, 1)
+        ctx.download(k3)
+        orc.physics_driver(oc, ob, nt)
+        assert np.array_equal(k3.sflux[:, 0:6, 4, 0], ob["sflux"])
+        _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS), f"fluxes step {nt}")
+    # l_rest forcing (:70-77)
+    ctx.fluxes(3, l_rest=1, **f)
+    orc.fluxes(oc, ob, 3, l_rest=1, **f)
+    ctx.download(k3, mk.api.F_SCALARS | mk.api.F_DIAG)
+    assert np.array_equal(k3.sflux[:, 0:6, 4, 0], ob["sflux"]) and np.all(k3.sflux[:, 2, 4, 0] == 300.0)
+    _assert_bitexact(cm.compare(k3, ob, nz, ["wXNT1"]), "ntflux after l_rest fluxes")
+
+
+def test_restart_roundtrip_n2(mk, tmp_path):
+    """save the restart set after 2 steps, continue 2 steps; a fresh context that
+    loads the file and runs the same 2 steps ends bit-identical (state, saved levels, old/new)."""
+    ncol, nz = 400, 60
+    kc, k3 = cm.make_hip_case(ncol, nz, land_every=5)
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    sf = cm.synth.forcing(ncol, "bench")
+    cm.set_forcing_3d(k3, sf)
+    ctx.set_forcing(k3.sflux)
+    ctx.step(1, 2)
+    rst = tmp_path / "kpp.restart"
+    ctx.save_restart(rst)
+    ctx.step(3, 2)
+    ctx.download(k3)
+    kc2, k3b = cm.make_hip_case(ncol, nz, land_every=5)
+    ctx2 = mk.MckppHip(kc2)
+    ctx2.load_restart(rst, ncol)
+    assert ctx2.ncolumns == ctx.ncolumns
+    ctx2.step(3, 2)
+    ctx2.download(k3b)
+    for n in ("U", "X", "Us", "Xs", "hmixd", "hmix", "kmix", "Tref", "Ssurf", "old", "new_", "difm", "wX"):
+        assert np.array_equal(getattr(k3, n), getattr(k3b, n)), n
+    bad = tmp_path / "junk"
+    bad.write_bytes(b"not a restart")
+    with pytest.raises(mk.MckppHipError, match="not a restart"):
+        ctx2.load_restart(bad, ncol)
+    kc3, _ = cm.make_hip_case(4, 40)
+    with pytest.raises(mk.MckppHipError, match="nz=60"):
+        mk.MckppHip(kc3).load_restart(rst, ncol)
+    ctx2.close()
