@@ -59,6 +59,8 @@ typedef struct mckpp_const_c {
   int32_t L_NO_FREEZE, L_NO_ISOTHERM, L_DAMP_CURR;
   int32_t clim_present; /* ocnT_file/='none' .and. sal_file/='none'   */
   int32_t iso_bot, dt_uvdamp;
+  int32_t maxmodeadv; /* second extent of modeadv/advection (6)       */
+  int32_t L_ADVECT;   /* prescribed advection on (src/mckpp_initialize_advection_mod.F90:65: nmodeadv=0 otherwise) */
   double hmixtolfrac, dto, grav, vonk, sice, iso_thresh;
   const double *zm;  /* zm(nzp1)                                      */
   const double *hm;  /* hm(nzp1)                                      */
@@ -98,6 +100,15 @@ typedef struct mckpp_state_ptrs_c {
   double *dbloc;              /* (npts,nz)                             */
   double *swfrac;             /* (npts,nzp1)                           */
   double *swdk_opt;           /* (npts,0:nz)                           */
+  /* optional forcing corrections / relaxation (src/mckpp_physics_ocnint_mod.F90:97-215,
+   * src/mckpp_physics_overrides.F90:42-125); only read when the matching switch is on */
+  double *relax_sst, *SST0, *fcorr_twod, *relax_sal, *relax_ocnT; /* (npts)        */
+  double *fcorr;              /* (npts) out: diagnosed surface flux correction    */
+  double *fcorr_withz, *sfcorr_withz, *ocnT_clim, *sal_clim;      /* (npts,nzp1)  */
+  double *tinc_fcorr, *sinc_fcorr, *ocnTcorr, *scorr;             /* (npts,nzp1) out */
+  int32_t *nmodeadv;          /* (npts,2)            - column 2 (salinity) is used */
+  int32_t *modeadv;           /* (npts,maxmodeadv,2)                               */
+  double *advection;          /* (npts,maxmodeadv,2)                               */
 } mckpp_state_ptrs_c;
 
 /* field_mask bits for mckpp_hip_download */

@@ -41,7 +41,7 @@ class _ConstC(C.Structure):
     _fields_ = (
         [(n, C.c_int32) for n in ("nz", "nztmax", "nsflxs", "njdt", "itermax")]
         + [(n, C.c_int32) for n in _SWITCHES]
-        + [("iso_bot", C.c_int32), ("dt_uvdamp", C.c_int32)]
+        + [("iso_bot", C.c_int32), ("dt_uvdamp", C.c_int32), ("maxmodeadv", C.c_int32), ("L_ADVECT", C.c_int32)]
         + [(n, C.c_double) for n in ("hmixtolfrac", "dto", "grav", "vonk", "sice", "iso_thresh")]
         + [(n, _dp) for n in ("zm", "hm", "dm", "tri", "wmt", "wst")]
     )
@@ -56,6 +56,9 @@ _STATE_DIAG = [
     "rho", "cp", "buoy", "difm", "difs", "dift", "wU", "wX", "wXNT", "ghat", "Rig", "Shsq", "dbloc",
     "swfrac", "swdk_opt",
 ]
+_STATE_EXT_D = ["relax_sst", "SST0", "fcorr_twod", "relax_sal", "relax_ocnT", "fcorr", "fcorr_withz", "sfcorr_withz",
+                "ocnT_clim", "sal_clim", "tinc_fcorr", "sinc_fcorr", "ocnTcorr", "scorr"]
+_STATE_EXT_I = ["nmodeadv", "modeadv"]
 
 
 class _StateC(C.Structure):
@@ -64,6 +67,9 @@ class _StateC(C.Structure):
         + [(n, _dp) for n in _STATE_D]
         + [(n, _ip) for n in _STATE_I]
         + [(n, _dp) for n in _STATE_DIAG]
+        + [(n, _dp) for n in _STATE_EXT_D]
+        + [(n, _ip) for n in _STATE_EXT_I]
+        + [("advection", _dp)]
     )
 
 
@@ -134,6 +140,8 @@ class KppConstFields:
         self.dto = float(dto)
         self.grav, self.vonk, self.sice = 9.816, 0.4, 4.0
         self.iso_bot, self.iso_thresh, self.dt_uvdamp = 2, 0.002, 360
+        self.maxmodeadv = 6
+        self.L_ADVECT = 0
         for s in _SWITCHES:
             setattr(self, s, 0)
         self.LKPP = self.LRI = self.L_SSref = 1
@@ -152,7 +160,7 @@ class KppConstFields:
 
     def as_c(self):
         c = _ConstC()
-        for n in ("nz", "nztmax", "nsflxs", "njdt", "itermax", "iso_bot", "dt_uvdamp"):
+        for n in ("nz", "nztmax", "nsflxs", "njdt", "itermax", "iso_bot", "dt_uvdamp", "maxmodeadv", "L_ADVECT"):
             setattr(c, n, int(getattr(self, n)))
         for n in _SWITCHES:
             setattr(c, n, int(getattr(self, n)))
@@ -208,17 +216,24 @@ class Kpp3dFields:
         self.dbloc = _f((npts, nz))
         self.swfrac = _f((npts, nzp1))
         self.swdk_opt = _f((npts, nz + 1))
+        for n in ("relax_sst", "SST0", "fcorr_twod", "relax_sal", "relax_ocnT", "fcorr"):
+            setattr(self, n, _f((npts,)))
+        for n in ("fcorr_withz", "sfcorr_withz", "ocnT_clim", "sal_clim", "tinc_fcorr", "sinc_fcorr", "ocnTcorr", "scorr"):
+            setattr(self, n, _f((npts, nzp1)))
+        self.nmodeadv = np.zeros((npts, 2), dtype=np.int32, order="F")
+        self.modeadv = np.zeros((npts, c.maxmodeadv, 2), dtype=np.int32, order="F")
+        self.advection = _f((npts, c.maxmodeadv, 2))
 
     def as_c(self):
         s = _StateC()
         s.npts = self.npts
-        for n in _STATE_D + _STATE_DIAG:
+        for n in _STATE_D + _STATE_DIAG + _STATE_EXT_D + ["advection"]:
             a = getattr(self, n)
             assert a.flags["F_CONTIGUOUS"] and a.dtype == np.float64, n
             setattr(s, n, a.ctypes.data_as(_dp))
-        for n in _STATE_I:
+        for n in _STATE_I + _STATE_EXT_I:
             a = getattr(self, n)
-            assert a.dtype == np.int32, n
+            assert a.dtype == np.int32 and a.flags["F_CONTIGUOUS"], n
             setattr(s, n, a.ctypes.data_as(_ip))
         return s
 

@@ -13,13 +13,15 @@
 
 #define MCKPP_CS 24
 #define MCKPP_CI 8
+#define MCKPP_XS 8
+enum { XS_RELAX_SST = 0, XS_SST0, XS_FCORR_TWOD, XS_RELAX_SAL, XS_RELAX_OCNT };
 
 // cs[] slots
 enum {
   CS_F = 0, CS_SSURF, CS_SREF, CS_SSREF, CS_OCDEPTH,
   CS_SFLUX1, CS_SFLUX2, CS_SFLUX3, CS_SFLUX4, CS_SFLUX5, CS_SFLUX6,
   CS_HMIXD0, CS_HMIXD1, CS_HMIX, CS_KMIX, CS_UREF, CS_VREF, CS_TREF,
-  CS_RESET, CS_DAMPU, CS_DAMPV, CS_FREEZE, CS_SPARE0, CS_SPARE1
+  CS_RESET, CS_DAMPU, CS_DAMPV, CS_FREEZE, CS_FCORR, CS_SPARE1
 };
 // ci[] slots
 enum { CI_OLD = 0, CI_NEW, CI_JERLOV, CI_INITFLAG, CI_STATUS, CI_NPASS, CI_LOCEAN, CI_IPT };
@@ -48,6 +50,17 @@ struct mckpp_kparams {
   int *ci;
   int *qhead;   // column queue head for the persistent cooperative kernel (zeroed per launch)
   unsigned long long *dbg;   // optional [16] phase-cycle accumulators (diagnostic builds of a run only)
+  // optional physics: ext != 0 selects the kernel build that carries it
+  int ext, L_RELAX_SST, L_RELAX_CALCONLY, L_FCORR, L_FCORR_WITHZ, L_SFCORR, L_SFCORR_WITHZ;
+  int L_RELAX_SAL, L_RELAX_OCNT, L_NO_FREEZE, L_NO_ISOTHERM, L_DAMP_CURR, iso_bot, dt_uvdamp, maxmodeadv;
+  double iso_thresh;
+  const double *dm;      // dm(0:nz)
+  const double *hsum;    // hsum(n) = hm(1)+...+hm(n), summed in that order (rhsmod's delta)
+  const double *xs;      // [ncol][MCKPP_XS]: relax_sst, SST0, fcorr_twod, relax_sal, relax_ocnT
+  const double *fcorr_withz, *sfcorr_withz, *ocnT_clim, *sal_clim;   // profile rows
+  double *tinc_fcorr, *sinc_fcorr, *ocnTcorr, *scorr;                // diagnostic rows
+  const int *adv_i;      // [ncol][1+maxmodeadv]: nmodeadv(2), modeadv(:,2)
+  const double *adv_d;   // [ncol][maxmodeadv]:   advection(:,2)
   // diagnostics (all or none)
   double *rho, *cp, *buoy, *talpha, *sbeta, *difm, *difs, *dift, *ghat;
   double *wU1, *wU2, *wX1, *wX2, *wX3, *wXNT1, *Rig, *dbloc, *Shsq;

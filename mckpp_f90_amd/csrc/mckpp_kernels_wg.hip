@@ -33,7 +33,8 @@ namespace {
 using namespace mckpp_dev;
 
 // per-slot LDS rows (each NA doubles, reference index = element index)
-enum { R_DM = 0, R_DT, R_DS, R_GH, R_YU, R_YT, R_YS, R_GM, R_GT, R_GS, R_BETM, R_YV, R_RB, R_COUNT };
+enum { R_DM = 0, R_DT, R_DS, R_GH, R_YU, R_YT, R_YS, R_GM, R_GT, R_GS, R_BETM, R_YV, R_RB, R_COUNT,
+       R_RHO = R_COUNT, R_CP, R_COUNT_EXT };   // rho, cp rows exist only in the optional-physics build
 // vmix scratch aliases (dead before the Thomas rows are built)
 enum { R_U = R_YU, R_V = R_YT, R_B = R_YS, R_R = R_GM, R_DB = R_GT, R_DMO = R_GS, R_T = R_BETM };
 
@@ -45,10 +46,10 @@ enum { C_B0 = 0, C_B0SOL, C_USTAR, C_WU01, C_WU02, C_WX01, C_WX02, C_WXNT0, C_UR
 
 template <int LPL>
 __host__ __device__ constexpr int wg_na() { return 64 * LPL + 3; }   // == 3 (mod 32): bank-spread rows
-template <int LPL>
+template <int LPL, bool EXT = false>
 __host__ __device__ constexpr int wg_slot_stride()
 {
-  int s = R_COUNT * wg_na<LPL>();
+  int s = (EXT ? R_COUNT_EXT : R_COUNT) * wg_na<LPL>();
   while (s % 32 != 9) ++s;   // slot s, system m at offset 9s+3m (mod 32 doubles): all distinct
   return s;
 }
@@ -59,7 +60,7 @@ __host__ __device__ constexpr int wg_slot_stride()
     __builtin_amdgcn_wave_barrier();                           \
   } while (0)
 
-template <int LPL, int W, int MINW>
+template <int LPL, int W, int MINW, bool EXT>
 __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams *__restrict__ pp, const int ntime)
 {
   // the parameter block is read through the scalar cache where it is used: passing its ~60
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
   const mckpp_kparams &p = *pp;
   extern __shared__ double lds[];
   constexpr int NA = wg_na<LPL>();
-  constexpr int SS = wg_slot_stride<LPL>();
+  constexpr int SS = wg_slot_stride<LPL, EXT>();
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nz = p.nz, nzp1 = p.nzp1;
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
   double Uo[LPL], Vo[LPL], To[LPL], So[LPL];
   double Ux[LPL], Vx[LPL], Tx[LPL], Sx[LPL];
   double talpha[LPL], sbeta[LPL];
+  double xt[LPL];   // EXT: tinc_fcorr of the latest pass (overrides.F90:87-88 adds to it)
   int kk[LPL];
   bool act[LPL], actz[LPL];
   FORJ {
@@ -108,6 +110,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     Uo[j] = Vo[j] = To[j] = So[j] = 0.0;
     Ux[j] = Vx[j] = Tx[j] = Sx[j] = 0.0;
     talpha[j] = sbeta[j] = 0.0;
+    xt[j] = 0.0;
   }
   const int lane_nz = (nz - 1) & 63, j_nz = (nz - 1) >> 6;
   const int lane_np = (nzp1 - 1) & 63, j_np = (nzp1 - 1) >> 6;
@@ -232,6 +235,22 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     }
 
     FORJ if (act[j]) { aU[kk[j]] = U[j]; aV[kk[j]] = V[j]; aB[kk[j]] = buoy[j]; }
+    double alphaDT[LPL], betaDS[LPL];
+    FORJ { alphaDT[j] = 0.0; betaDS[j] = 0.0; }
+    if constexpr (EXT) {
+      double *aRho = row(R_RHO), *aCp = row(R_CP);
+      FORJ if (act[j]) { aRho[kk[j]] = rho[j]; aCp[kk[j]] = cp[j]; }
+      if (p.LDD) {   // alphaDT, betaDS across interfaces, verticalmixing_mod.F90:103-108
+        double *sA = row(R_YV), *sB = row(R_RB), *sT = row(R_T), *sS = row(R_GH);
+        FORJ if (act[j]) { int k = kk[j]; sA[k] = talpha[j]; sB[k] = sbeta[j]; sT[k] = T[j]; sS[k] = S[j]; }
+        WAVE_LDS_SYNC();
+        FORJ {
+          int k = kk[j];
+          alphaDT[j] = 0.5 * (talpha[j] + sA[k + 1]) * (T[j] - sT[k + 1]);
+          betaDS[j] = 0.5 * (sbeta[j] + sB[k + 1]) * (S[j] - sS[k + 1]);
+        }
+      }
+    }
     WAVE_LDS_SYNC();
     double Ritop[LPL], dVsq[LPL], dbloc[LPL], shsq[LPL], Rig[LPL], zdiff[LPL];
     {   // surface-layer reference values, verticalmixing_mod.F90:111-137
@@ -314,11 +333,36 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       dm_i[j] = (0.0001 + fri * 0.005);
       ds_i[j] = (0.00001 + fri * 0.005);
     }
+    double dt_i[LPL];
+    FORJ dt_i[j] = ds_i[j];   // dift = difs, rimix_mod.F90:95-97
+    if constexpr (EXT) {
+      if (p.LDD) {   // ddmix_mod.F90:12-52
+        const double Rrho0 = 1.9, dsfmax = 1.0e-4;
+        FORJ {
+          const double aDT = alphaDT[j], bDS = betaDS[j];
+          if ((aDT > bDS) && (bDS > 0.)) {
+            double Rrho = dmin2(aDT / bDS, Rrho0);
+            double rr = ((Rrho - 1) / (Rrho0 - 1));
+            double diffdd = 1.0 - rr * rr;
+            diffdd = dsfmax * diffdd * diffdd * diffdd;
+            dt_i[j] = dt_i[j] + diffdd * 0.8 / Rrho;
+            ds_i[j] = ds_i[j] + diffdd;
+          } else if ((aDT < 0.0) && (bDS < 0.0) && (aDT < bDS)) {
+            double Rrho = aDT / bDS;
+            double diffdd = 1.5e-6 * 9.0 * 0.101 * mckpp_exp(4.6 * mckpp_exp(-0.54 * (1 / Rrho - 1)));
+            double prandtl = 0.15 * Rrho;
+            if (Rrho > 0.5) prandtl = (1.85 - 0.85 / Rrho) * Rrho;
+            dt_i[j] = dt_i[j] + diffdd;
+            ds_i[j] = ds_i[j] + prandtl * diffdd;
+          }
+        }
+      }
+    }
     WAVE_LDS_SYNC();
-    FORJ {   // interior diffusivities; dift == difs (rimix_mod.F90:95-97)
+    FORJ {   // interior diffusivities
       int k = kk[j];
-      if (actz[j]) { aDm[k] = dm_i[j]; aDs[k] = ds_i[j]; aDt[k] = ds_i[j]; }
-      if (k == nz) { aDm[k + 1] = dm_i[j]; aDs[k + 1] = ds_i[j]; aDt[k + 1] = ds_i[j]; }   // kppmix_mod.F90:82-84
+      if (actz[j]) { aDm[k] = dm_i[j]; aDs[k] = ds_i[j]; aDt[k] = dt_i[j]; }
+      if (k == nz) { aDm[k + 1] = dm_i[j]; aDs[k + 1] = ds_i[j]; aDt[k + 1] = dt_i[j]; }   // kppmix_mod.F90:82-84
       if (k == 1) { aDm[0] = 0.0; aDs[0] = 0.0; aDt[0] = 0.0; }
     }
     // bldepth, level-parallel part (bldepth_mod.F90:105-147)
@@ -338,6 +382,85 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       dmo = st * dmo - (1. - st) * zm_kmp1;
       if (k >= 2 && actz[j]) { aR[k] = raw; aDmo[k] = dmo; }
       if (k == 1) { aR[1] = 0.0; aDmo[1] = -zm_kmp1; }
+    }
+  };
+
+  // ---- optional terms of the T and S right-hand sides (ocnint_mod.F90:97-215) -----
+  // Level k of this lane: relaxation / flux corrections / prescribed advection (rhsmod,
+  // solvers.F90:176-335, salinity only).  Also leaves tinc_fcorr in xt and writes the
+  // correction diagnostics when this may be the last pass.
+  auto ext_rhs = [&](int k, int j, int kmixe, double &rhsT, double &rhsS) {
+    const double dto = p.dto;
+    const double *xs = p.xs + (size_t)col * MCKPP_XS;
+    const double *aRho = row(R_RHO), *aCp = row(R_CP);
+    const double rhok = aRho[k], cpk = aCp[k];
+    const size_t oin = rowoff() + (k - 1);
+    if (k == 1) {
+      if (p.L_RELAX_SST && !p.L_FCORR_WITHZ && !p.L_FCORR) {   // :97-114
+        const double relax_sst = xs[XS_RELAX_SST], SST0 = xs[XS_SST0];
+        double fc = 0.0;
+        if (relax_sst > 1.e-10) {
+          if (!p.L_RELAX_CALCONLY) rhsT = rhsT + dto * relax_sst * (SST0 - To[j]) * p.dm[kmixe] / c_hm[1];
+          fc = relax_sst * (SST0 - To[j]) * p.dm[kmixe] * rhok * cpk;
+        }
+        csrow()[CS_FCORR] = fc;
+      }
+      if (p.L_FCORR && !p.L_RELAX_SST && !p.L_FCORR_WITHZ)     // :121-125
+        rhsT = rhsT + dto * xs[XS_FCORR_TWOD] / (rhok * cpk * c_hm[1]);
+    }
+    double tinc = 0.;                                           // :133-160
+    if (p.L_FCORR_WITHZ && !p.L_FCORR) tinc = dto * p.fcorr_withz[oin] / (rhok * cpk);
+    if (p.L_RELAX_OCNT) tinc = tinc + dto * xs[XS_RELAX_OCNT] * (p.ocnT_clim[oin] - To[j]);
+    rhsT = rhsT + tinc;
+    xt[j] = tinc;
+    const double ocnTcorr = tinc * rhok * cpk / dto;
+    // prescribed advection of salinity, rhsmod with jsclr = 2 (:179-184)
+    const int *ai = p.adv_i + (size_t)col * (p.maxmodeadv + 1);
+    const double *ad = p.adv_d + (size_t)col * (p.maxmodeadv + 1);
+    const int nmode = ai[0];
+    const int nzi = nz, km = kmixe;
+    for (int im = 0; im < nmode; ++im) {
+      const int mode = ai[1 + im];
+      if (mode <= 0) continue;
+      const double fact = dto * ad[im] * 0.033;
+      if (mode == 1) {
+        if (k == 1) rhsS = rhsS + fact / c_hm[1];
+      } else if (mode == 2) {
+        const double delta = p.hsum[km - 1];
+        if (k <= km - 1) rhsS = rhsS + fact / delta;
+      } else if (mode == 3) {
+        const double delta = p.hsum[nzi];
+        if (k <= nzi) rhsS = rhsS + fact / delta;
+      } else if (mode == 4) {
+        const int nzend = nzi - 1;
+        int n1 = 0;
+        do { n1 = n1 + 1; } while (c_zm[n1] >= -100. && n1 < nzp1);
+        double delta = 0.0;
+        for (int n = n1; n <= nzend; ++n) delta = delta + c_hm[n];
+        if (k >= n1 && k <= nzend) rhsS = rhsS + fact / delta;
+      } else if (mode == 5) {
+        if (k == nzi) rhsS = rhsS + fact / c_hm[nzi];
+      } else if (mode == 6 || mode == 7) {
+        int n1, n2 = 0;
+        double depth, dmax, delta = 0.0;
+        if (mode == 6) { n1 = 1; depth = c_hm[1]; dmax = p.dm[km] - 0.5 * (c_hm[km] + c_hm[km - 1]); }
+        else { n1 = km - 1; depth = p.dm[km] - 0.5 * c_hm[km]; dmax = 100.; }
+        for (int n = n1; n <= nzi; ++n) {
+          n2 = n;
+          delta = delta + c_hm[n];
+          depth = depth + c_hm[n + 1];
+          if (depth >= dmax) break;
+        }
+        if (k >= n1 && k <= n2) rhsS = rhsS + fact / delta;
+      }
+    }
+    double sinc = 0.;                                           // :187-213
+    if (p.L_SFCORR_WITHZ && !p.L_SFCORR) sinc = dto * p.sfcorr_withz[oin];
+    if (p.L_RELAX_SAL) sinc = sinc + dto * xs[XS_RELAX_SAL] * (p.sal_clim[oin] - So[j]);
+    rhsS = rhsS + sinc;
+    if (maybe_final()) {
+      const size_t o = rowoff() + k;
+      p.tinc_fcorr[o] = tinc; p.ocnTcorr[o] = ocnTcorr; p.sinc_fcorr[o] = sinc; p.scorr[o] = sinc / dto;
     }
   };
 
@@ -526,7 +649,11 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       else
         rhsS = So[j] + dto / hk * (wX0_2 * (difs[j] * ghat[j] - ds_m1 * gh_m1) + 0.0 - 0.0);
       if (k == nz && nz > 1) rhsS = rhsS + So_np * tri1_nz * difs[j];
+      if constexpr (EXT) ext_rhs(k, j, kbl, rhsT, rhsS);
       yU[k] = rhsU; yT[k] = rhsT; yS[k] = rhsS;
+    }
+    if constexpr (EXT) {   // tinc_fcorr / ocnTcorr / sinc_fcorr / scorr of level nzp1 (ocnint_mod.F90:153-160, 207-213)
+      FORJ if (kk[j] == nzp1) { double t = 0.0, s2 = 0.0; ext_rhs(nzp1, j, kbl, t, s2); }
     }
   };
 
@@ -599,18 +726,91 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       double Ssurf;
       if (p.L_SSref) Ssurf = cs[CS_SSREF];
       else Ssurf = first_lane(S[0]) + cs[CS_SREF];
+      double dampu = 0.0, dampv = 0.0, reset_out = 0.0, freeze = cs[CS_FREEZE];
+      if constexpr (EXT) {
+        if (p.L_DAMP_CURR) {   // ocnstep_mod.F90:317-340
+          const double rr = (double)p.dt_uvdamp * (86400. / p.dto);
+          const double inc = 1.0 / (double)nzp1;
+          int nu = 0, nv = 0;
+          FORJ {
+            double a = 0.99 * __builtin_fabs(U[j]), b = (U[j] * U[j]) / rr;
+            nu += __popcll(__ballot(act[j] && (b < a)));
+            U[j] = U[j] - dsign(dmin2(a, b), U[j]);
+            a = 0.99 * __builtin_fabs(V[j]); b = (V[j] * V[j]) / rr;
+            nv += __popcll(__ballot(act[j] && (b < a)));
+            V[j] = V[j] - dsign(dmin2(a, b), V[j]);
+          }
+          for (int i = 0; i < nu; ++i) dampu = dampu + inc;
+          for (int i = 0; i < nv; ++i) dampv = dampv + inc;
+        }
+      }
       old = newi;
       newi = 1 - old;
       FORJ if (act[j]) {
         size_t o = ro + lane + 64 * j;
         p.Us[newi][o] = U[j]; p.Vs[newi][o] = V[j]; p.Ts[newi][o] = T[j]; p.Ss[newi][o] = S[j];
       }
-      if (comp_flag) {   // overrides.F90:72-78
-        FORJ if (act[j]) {
+      // check_profile, overrides.F90:42-125
+      reset_out = (double)nreset;
+      if (comp_flag) {
+        if (EXT && p.clim_present) {   // :57-71
+          FORJ if (act[j]) {
+            size_t o = ro + lane + 64 * j;
+            T[j] = p.ocnT_clim[o];
+            S[j] = p.sal_clim[o];
+          }
+        }
+        FORJ if (act[j]) {   // :66 / :76
           size_t o = ro + lane + 64 * j;
           U[j] = p.U_init[o];
           V[j] = p.V_init[o];
         }
+        reset_out = 999.;
+      }
+      const int l_ocean = ci[CI_LOCEAN];
+      if constexpr (EXT) {
+        if (l_ocean && p.L_NO_FREEZE) {   // :85-94
+          const double inc = 1.0 / (double)nzp1;
+          int nf = 0;
+          FORJ {
+            bool cold = act[j] && (T[j] < -1.8);
+            if (cold) { xt[j] = xt[j] + (-1.8 - T[j]); T[j] = -1.8; }
+            nf += __popcll(__ballot(cold));
+          }
+          for (int i = 0; i < nf; ++i) freeze = freeze + inc;
+          FORJ if (act[j]) p.tinc_fcorr[ro + kk[j]] = xt[j];
+        }
+      }
+      if (EXT && l_ocean && p.L_NO_ISOTHERM) {   // :102-120
+        double *tT = row(R_YU), *tD = row(R_YT), *tZ = row(R_YS);
+        WAVE_LDS_SYNC();
+        FORJ if (act[j]) tT[kk[j]] = T[j];
+        WAVE_LDS_SYNC();
+        FORJ {
+          int k = kk[j];
+          if (k >= 2 && act[j]) {
+            double dz = c_zm[k] - c_zm[k - 1];
+            tD[k] = __builtin_fabs((T[j] - tT[k - 1])) * dz;
+            tZ[k] = dz;
+          }
+        }
+        WAVE_LDS_SYNC();
+        double dtdz_total = 0., dz_total = 0.;
+        for (int k = 2; k <= p.iso_bot; ++k) {
+          dtdz_total = dtdz_total + tD[k];
+          dz_total = dz_total + tZ[k];
+        }
+        dtdz_total = dtdz_total / dz_total;
+        if (__builtin_fabs(dtdz_total) < p.iso_thresh) {
+          FORJ if (act[j]) {
+            size_t o = ro + lane + 64 * j;
+            T[j] = p.ocnT_clim[o];
+            S[j] = p.sal_clim[o];
+          }
+          reset_out = (-1.) * reset_out;
+        }
+      } else {
+        reset_out = 0.0;   // :121-123
       }
       FORJ if (act[j]) {
         size_t o = ro + lane + 64 * j;
@@ -623,8 +823,9 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
         cs[CS_UREF] = uref; cs[CS_VREF] = vref; cs[CS_TREF] = Tref;
         cs[CS_SSURF] = Ssurf;
         cs[newi ? CS_HMIXD1 : CS_HMIXD0] = hmixn;
-        cs[CS_RESET] = 0.0;   // overrides.F90:121-123
-        cs[CS_DAMPU] = 0.0; cs[CS_DAMPV] = 0.0;
+        cs[CS_RESET] = reset_out;
+        cs[CS_DAMPU] = dampu; cs[CS_DAMPV] = dampv;
+        cs[CS_FREEZE] = freeze;
         ci[CI_OLD] = old; ci[CI_NEW] = newi;
         ci[CI_STATUS] = status; ci[CI_NPASS] = npass;
       }
@@ -905,24 +1106,26 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
 #undef STAMP
 }
 
-template <int LPL, int W>
+template <int LPL, int W, bool EXT>
 size_t wg_lds_bytes()
 {
-  return (size_t)(4 * wg_na<LPL>() + W * wg_slot_stride<LPL>() + W * C_COUNT) * sizeof(double) + 2 * W * sizeof(int);
+  return (size_t)(4 * wg_na<LPL>() + W * wg_slot_stride<LPL, EXT>() + W * C_COUNT) * sizeof(double) +
+         2 * W * sizeof(int);
 }
 
-template <int LPL, int W, int MINW>
+template <int LPL, int W, int MINW, bool EXT = false>
 hipError_t launch_wg(const mckpp_kparams &p, const mckpp_kparams *dp, int nblocks, hipStream_t stream)
 {
-  const size_t lds = wg_lds_bytes<LPL, W>();
+  const size_t lds = wg_lds_bytes<LPL, W, EXT>();
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_column_wg<LPL, W, MINW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_column_wg<LPL, W, MINW, EXT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_column_wg<LPL, W, MINW>), dim3((unsigned)nblocks), dim3(64 * W), lds, stream, dp, p.ntime);
+  hipLaunchKernelGGL((k_column_wg<LPL, W, MINW, EXT>), dim3((unsigned)nblocks), dim3(64 * W), lds, stream, dp,
+                     p.ntime);
   return hipGetLastError();
 }
 
@@ -955,6 +1158,18 @@ hipError_t mckpp_launch_column_kernel_wg(const mckpp_kparams &p, const mckpp_kpa
   const int groups = (p.ncol + W - 1) / W;
   if (nblocks > groups) nblocks = groups;
   if (nblocks < 1) nblocks = 1;
+  if (p.ext) {   // optional-physics build: W = 4, register budget of two (LPL=1) or one workgroup per SIMD set
+    per_cu = (lpl == 1) ? 4 : (lpl == 2 ? 2 : 1);
+    nblocks = num_cu * per_cu;
+    if (nblocks > (p.ncol + 3) / 4) nblocks = (p.ncol + 3) / 4;
+    if (nblocks < 1) nblocks = 1;
+    switch (lpl) {
+      case 1: return launch_wg<1, 4, 4, true>(p, dp, nblocks, stream);
+      case 2: return launch_wg<2, 4, 2, true>(p, dp, nblocks, stream);
+      case 3: return launch_wg<3, 4, 1, true>(p, dp, nblocks, stream);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (lpl) {
     case 1:
       if (W == 8) return (per_cu >= 2) ? launch_wg<1, 8, 4>(p, dp, nblocks, stream) : launch_wg<1, 8, 2>(p, dp, nblocks, stream);

@@ -40,6 +40,10 @@ int fail(const char *fmt, ...)
 
 // profile rows (element j <-> level j+1)
 enum { P_U = 0, P_V, P_T, P_S, P_US0, P_US1, P_VS0, P_VS1, P_TS0, P_TS1, P_SS0, P_SS1, P_UINIT, P_VINIT, P_COUNT };
+// optional-physics input rows (allocated only when a switch needs them)
+enum { E_FCORR_WITHZ = 0, E_SFCORR_WITHZ, E_OCNT_CLIM, E_SAL_CLIM, E_COUNT };
+// optional-physics output rows (indexed by k like the diagnostics)
+enum { O_TINC = 0, O_SINC, O_OCNTCORR, O_SCORR, O_COUNT };
 // diagnostic rows (element k <-> reference index k)
 enum { D_RHO = 0, D_CP, D_BUOY, D_TALPHA, D_SBETA, D_DIFM, D_DIFS, D_DIFT, D_GHAT, D_WU1, D_WU2,
        D_WX1, D_WX2, D_WX3, D_WXNT1, D_RIG, D_DBLOC, D_SHSQ, D_COUNT };
@@ -69,6 +73,11 @@ struct mckpp_hip_ctx {
   int *d_ipt = nullptr;
   double *d_prof[P_COUNT] = {};
   double *d_diag[D_COUNT] = {};
+  bool ext = false;   // any optional-physics switch on (kernel build with the N3 code)
+  double *d_ext_in[E_COUNT] = {};
+  double *d_ext_out[O_COUNT] = {};
+  double *d_xs = nullptr, *d_adv_d = nullptr, *d_dm = nullptr, *d_hsum = nullptr;
+  int *d_adv_i = nullptr;
   double *d_cs = nullptr;
   int *d_ci = nullptr;
   int *d_qhead = nullptr;
@@ -148,10 +157,9 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   if (!c->zm || !c->hm || !c->dm || !c->tri || !c->wmt || !c->wst)
     return fail("mckpp_hip_init: zm/hm/dm/tri/wmt/wst must all be set");
   if (!c->LKPP || !c->LRI) return fail("mckpp_hip_init: LKPP and LRI must be .TRUE. (the device path implements the KPP scheme)");
-  if (c->LDD || c->L_RELAX_SST || c->L_FCORR || c->L_FCORR_WITHZ || c->L_SFCORR || c->L_SFCORR_WITHZ ||
-      c->L_RELAX_SAL || c->L_RELAX_OCNT || c->L_NO_FREEZE || c->L_NO_ISOTHERM || c->L_DAMP_CURR || c->clim_present)
-    return fail("mckpp_hip_init: LDD / relaxation / flux-correction / damping / freeze / isotherm / "
-                "climatology-reset switches are not implemented on the device path yet (SURVEY 8(f) N3)");
+  if (c->maxmodeadv < 0 || c->maxmodeadv > 16) return fail("mckpp_hip_init: maxmodeadv=%d", c->maxmodeadv);
+  if (c->L_NO_ISOTHERM && (c->iso_bot < 2 || c->iso_bot > c->nz + 1))
+    return fail("mckpp_hip_init: iso_bot=%d outside 2..nzp1", c->iso_bot);
   const int nzp1 = c->nz + 1;
   const int lpl = (nzp1 + 2 + 63) / 64;
   if (lpl > 3) return fail("mckpp_hip_init: nz=%d too deep (max 190 levels)", c->nz);
@@ -174,6 +182,13 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   h->ldc = 64 * lpl + 8;
   h->num_cu = prop.multiProcessorCount;
   if (const char *kv = getenv("MCKPP_KERNEL")) h->kernel_variant = (strcmp(kv, "v1") == 0) ? 1 : 2;
+  h->ext = c->LDD || c->L_RELAX_SST || c->L_FCORR || c->L_FCORR_WITHZ || c->L_SFCORR || c->L_SFCORR_WITHZ ||
+           c->L_RELAX_SAL || c->L_RELAX_OCNT || c->L_NO_FREEZE || c->L_NO_ISOTHERM || c->L_DAMP_CURR ||
+           c->clim_present || c->L_ADVECT;
+  if (h->ext && h->kernel_variant == 1) {
+    delete h;
+    return fail("mckpp_hip_init: MCKPP_KERNEL=v1 carries the default physics only");
+  }
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipMalloc(&h->d_qhead, sizeof(int)));
   HIPCHK(hipMalloc(&h->d_params, sizeof(mckpp_kparams)));
@@ -189,6 +204,16 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   for (int k = 1; k <= nzp1; ++k) { zm[k] = c->zm[k - 1]; hm[k] = c->hm[k - 1]; }
   for (int k = 0; k <= nz; ++k) { t0[k] = c->tri[k]; t1[k] = c->tri[n1 + k]; }
   h->dm_nz = c->dm[nz];
+  {
+    std::vector<double> dm(ldc, 0.0), hs(ldc, 0.0);
+    for (int k = 0; k <= nz; ++k) dm[k] = c->dm[k];
+    double acc = 0.0;
+    for (int n = 1; n <= nzp1; ++n) { acc = acc + hm[n]; hs[n] = acc; }
+    HIPCHK(hipMalloc(&h->d_dm, ldc * sizeof(double)));
+    HIPCHK(hipMemcpy(h->d_dm, dm.data(), ldc * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&h->d_hsum, ldc * sizeof(double)));
+    HIPCHK(hipMemcpy(h->d_hsum, hs.data(), ldc * sizeof(double), hipMemcpyHostToDevice));
+  }
   // Jerlov tables: swfrac_opt (swfrac_mod.F90:36-41, fact = hbf = 1) and swdk_opt (fluxes_mod.F90:104-107)
   h->h_swfrac_tab.assign((size_t)6 * ldc, 0.0);
   h->h_swdk_tab.assign((size_t)6 * ldc, 0.0);
@@ -237,6 +262,12 @@ static void free_state(mckpp_hip_ctx *h)
 {
   for (auto &p : h->d_prof) { if (p) hipFree(p); p = nullptr; }
   for (auto &p : h->d_diag) { if (p) hipFree(p); p = nullptr; }
+  for (auto &p : h->d_ext_in) { if (p) hipFree(p); p = nullptr; }
+  for (auto &p : h->d_ext_out) { if (p) hipFree(p); p = nullptr; }
+  if (h->d_xs) hipFree(h->d_xs);
+  if (h->d_adv_d) hipFree(h->d_adv_d);
+  if (h->d_adv_i) hipFree(h->d_adv_i);
+  h->d_xs = nullptr; h->d_adv_d = nullptr; h->d_adv_i = nullptr;
   if (h->d_cs) hipFree(h->d_cs);
   if (h->d_ci) hipFree(h->d_ci);
   if (h->d_ipt) hipFree(h->d_ipt);
@@ -253,7 +284,7 @@ int mckpp_hip_finalize(mckpp_hip_handle h)
   if (h->stream) hipStreamSynchronize(h->stream);
   free_state(h);
   hipFree(h->d_zm); hipFree(h->d_hm); hipFree(h->d_tri0); hipFree(h->d_tri1);
-  hipFree(h->d_swfrac_tab); hipFree(h->d_swdk_tab); hipFree(h->d_wtab); hipFree(h->d_qhead); hipFree(h->d_params);
+  hipFree(h->d_swfrac_tab); hipFree(h->d_swdk_tab); hipFree(h->d_wtab); hipFree(h->d_qhead); hipFree(h->d_params); hipFree(h->d_dm); hipFree(h->d_hsum);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -324,6 +355,13 @@ int mckpp_hip_upload(mckpp_hip_handle h, const mckpp_state_ptrs_c *s)
       HIPCHK(hipMalloc(&h->d_cs, (size_t)ncol * MCKPP_CS * sizeof(double)));
       HIPCHK(hipMalloc(&h->d_ci, (size_t)ncol * MCKPP_CI * sizeof(int)));
       HIPCHK(hipMalloc(&h->d_ipt, (size_t)ncol * sizeof(int)));
+      if (h->ext) {
+        for (auto &p : h->d_ext_in) { HIPCHK(hipMalloc(&p, rowbytes)); HIPCHK(hipMemsetAsync(p, 0, rowbytes, h->stream)); }
+        for (auto &p : h->d_ext_out) { HIPCHK(hipMalloc(&p, rowbytes)); HIPCHK(hipMemsetAsync(p, 0, rowbytes, h->stream)); }
+        HIPCHK(hipMalloc(&h->d_xs, (size_t)ncol * MCKPP_XS * sizeof(double)));
+        HIPCHK(hipMalloc(&h->d_adv_d, (size_t)ncol * (h->c.maxmodeadv + 1) * sizeof(double)));
+        HIPCHK(hipMalloc(&h->d_adv_i, (size_t)ncol * (h->c.maxmodeadv + 1) * sizeof(int)));
+      }
     }
   }
   h->ipt = ipt;
@@ -349,6 +387,41 @@ int mckpp_hip_upload(mckpp_hip_handle h, const mckpp_state_ptrs_c *s)
   if (s->U_init) {
     if (up_rows(h, s->U_init, nzp1, h->d_prof[P_UINIT], 0)) return -1;
     if (up_rows(h, s->U_init + slab, nzp1, h->d_prof[P_VINIT], 0)) return -1;
+  }
+  if (h->ext) {
+    const mckpp_const_c &k = h->c;
+    if ((k.L_FCORR_WITHZ && !s->fcorr_withz) || (k.L_SFCORR_WITHZ && !s->sfcorr_withz) ||
+        ((k.L_RELAX_OCNT || k.clim_present || k.L_NO_ISOTHERM) && !s->ocnT_clim) ||
+        ((k.L_RELAX_SAL || k.clim_present || k.L_NO_ISOTHERM) && !s->sal_clim) ||
+        (k.L_RELAX_SST && (!s->relax_sst || !s->SST0)) || (k.L_FCORR && !s->fcorr_twod) ||
+        (k.L_RELAX_SAL && !s->relax_sal) || (k.L_RELAX_OCNT && !s->relax_ocnT))
+      return fail("mckpp_hip_upload: a switch is on but the field it reads is a NULL pointer");
+    if (s->fcorr_withz && up_rows(h, s->fcorr_withz, nzp1, h->d_ext_in[E_FCORR_WITHZ], 0)) return -1;
+    if (s->sfcorr_withz && up_rows(h, s->sfcorr_withz, nzp1, h->d_ext_in[E_SFCORR_WITHZ], 0)) return -1;
+    if (s->ocnT_clim && up_rows(h, s->ocnT_clim, nzp1, h->d_ext_in[E_OCNT_CLIM], 0)) return -1;
+    if (s->sal_clim && up_rows(h, s->sal_clim, nzp1, h->d_ext_in[E_SAL_CLIM], 0)) return -1;
+    const int mm = k.maxmodeadv;
+    std::vector<double> xs((size_t)ncol * MCKPP_XS, 0.0), ad((size_t)ncol * (mm + 1), 0.0);
+    std::vector<int> ai((size_t)ncol * (mm + 1), 0);
+    for (int64_t c = 0; c < ncol; ++c) {
+      const int64_t i = ipt[c];
+      double *x = &xs[(size_t)c * MCKPP_XS];
+      x[XS_RELAX_SST] = s->relax_sst ? s->relax_sst[i] : 0.0;
+      x[XS_SST0] = s->SST0 ? s->SST0[i] : 0.0;
+      x[XS_FCORR_TWOD] = s->fcorr_twod ? s->fcorr_twod[i] : 0.0;
+      x[XS_RELAX_SAL] = s->relax_sal ? s->relax_sal[i] : 0.0;
+      x[XS_RELAX_OCNT] = s->relax_ocnT ? s->relax_ocnT[i] : 0.0;
+      int nm = (k.L_ADVECT && s->nmodeadv) ? s->nmodeadv[i + npts * 1] : 0;   // nmodeadv(ipt,2)
+      if (nm < 0 || nm > mm) return fail("mckpp_hip_upload: nmodeadv(%lld,2)=%d outside 0..%d", (long long)i + 1, nm, mm);
+      ai[(size_t)c * (mm + 1)] = nm;
+      for (int j = 0; j < mm; ++j) {
+        ai[(size_t)c * (mm + 1) + 1 + j] = s->modeadv ? s->modeadv[i + npts * (j + (int64_t)mm * 1)] : 0;
+        ad[(size_t)c * (mm + 1) + j] = s->advection ? s->advection[i + npts * (j + (int64_t)mm * 1)] : 0.0;
+      }
+    }
+    HIPCHK(hipMemcpy(h->d_xs, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_adv_d, ad.data(), ad.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_adv_i, ai.data(), ai.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   std::vector<double> cs((size_t)ncol * MCKPP_CS, 0.0);
   std::vector<int> ci((size_t)ncol * MCKPP_CI, 0);
@@ -376,6 +449,7 @@ int mckpp_hip_upload(mckpp_hip_handle h, const mckpp_state_ptrs_c *s)
     r[CS_DAMPU] = g(s->dampu_flag, 0.0);
     r[CS_DAMPV] = g(s->dampv_flag, 0.0);
     r[CS_FREEZE] = g(s->freeze_flag, 0.0);
+    r[CS_FCORR] = g(s->fcorr, 0.0);
     q[CI_OLD] = s->old ? s->old[i] : 0;
     q[CI_NEW] = s->new_ ? s->new_[i] : 1;
     q[CI_JERLOV] = s->jerlov ? s->jerlov[i] : 3;
@@ -450,6 +524,17 @@ static void fill_params(mckpp_hip_ctx *h, mckpp_kparams &p, int ntime, int mode)
   p.Ts[0] = h->d_prof[P_TS0]; p.Ts[1] = h->d_prof[P_TS1]; p.Ss[0] = h->d_prof[P_SS0]; p.Ss[1] = h->d_prof[P_SS1];
   p.U_init = h->d_prof[P_UINIT]; p.V_init = h->d_prof[P_VINIT];
   p.cs = h->d_cs; p.ci = h->d_ci; p.qhead = h->d_qhead; p.dbg = h->d_dbg;
+  p.ext = h->ext ? 1 : 0;
+  p.L_RELAX_SST = h->c.L_RELAX_SST; p.L_RELAX_CALCONLY = h->c.L_RELAX_CALCONLY; p.L_FCORR = h->c.L_FCORR;
+  p.L_FCORR_WITHZ = h->c.L_FCORR_WITHZ; p.L_SFCORR = h->c.L_SFCORR; p.L_SFCORR_WITHZ = h->c.L_SFCORR_WITHZ;
+  p.L_RELAX_SAL = h->c.L_RELAX_SAL; p.L_RELAX_OCNT = h->c.L_RELAX_OCNT; p.L_NO_FREEZE = h->c.L_NO_FREEZE;
+  p.L_NO_ISOTHERM = h->c.L_NO_ISOTHERM; p.L_DAMP_CURR = h->c.L_DAMP_CURR; p.iso_bot = h->c.iso_bot;
+  p.dt_uvdamp = h->c.dt_uvdamp; p.maxmodeadv = h->c.maxmodeadv; p.iso_thresh = h->c.iso_thresh;
+  p.dm = h->d_dm; p.hsum = h->d_hsum; p.xs = h->d_xs; p.adv_i = h->d_adv_i; p.adv_d = h->d_adv_d;
+  p.fcorr_withz = h->d_ext_in[E_FCORR_WITHZ]; p.sfcorr_withz = h->d_ext_in[E_SFCORR_WITHZ];
+  p.ocnT_clim = h->d_ext_in[E_OCNT_CLIM]; p.sal_clim = h->d_ext_in[E_SAL_CLIM];
+  p.tinc_fcorr = h->d_ext_out[O_TINC]; p.sinc_fcorr = h->d_ext_out[O_SINC];
+  p.ocnTcorr = h->d_ext_out[O_OCNTCORR]; p.scorr = h->d_ext_out[O_SCORR];
   p.rho = h->d_diag[D_RHO]; p.cp = h->d_diag[D_CP]; p.buoy = h->d_diag[D_BUOY];
   p.talpha = h->d_diag[D_TALPHA]; p.sbeta = h->d_diag[D_SBETA];
   p.difm = h->d_diag[D_DIFM]; p.difs = h->d_diag[D_DIFS]; p.dift = h->d_diag[D_DIFT]; p.ghat = h->d_diag[D_GHAT];
@@ -586,6 +671,7 @@ int mckpp_hip_download(mckpp_hip_handle h, mckpp_state_ptrs_c *s, uint32_t mask)
         if (s->dampv_flag) s->dampv_flag[i] = r[CS_DAMPV];
         if (s->freeze_flag) s->freeze_flag[i] = r[CS_FREEZE];
         if (s->l_initflag) s->l_initflag[i] = q[CI_INITFLAG];
+        if (s->fcorr && h->ext) s->fcorr[i] = r[CS_FCORR];
         if (s->sflux)   // sflux(:,1:6,5,0) as assembled by mckpp_hip_fluxes / set_forcing
           for (int m = 0; m < 6; ++m) s->sflux[i + npts * m + npts * (int64_t)h->c.nsflxs * 4] = r[CS_SFLUX1 + m];
       }
@@ -616,6 +702,12 @@ int mckpp_hip_download(mckpp_hip_handle h, mckpp_state_ptrs_c *s, uint32_t mask)
     if (s->Rig && down_rows(h, h->d_diag[D_RIG], 1, nz, s->Rig)) return -1;
     if (s->Shsq && down_rows(h, h->d_diag[D_SHSQ], 1, nz, s->Shsq)) return -1;
     if (s->dbloc && down_rows(h, h->d_diag[D_DBLOC], 1, nz, s->dbloc)) return -1;
+    if (h->ext) {
+      if (s->tinc_fcorr && down_rows(h, h->d_ext_out[O_TINC], 1, nzp1, s->tinc_fcorr)) return -1;
+      if (s->sinc_fcorr && down_rows(h, h->d_ext_out[O_SINC], 1, nzp1, s->sinc_fcorr)) return -1;
+      if (s->ocnTcorr && down_rows(h, h->d_ext_out[O_OCNTCORR], 1, nzp1, s->ocnTcorr)) return -1;
+      if (s->scorr && down_rows(h, h->d_ext_out[O_SCORR], 1, nzp1, s->scorr)) return -1;
+    }
     if (s->swfrac || s->swdk_opt) {
       std::vector<int> ci((size_t)ncol * MCKPP_CI);
       HIPCHK(hipMemcpy(ci.data(), h->d_ci, ci.size() * sizeof(int), hipMemcpyDeviceToHost));

@@ -24,6 +24,12 @@ module mckpp_data_fields
     real(c_double), allocatable :: taux(:), tauy(:), swf(:), lwf(:), lhf(:), shf(:), rain(:), snow(:)
     integer(c_int), allocatable :: old(:), new(:), jerlov(:)
     logical(c_int), allocatable :: l_ocean(:), l_initflag(:), run_physics(:)
+    ! optional relaxation / flux-correction inputs and outputs (allocate the ones a switch needs:
+    ! mckpp_allocate_3d_optional); same names and shapes as the reference
+    real(c_double), allocatable :: relax_sst(:), SST0(:), fcorr_twod(:), relax_sal(:), relax_ocnT(:), fcorr(:)
+    real(c_double), allocatable :: fcorr_withz(:,:), sfcorr_withz(:,:), ocnT_clim(:,:), sal_clim(:,:)
+    real(c_double), allocatable :: tinc_fcorr(:,:), sinc_fcorr(:,:), ocnTcorr(:,:), scorr(:,:), advection(:,:,:)
+    integer(c_int), allocatable :: nmodeadv(:,:), modeadv(:,:,:)
     ! what the last vmix / ocnint pass of a step leaves behind
     real(c_double), allocatable :: rho(:,:), cp(:,:), buoy(:,:)
     real(c_double), allocatable :: difm(:,:), difs(:,:), dift(:,:), ghat(:,:)
@@ -55,7 +61,7 @@ module mckpp_data_fields
     logical :: L_SFCORR = .false., L_SFCORR_WITHZ = .false., L_RELAX_SAL = .false., L_RELAX_OCNT = .false.
     logical :: L_NO_FREEZE = .false., L_NO_ISOTHERM = .false., L_DAMP_CURR = .false.
     logical :: L_VARY_BOTTOM_TEMP = .false., L_RESTART = .false., L_STRETCHGRID = .false.
-    logical :: L_FLUXDATA = .false., L_REST = .false.
+    logical :: L_FLUXDATA = .false., L_REST = .false., L_ADVECT = .false.
     character(len=200) :: ocnT_file = 'none', sal_file = 'none'
   end type kpp_const_type
 
@@ -91,6 +97,20 @@ contains
       s%wU = 0; s%wX = 0; s%wXNT = 0; s%Rig = 0; s%dbloc = 0; s%Shsq = 0; s%swfrac = 0; s%swdk_opt = 0
     end associate
   end subroutine mckpp_allocate_3d_fields
+
+  !> Components only the optional switches touch (reference extents, data_fields.F90:380-398)
+  subroutine mckpp_allocate_3d_optional()
+    associate (s => kpp_3d_fields)
+      allocate (s%relax_sst(npts), s%SST0(npts), s%fcorr_twod(npts), s%relax_sal(npts), s%relax_ocnT(npts), s%fcorr(npts))
+      allocate (s%fcorr_withz(npts,nzp1), s%sfcorr_withz(npts,nzp1), s%ocnT_clim(npts,nzp1), s%sal_clim(npts,nzp1))
+      allocate (s%tinc_fcorr(npts,nzp1), s%sinc_fcorr(npts,nzp1), s%ocnTcorr(npts,nzp1), s%scorr(npts,nzp1))
+      allocate (s%nmodeadv(npts,2), s%modeadv(npts,maxmodeadv,2), s%advection(npts,maxmodeadv,2))
+      s%relax_sst = 0; s%SST0 = 0; s%fcorr_twod = 0; s%relax_sal = 0; s%relax_ocnT = 0; s%fcorr = 0
+      s%fcorr_withz = 0; s%sfcorr_withz = 0; s%ocnT_clim = 0; s%sal_clim = 0
+      s%tinc_fcorr = 0; s%sinc_fcorr = 0; s%ocnTcorr = 0; s%scorr = 0
+      s%nmodeadv = 0; s%modeadv = 0; s%advection = 0
+    end associate
+  end subroutine mckpp_allocate_3d_optional
 
   subroutine mckpp_allocate_1d_fields(q)
     type(kpp_1d_type), intent(inout) :: q

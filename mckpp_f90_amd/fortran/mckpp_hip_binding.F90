@@ -16,6 +16,7 @@ module mckpp_hip_binding
     integer(c_int32_t) :: L_NO_FREEZE, L_NO_ISOTHERM, L_DAMP_CURR
     integer(c_int32_t) :: clim_present
     integer(c_int32_t) :: iso_bot, dt_uvdamp
+    integer(c_int32_t) :: maxmodeadv, L_ADVECT
     real(c_double) :: hmixtolfrac, dto, grav, vonk, sice, iso_thresh
     type(c_ptr) :: zm, hm, dm, tri, wmt, wst
   end type mckpp_const_c
@@ -30,6 +31,10 @@ module mckpp_hip_binding
     type(c_ptr) :: old, new_, jerlov
     type(c_ptr) :: l_ocean, l_initflag, run_physics
     type(c_ptr) :: rho, cp, buoy, difm, difs, dift, wU, wX, wXNT, ghat, Rig, Shsq, dbloc, swfrac, swdk_opt
+    type(c_ptr) :: relax_sst, SST0, fcorr_twod, relax_sal, relax_ocnT, fcorr
+    type(c_ptr) :: fcorr_withz, sfcorr_withz, ocnT_clim, sal_clim
+    type(c_ptr) :: tinc_fcorr, sinc_fcorr, ocnTcorr, scorr
+    type(c_ptr) :: nmodeadv, modeadv, advection
   end type mckpp_state_ptrs_c
 
   interface

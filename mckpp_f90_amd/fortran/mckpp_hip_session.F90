@@ -48,6 +48,7 @@ contains
     ! src/mckpp_physics_overrides.F90:57-58
     c%clim_present = l2i(trim(k%ocnT_file) /= 'none' .and. trim(k%sal_file) /= 'none')
     c%iso_bot = k%iso_bot; c%dt_uvdamp = k%dt_uvdamp
+    c%maxmodeadv = maxmodeadv; c%L_ADVECT = l2i(k%L_ADVECT)
     c%hmixtolfrac = hmixtolfrac; c%dto = k%dto; c%grav = k%grav; c%vonk = k%vonk; c%sice = k%sice
     c%iso_thresh = k%iso_thresh
     c%zm = c_loc(k%zm); c%hm = c_loc(k%hm); c%dm = c_loc(k%dm)
@@ -74,7 +75,31 @@ contains
     s%wU = c_loc(f%wU); s%wX = c_loc(f%wX); s%wXNT = c_loc(f%wXNT); s%ghat = c_loc(f%ghat)
     s%Rig = c_loc(f%Rig); s%Shsq = c_loc(f%Shsq); s%dbloc = c_loc(f%dbloc)
     s%swfrac = c_loc(f%swfrac); s%swdk_opt = c_loc(f%swdk_opt)
+    s%relax_sst = opt1(f%relax_sst); s%SST0 = opt1(f%SST0); s%fcorr_twod = opt1(f%fcorr_twod)
+    s%relax_sal = opt1(f%relax_sal); s%relax_ocnT = opt1(f%relax_ocnT); s%fcorr = opt1(f%fcorr)
+    s%fcorr_withz = opt2(f%fcorr_withz); s%sfcorr_withz = opt2(f%sfcorr_withz)
+    s%ocnT_clim = opt2(f%ocnT_clim); s%sal_clim = opt2(f%sal_clim)
+    s%tinc_fcorr = opt2(f%tinc_fcorr); s%sinc_fcorr = opt2(f%sinc_fcorr)
+    s%ocnTcorr = opt2(f%ocnTcorr); s%scorr = opt2(f%scorr)
+    s%nmodeadv = c_null_ptr; s%modeadv = c_null_ptr; s%advection = c_null_ptr
+    if (allocated(f%nmodeadv)) s%nmodeadv = c_loc(f%nmodeadv)
+    if (allocated(f%modeadv)) s%modeadv = c_loc(f%modeadv)
+    if (allocated(f%advection)) s%advection = c_loc(f%advection)
   end subroutine mckpp_hip_state_view
+
+  !> c_loc of an optional (possibly unallocated) component
+  function opt1(a) result(p)
+    real(c_double), allocatable, target, intent(in) :: a(:)
+    type(c_ptr) :: p
+    p = c_null_ptr
+    if (allocated(a)) p = c_loc(a)
+  end function opt1
+  function opt2(a) result(p)
+    real(c_double), allocatable, target, intent(in) :: a(:,:)
+    type(c_ptr) :: p
+    p = c_null_ptr
+    if (allocated(a)) p = c_loc(a)
+  end function opt2
 
   !> Create the device context from kpp_const_fields (idempotent).
   subroutine mckpp_hip_attach()

@@ -58,7 +58,7 @@ contains
       one%sflux(1,:,:,:) = q%sflux
       one%old(1) = q%old; one%new(1) = q%new; one%jerlov(1) = q%jerlov
       one%l_ocean(1) = q%l_ocean; one%l_initflag(1) = q%l_initflag; one%run_physics(1) = .true.
-      call mckpp_hip_state_view(one, 1, s)
+      call mckpp_hip_state_view(one, 1, s)   ! optional-physics components stay unallocated -> NULL
       call mckpp_hip_check(mckpp_hip_upload(h1, s), 'mckpp_hip_upload (ocnstep)')
       call mckpp_hip_check(mckpp_hip_step(h1, int(ntime, c_int), 1_c_int), 'mckpp_hip_step (ocnstep)')
       call mckpp_hip_check(mckpp_hip_download(h1, s, int(MCKPP_F_ALL, c_int32_t)), 'mckpp_hip_download (ocnstep)')

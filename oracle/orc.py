@@ -195,6 +195,9 @@ class Batch:
         for n in INT_FIELDS:
             if want is None or n in want:
                 self.a[n] = np.zeros(ncol, dtype=np.int32)
+        self.a["nmodeadv"] = np.zeros((ncol, 2), dtype=np.int32)
+        self.a["modeadv"] = np.zeros((ncol, 2, 6), dtype=np.int32)
+        self.a["advection"] = np.zeros((ncol, 2, 6))
         self.a["sflux"] = np.zeros((ncol, 6))
         self.a["hmixd"] = np.zeros((ncol, 2))
         self.a["ocdepth"] = np.full(ncol, -10000.0)

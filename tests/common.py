@@ -25,6 +25,7 @@ def make_oracle(ncol, nz, mix="bench", exp_mode=1, grid="uniform", dto=3600.0, n
                 index=None, ntotal=None, **sw):
     """Oracle const + batch with synthetic columns; runs init_ocean unless init=False."""
     zm, hm, dm = grid_for(nz, grid)
+    sw = {k: v for k, v in sw.items() if k != "L_ADVECT"}   # the oracle keys advection on nmodeadv alone
     oc = orc.Const(nz, dto=dto, exp_mode=exp_mode, zm=zm, hm=hm, dm=dm, **sw)
     col = synth.columns(ncol, nz, zm=zm, index=index, ntotal=ntotal)
     ob = orc.Batch(ncol, nz)
@@ -87,6 +88,7 @@ def batch_to_3d_view(ob, name, lo, n):
 
 PROFILE_FIELDS = ["U", "V", "T", "S", "Us0", "Us1", "Vs0", "Vs1", "Ts0", "Ts1", "Ss0", "Ss1"]
 SCALAR_FIELDS = ["hmix", "kmix", "Tref", "uref", "vref", "Ssurf", "reset_flag"]
+EXT_SCALARS = ["fcorr", "freeze_flag", "dampu_flag", "dampv_flag"]
 DIAG_FIELDS = {  # batch name -> (3d array, component or None, first index, count(nz))
     "rho": ("rho", None, 0, lambda nz: nz + 2), "cp": ("cp", None, 0, lambda nz: nz + 2),
     "buoy": ("buoy", None, 1, lambda nz: nz + 1),
@@ -98,7 +100,10 @@ DIAG_FIELDS = {  # batch name -> (3d array, component or None, first index, coun
     "Rig": ("Rig", None, 1, lambda nz: nz), "dbloc": ("dbloc", None, 1, lambda nz: nz),
     "Shsq": ("Shsq", None, 1, lambda nz: nz),
     "swfrac": ("swfrac", None, 1, lambda nz: nz + 1), "swdk_opt": ("swdk_opt", None, 0, lambda nz: nz + 1),
+    "tinc_fcorr": ("tinc_fcorr", None, 1, lambda nz: nz + 1), "sinc_fcorr": ("sinc_fcorr", None, 1, lambda nz: nz + 1),
+    "ocnTcorr": ("ocnTcorr", None, 1, lambda nz: nz + 1), "scorr": ("scorr", None, 1, lambda nz: nz + 1),
 }
+EXT_FIELDS = ["tinc_fcorr", "sinc_fcorr", "ocnTcorr", "scorr", "fcorr", "freeze_flag", "dampu_flag", "dampv_flag"]
 
 
 def hip_field(k3, name, nz):
@@ -127,7 +132,7 @@ def compare(k3, ob, nz, fields, active=None):
     out = {}
     sel = slice(None) if active is None else active
     for name in fields:
-        if name in SCALAR_FIELDS or name in ("hmixd0", "hmixd1"):
+        if name in SCALAR_FIELDS or name in EXT_SCALARS or name in ("hmixd0", "hmixd1"):
             if name.startswith("hmixd"):
                 h = k3.hmixd[:, int(name[-1])]
                 o = ob["hmixd"][:, int(name[-1])]

@@ -1,0 +1,149 @@
+"""the optional physics switches of ocnint / ocnstep / check_profile on the device
+(src/mckpp_physics_ocnint_mod.F90:97-215, src/mckpp_physics_solvers.F90:176-335,
+src/mckpp_physics_verticalmixing_ddmix_mod.F90, src/mckpp_physics_ocnstep_mod.F90:317-340,
+src/mckpp_physics_overrides.F90:42-125).  Every switch combination is compared bit for bit with the
+oracle's restatement on identical inputs."""
+import numpy as np
+import pytest
+
+import common as cm
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = cm.PROFILE_FIELDS + cm.SCALAR_FIELDS + ["hmixd0", "hmixd1"] + list(cm.DIAG_FIELDS.keys()) + cm.EXT_SCALARS
+
+
+@pytest.fixture(scope="module")
+def mk(built):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X (no HIP device visible)")
+    import mckpp_f90_amd as m
+
+    return m
+
+
+def _case(mk, ncol, nz, switches, prep, nsteps=2, grid="uniform"):
+    """switches: dict of kpp_const switch -> value (same names on both sides);
+    prep(k3, ob, col_T, col_S): fill the optional input fields identically on both sides."""
+    from oracle import orc
+
+    oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1, grid=grid, **switches)
+    kc, k3 = cm.make_hip_case(ncol, nz, grid=grid)
+    for k, v in switches.items():
+        setattr(kc, k, v)
+    prep(k3, ob)
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    orc.init_ocean(oc, ob, 0)
+    sf = cm.synth.forcing(ncol, "bench")
+    ob["sflux"] = sf
+    cm.set_forcing_3d(k3, sf)
+    for nt in range(1, nsteps + 1):
+        ctx = mk.mckpp_physics_driver(k3, kc, nt)
+        orc.physics_driver(oc, ob, nt)
+        st, nf, npass = ctx.status()
+        assert np.array_equal(st, ob["status"]) and np.array_equal(npass, ob["npasses"])
+        res = cm.compare(k3, ob, nz, FIELDS)
+        bad = {k: v for k, v in res.items() if v[2] != 0}
+        assert not bad, f"{switches} step {nt}: {bad}"
+    return k3, ob
+
+
+def _set2(k3, ob, name, arr):
+    """same (ncol, nzp1) profile field on both sides"""
+    nzp1 = arr.shape[1]
+    getattr(k3, name)[:, :] = arr
+    ob.a[name][:, 1:nzp1 + 1] = arr
+
+
+def test_relax_sst_and_calconly(mk):
+    def prep(k3, ob):
+        n = k3.npts
+        r = np.full(n, 1.0 / (5 * 86400.0)); r[::4] = 0.0        # some columns not relaxed
+        k3.relax_sst[:] = r; ob["relax_sst"] = r
+        sst = k3.X[:, 0, 0] + 1.5
+        k3.SST0[:] = sst; ob["SST0"] = sst
+    k3, ob = _case(mk, 96, 40, dict(L_RELAX_SST=1), prep)
+    assert np.any(k3.fcorr != 0) and np.all(k3.fcorr[::4] == 0)
+    _case(mk, 32, 40, dict(L_RELAX_SST=1, L_RELAX_CALCONLY=1), prep)
+
+
+def test_fcorr_twod_and_withz(mk):
+    def prep2(k3, ob):
+        v = np.linspace(-80.0, 80.0, k3.npts)
+        k3.fcorr_twod[:] = v; ob["fcorr_twod"] = v
+    _case(mk, 64, 40, dict(L_FCORR=1), prep2)
+
+    def prepz(k3, ob):
+        nzp1 = k3.X.shape[1]
+        z = np.arange(nzp1)[None, :]
+        _set2(k3, ob, "fcorr_withz", 5.0 * np.exp(-z / 10.0) * np.linspace(-1, 1, k3.npts)[:, None])
+        _set2(k3, ob, "sfcorr_withz", 1e-7 * np.cos(z / 7.0) * np.ones((k3.npts, 1)))
+    k3, ob = _case(mk, 64, 40, dict(L_FCORR_WITHZ=1, L_SFCORR_WITHZ=1), prepz)
+    assert np.any(k3.tinc_fcorr != 0) and np.any(k3.scorr != 0)
+
+
+def test_relax_ocnt_and_sal(mk):
+    def prep(k3, ob):
+        n = k3.npts
+        _set2(k3, ob, "ocnT_clim", np.asarray(k3.X[:, :, 0]) - 0.3)
+        _set2(k3, ob, "sal_clim", np.asarray(k3.X[:, :, 1]) + 0.05)
+        r = np.full(n, 1.0 / (30 * 86400.0))
+        k3.relax_ocnT[:] = r; ob["relax_ocnT"] = r
+        k3.relax_sal[:] = 2 * r; ob["relax_sal"] = 2 * r
+    k3, ob = _case(mk, 64, 60, dict(L_RELAX_OCNT=1, L_RELAX_SAL=1), prep)
+    assert np.any(k3.ocnTcorr != 0) and np.any(k3.sinc_fcorr != 0)
+
+
+def test_double_diffusion(mk):
+    def prep(k3, ob):
+        # salt-fingering favourable stratification on half of the columns: warm salty over cold fresh
+        nzp1 = k3.X.shape[1]
+        z = np.linspace(0, 1, nzp1)[None, :]
+        S = np.asarray(k3.X[:, :, 1]).copy()
+        S[::2] = 0.4 - 0.8 * z
+        k3.X[:, :, 1] = S
+        ob.a["S"][:, 1:nzp1 + 1] = S
+    _case(mk, 64, 40, dict(LDD=1), prep, nsteps=3)
+
+
+def test_current_damping(mk):
+    _case(mk, 64, 40, dict(L_DAMP_CURR=1, dt_uvdamp=360), lambda k3, ob: None)
+
+
+def test_no_freeze_and_isotherm_and_clim_reset(mk):
+    def prep(k3, ob):
+        nzp1 = k3.X.shape[1]
+        T = np.asarray(k3.X[:, :, 0]).copy()
+        T[::3, :] = -2.2                       # below -1.8 everywhere: clamped, freeze_flag counts levels
+        T[1::3, :] = 12.0                      # isothermal columns: reset to climatology
+        k3.X[:, :, 0] = T
+        ob.a["T"][:, 1:nzp1 + 1] = T
+        _set2(k3, ob, "ocnT_clim", 8.0 + 10.0 * np.exp(-np.arange(nzp1) / 15.0)[None, :] * np.ones((k3.npts, 1)))
+        _set2(k3, ob, "sal_clim", np.asarray(k3.X[:, :, 1]) * 0.5)
+        k3.U[2::3, 0:3, 0] = 40.0              # absurd currents: trap -> climatology + U_init
+        ob.a["U"][2::3, 1:4] = 40.0
+    sw = dict(L_NO_FREEZE=1, L_NO_ISOTHERM=1, clim_present=1, iso_bot=20, iso_thresh=0.002)
+    k3, ob = _case(mk, 60, 40, sw, prep, nsteps=1)
+    # frozen columns clamped, isothermal columns reset (negative count), trapped columns reset to climatology
+    assert np.any(k3.freeze_flag > 0) and np.any(k3.reset_flag < 0) and np.any(np.abs(k3.reset_flag) == 999)
+    _case(mk, 60, 40, sw, prep, nsteps=3)
+
+
+@pytest.mark.parametrize("grid", ["uniform", "stretched"])
+def test_prescribed_advection_modes(mk, grid):
+    def prep(k3, ob):
+        n = k3.npts
+        for c in range(n):
+            mode = 1 + (c % 7)
+            k3.nmodeadv[c, 1] = 2
+            k3.modeadv[c, 0, 1] = mode
+            k3.modeadv[c, 1, 1] = 1 + ((c + 3) % 7)
+            k3.advection[c, 0, 1] = 1e-6 * (1 + c % 5)
+            k3.advection[c, 1, 1] = -5e-7
+        ob["nmodeadv"][:, 1] = k3.nmodeadv[:, 1]
+        ob["modeadv"][:, 1, :] = k3.modeadv[:, :, 1]
+        ob["advection"][:, 1, :] = k3.advection[:, :, 1]
+    nz = 60 if grid == "uniform" else 69
+    _case(mk, 70, nz, dict(L_ADVECT=1), prep, grid=grid)

@@ -197,8 +197,11 @@ def test_edge_sizes_and_errors(mk):
     assert ctx.ncolumns == 0 and np.all(k3.hmix == 0)
     # unsupported switches and bad inputs are refused with a message, never computed on the CPU
     kc2, k32 = cm.make_hip_case(4, 40)
-    kc2.LDD = 1
-    with pytest.raises(mk.MckppHipError, match="not implemented"):
+    kc2.L_NO_ISOTHERM, kc2.iso_bot = 1, 1
+    with pytest.raises(mk.MckppHipError, match="iso_bot"):
+        mk.MckppHip(kc2)
+    kc2.L_NO_ISOTHERM, kc2.LKPP = 0, 0
+    with pytest.raises(mk.MckppHipError, match="LKPP"):
         mk.MckppHip(kc2)
     kc3, k33 = cm.make_hip_case(4, 40)
     k33.jerlov[2] = 9
