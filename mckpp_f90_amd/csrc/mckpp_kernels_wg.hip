@@ -96,7 +96,6 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
   // ---- per-slot register state -------------------------------------------
   double U[LPL], V[LPL], T[LPL], S[LPL];
   double Uo[LPL], Vo[LPL], To[LPL], So[LPL];
-  double Ux[LPL], Vx[LPL], Tx[LPL], Sx[LPL];
   double talpha[LPL], sbeta[LPL];
   double xt[LPL];   // EXT: tinc_fcorr of the latest pass (overrides.F90:87-88 adds to it)
   int kk[LPL];
@@ -108,7 +107,6 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     actz[j] = k <= nz;
     U[j] = V[j] = T[j] = S[j] = 0.0;
     Uo[j] = Vo[j] = To[j] = So[j] = 0.0;
-    Ux[j] = Vx[j] = Tx[j] = Sx[j] = 0.0;
     talpha[j] = sbeta[j] = 0.0;
     xt[j] = 0.0;
   }
@@ -141,11 +139,15 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       double vo = act[j] ? p.Vs[old][o] : 0.0, vn = act[j] ? p.Vs[newi][o] : 0.0;
       double to = act[j] ? p.Ts[old][o] : 0.0, tn = act[j] ? p.Ts[newi][o] : 0.0;
       double so = act[j] ? p.Ss[old][o] : 0.0, sn = act[j] ? p.Ss[newi][o] : 0.0;
-      U[j] = 2. * un - uo; Ux[j] = U[j];
-      V[j] = 2. * vn - vo; Vx[j] = V[j];
-      T[j] = 2. * tn - to; Tx[j] = T[j];
-      S[j] = 2. * sn - so; Sx[j] = S[j];
+      U[j] = 2. * un - uo;
+      V[j] = 2. * vn - vo;
+      T[j] = 2. * tn - to;
+      S[j] = 2. * sn - so;
+      // the relaxation memory equals the new iterate (Ux = U, ocnstep_mod.F90:105,110): seed the
+      // solution rows with it so the first under-relaxation returns it unchanged
+      if (act[j]) { int k = kk[j]; row(R_YU)[k] = U[j]; row(R_YV)[k] = V[j]; row(R_YT)[k] = T[j]; row(R_YS)[k] = S[j]; }
     }
+    WAVE_LDS_SYNC();
     npass_try = 0;
     iconv = 0;
   };
@@ -170,7 +172,6 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       U[j] = act[j] ? p.U[o] : 0.0; V[j] = act[j] ? p.V[o] : 0.0;
       T[j] = act[j] ? p.T[o] : 0.0; S[j] = act[j] ? p.S[o] : 0.0;
       Uo[j] = U[j]; Vo[j] = V[j]; To[j] = T[j]; So[j] = S[j];
-      Ux[j] = U[j]; Vx[j] = V[j]; Tx[j] = T[j]; Sx[j] = S[j];
     }
     if (p.mode == MCKPP_MODE_STEP) extrapolate();
     if (p.mode == MCKPP_MODE_INIT) l_initflag = 1;   // initialize_ocean.F90:59
@@ -188,12 +189,17 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     const double *cs = csrow();
     const double Sref = cs[CS_SREF];
     if (p.mode == MCKPP_MODE_STEP) {
-      FORJ {   // under-relaxation, ocnstep_mod.F90:123-132 / :142-151
-        U[j] = lambda * Ux[j] + (1 - lambda) * U[j]; Ux[j] = U[j];
-        V[j] = lambda * Vx[j] + (1 - lambda) * V[j]; Vx[j] = V[j];
-        T[j] = lambda * Tx[j] + (1 - lambda) * T[j]; Tx[j] = T[j];
-        S[j] = lambda * Sx[j] + (1 - lambda) * S[j]; Sx[j] = S[j];
+      // under-relaxation, ocnstep_mod.F90:123-132 / :142-151.  The registers hold the previous
+      // iterate (the reference's Ux/Xx), the slot's solution rows hold what ocnint returned.
+      const double *yU = row(R_YU), *yV = row(R_YV), *yT = row(R_YT), *yS = row(R_YS);
+      FORJ if (act[j]) {
+        int k = kk[j];
+        U[j] = lambda * U[j] + (1 - lambda) * yU[k];
+        V[j] = lambda * V[j] + (1 - lambda) * yV[k];
+        T[j] = lambda * T[j] + (1 - lambda) * yT[k];
+        S[j] = lambda * S[j] + (1 - lambda) * yS[k];
       }
+      WAVE_LDS_SYNC();
     }
     const double zm1 = first_lane(c_zm[1]), zm_kmp1 = first_lane(c_zm[nzp1]);
     double zmk[LPL], rho[LPL], cp[LPL], buoy[LPL];
@@ -652,6 +658,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       if constexpr (EXT) ext_rhs(k, j, kbl, rhsT, rhsS);
       yU[k] = rhsU; yT[k] = rhsT; yS[k] = rhsS;
     }
+    FORJ if (kk[j] == nzp1) { yU[nzp1] = Uo[j]; yT[nzp1] = To[j]; yS[nzp1] = So[j]; }   // solvers.F90:159
     if constexpr (EXT) {   // tinc_fcorr / ocnTcorr / sinc_fcorr / scorr of level nzp1 (ocnint_mod.F90:153-160, 207-213)
       FORJ if (kk[j] == nzp1) { double t = 0.0, s2 = 0.0; ext_rhs(nzp1, j, kbl, t, s2); }
     }
@@ -659,7 +666,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
 
   // ---- phase E: collect U,T,S; V right-hand side (ocnint_mod.F90:62-69) ----
   auto phaseE = [&]() {
-    const double *yU = row(R_YU), *yT = row(R_YT), *yS = row(R_YS);
+    const double *yU = row(R_YU);
     double *yV = row(R_YV);
     const double Vo_np = first_lane(bcast_level(Vo, lane_np, j_np));
     const double dto = p.dto, tri1_nz = first_lane(c_t1[nz]), hm1 = first_lane(c_hm[1]), f = first_lane(sc[C_F]),
@@ -667,14 +674,14 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     FORJ {
       int k = kk[j];
       if (actz[j]) {
-        U[j] = yU[k]; T[j] = yT[k]; S[j] = yS[k];
+        const double un = yU[k];
         double rhsV;
-        if (k == 1) rhsV = Vo[j] - dto * (f * .5 * (Uo[j] + U[j]) + wU0_2 / hm1);
-        else rhsV = Vo[j] - dto * f * .5 * (Uo[j] + U[j]);
+        if (k == 1) rhsV = Vo[j] - dto * (f * .5 * (Uo[j] + un) + wU0_2 / hm1);
+        else rhsV = Vo[j] - dto * f * .5 * (Uo[j] + un);
         if (k == nz) rhsV = rhsV + tri1_nz * aDm[k] * Vo_np;
         yV[k] = rhsV;
       } else if (act[j]) {   // yn(nzi+1) = yo(nzi+1), solvers.F90:159
-        U[j] = Uo[j]; T[j] = To[j]; S[j] = So[j];
+        yV[k] = Vo[j];
       }
     }
   };
@@ -863,16 +870,18 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
 
   // ---- phase G: collect V; ocnstep control (ocnstep_mod.F90:122-236) ----
   auto phaseG = [&]() {
-    if (p.mode != MCKPP_MODE_INIT) {
-      const double *yV = row(R_YV);
-      FORJ {
-        if (actz[j]) V[j] = yV[kk[j]];
-        else if (act[j]) V[j] = Vo[j];
-      }
-      if (sbad[wave]) status |= 1;
-    }
+    auto load_solution = [&]() {   // U,V,T,S <- what the last ocnint returned
+      const double *yU = row(R_YU), *yV = row(R_YV), *yT = row(R_YT), *yS = row(R_YS);
+      FORJ if (act[j]) { int k = kk[j]; U[j] = yU[k]; V[j] = yV[k]; T[j] = yT[k]; S[j] = yS[k]; }
+      WAVE_LDS_SYNC();
+    };
+    if (p.mode != MCKPP_MODE_INIT && sbad[wave]) status |= 1;
     ++npass;
-    if (p.mode != MCKPP_MODE_STEP) { finalize(); return; }
+    if (p.mode != MCKPP_MODE_STEP) {
+      if (p.mode != MCKPP_MODE_INIT) load_solution();
+      finalize();
+      return;
+    }
     ++npass_try;
     const double hbl = sc[C_HBL];
     if (npass_try <= 3) {   // compulsory passes
@@ -892,6 +901,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       else if (hmixn > hmixe) { put(C_HMIXE, hmixn); kmixe = kmixn; return; }
     }
     if (npass_try > (p.itermax + 1)) status |= 2;
+    load_solution();
     // instability trap
     comp_flag = 0;
     double f = sc[C_F];
