@@ -191,6 +191,15 @@ int mckpp_hip_download(mckpp_hip_handle h, mckpp_state_ptrs_c *s, uint32_t field
 int mckpp_hip_save_restart(mckpp_hip_handle h, const char *path);
 int mckpp_hip_load_restart(mckpp_hip_handle h, const char *path);
 
+/* Output-window reductions on the device (replace the XIOS temporal operations
+ * "average" / "minimum" / "maximum" of run/iodef.xml:91-116 on the fields sent
+ * at src/mckpp_xios_io.F90:74-210): reset at the start of an output window,
+ * accumulate once after each step, fetch at the end.
+ * field: 0 U, 1 V, 2 T, 3 S -> out(npts,nzp1); 4 hmix -> out(npts).  op: 0 mean, 1 min, 2 max. */
+int mckpp_hip_window_reset(mckpp_hip_handle h);
+int mckpp_hip_window_accumulate(mckpp_hip_handle h);
+int mckpp_hip_window_fetch(mckpp_hip_handle h, int field, int op, double *out);
+
 /* Per-column status words (npts entries in 3D ordering; land = 0), number of
  * columns with a non-zero word, and (optional) vmix+ocnint passes per column
  * of the last step. Any output pointer may be NULL. */

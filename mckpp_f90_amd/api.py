@@ -91,6 +91,9 @@ def _bind(lib):
     lib.mckpp_hip_upload.argtypes = [C.c_void_p, C.POINTER(_StateC)]
     lib.mckpp_hip_set_forcing.argtypes = [C.c_void_p, _dp]
     lib.mckpp_hip_set_diagnostics.argtypes = [C.c_void_p, C.c_int]
+    lib.mckpp_hip_window_reset.argtypes = [C.c_void_p]
+    lib.mckpp_hip_window_accumulate.argtypes = [C.c_void_p]
+    lib.mckpp_hip_window_fetch.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
     lib.mckpp_hip_save_restart.argtypes = [C.c_void_p, C.c_char_p]
     lib.mckpp_hip_load_restart.argtypes = [C.c_void_p, C.c_char_p]
     lib.mckpp_hip_fluxes.argtypes = [C.c_void_p, C.c_int] + [_dp] * 8 + [C.c_int, C.c_double, C.c_double]
@@ -278,6 +281,17 @@ class MckppHip:
     def load_restart(self, path, npts):
         _chk(_lib().mckpp_hip_load_restart(self._h, str(path).encode()))
         self._npts_cache = npts
+
+    def window_reset(self):
+        _chk(_lib().mckpp_hip_window_reset(self._h))
+
+    def window_accumulate(self):
+        _chk(_lib().mckpp_hip_window_accumulate(self._h))
+
+    def window_fetch(self, field, op, out):
+        assert out.flags["F_CONTIGUOUS"] and out.dtype == np.float64
+        _chk(_lib().mckpp_hip_window_fetch(self._h, int(field), int(op), out.ctypes.data_as(_dp)))
+        return out
 
     def set_diagnostics(self, on):
         _chk(_lib().mckpp_hip_set_diagnostics(self._h, int(on)))

@@ -79,6 +79,10 @@ hipError_t mckpp_launch_eos_batch(int64_t n, const double *s, const double *t, c
 hipError_t mckpp_launch_exp_batch(int64_t n, const double *x, double *y, hipStream_t stream);
 hipError_t mckpp_launch_fluxes(const mckpp_kparams &p, int ntime, const double *f8, int l_rest, double flsn,
                                double el, hipStream_t stream);
+hipError_t mckpp_launch_window_accumulate(const double *u, const double *v, const double *t, const double *s,
+                                          double *acc, size_t nelem, const double *cs, double *hacc, int ncol,
+                                          int first, hipStream_t stream);
+hipError_t mckpp_launch_window_mean(const double *sum, double *out, size_t n, double count, hipStream_t stream);
 // layout kernels: Fortran (npts-fastest) <-> device rows
 hipError_t mckpp_launch_gather_rows(const double *src3d, int64_t npts, int nlev, int lev_off,
                                     const int *ipt, int64_t ncol, double *dst, int ld, int dst_off,

@@ -892,6 +892,49 @@ __global__ void k_fluxes(mckpp_kparams p, int ntime, const double *__restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Output-window reductions: running sum / min / max of the
+// profile rows and of hmix, replacing XIOS's temporal operations
+// (run/iodef.xml:91-116) so only reduced fields leave the device.  Pure
+// streaming: 16 B per lane per access, one pass over the rows per step.
+// acc layout: [field][3][ncol*ld] with 3 = {sum, min, max}; hacc: [3][ncol].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_window_accumulate(const double2 *__restrict__ u, const double2 *__restrict__ v,
+                                                         const double2 *__restrict__ t, const double2 *__restrict__ s,
+                                                         double2 *__restrict__ acc, size_t n2, const double *__restrict__ cs,
+                                                         double *__restrict__ hacc, int ncol, int first)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const double2 *src[4] = {u, v, t, s};
+  if (i < n2) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const double2 x = src[f][i];
+      double2 *a = acc + (size_t)f * 3 * n2;
+      double2 sm = a[i], mn = a[n2 + i], mx = a[2 * n2 + i];
+      if (first) { sm = make_double2(0.0, 0.0); mn = x; mx = x; }
+      sm.x = sm.x + x.x; sm.y = sm.y + x.y;
+      mn.x = x.x < mn.x ? x.x : mn.x; mn.y = x.y < mn.y ? x.y : mn.y;
+      mx.x = x.x > mx.x ? x.x : mx.x; mx.y = x.y > mx.y ? x.y : mx.y;
+      a[i] = sm; a[n2 + i] = mn; a[2 * n2 + i] = mx;
+    }
+  }
+  if (i < (size_t)ncol) {
+    const double h = cs[i * MCKPP_CS + CS_HMIX];
+    double sm = hacc[i], mn = hacc[ncol + i], mx = hacc[2 * (size_t)ncol + i];
+    if (first) { sm = 0.0; mn = h; mx = h; }
+    hacc[i] = sm + h;
+    hacc[ncol + i] = h < mn ? h : mn;
+    hacc[2 * (size_t)ncol + i] = h > mx ? h : mx;
+  }
+}
+
+__global__ void k_window_mean(const double *__restrict__ sum, double *__restrict__ out, size_t n, double count)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = sum[i] / count;
+}
+
 }  // namespace
 
 size_t mckpp_column_kernel_lds_bytes(int nzp1)
@@ -960,5 +1003,24 @@ hipError_t mckpp_launch_fluxes(const mckpp_kparams &p, int ntime, const double *
   if (p.ncol <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_fluxes, dim3((unsigned)((p.ncol + 255) / 256)), dim3(256), 0, stream, p, ntime, f8, l_rest,
                      flsn, el);
+  return hipGetLastError();
+}
+
+hipError_t mckpp_launch_window_accumulate(const double *u, const double *v, const double *t, const double *s,
+                                          double *acc, size_t nelem, const double *cs, double *hacc, int ncol,
+                                          int first, hipStream_t stream)
+{
+  const size_t n2 = nelem / 2;   // rows are 64*LPL doubles: always even
+  const size_t nthreads = n2 > (size_t)ncol ? n2 : (size_t)ncol;
+  hipLaunchKernelGGL(k_window_accumulate, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream,
+                     reinterpret_cast<const double2 *>(u), reinterpret_cast<const double2 *>(v),
+                     reinterpret_cast<const double2 *>(t), reinterpret_cast<const double2 *>(s),
+                     reinterpret_cast<double2 *>(acc), n2, cs, hacc, ncol, first);
+  return hipGetLastError();
+}
+
+hipError_t mckpp_launch_window_mean(const double *sum, double *out, size_t n, double count, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_window_mean, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sum, out, n, count);
   return hipGetLastError();
 }

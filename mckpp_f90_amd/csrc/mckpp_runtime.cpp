@@ -78,6 +78,8 @@ struct mckpp_hip_ctx {
   double *d_ext_out[O_COUNT] = {};
   double *d_xs = nullptr, *d_adv_d = nullptr, *d_dm = nullptr, *d_hsum = nullptr;
   int *d_adv_i = nullptr;
+  double *d_wacc = nullptr, *d_whacc = nullptr;   // output-window accumulators
+  int window_count = 0;
   double *d_cs = nullptr;
   int *d_ci = nullptr;
   int *d_qhead = nullptr;
@@ -268,6 +270,9 @@ static void free_state(mckpp_hip_ctx *h)
   if (h->d_adv_d) hipFree(h->d_adv_d);
   if (h->d_adv_i) hipFree(h->d_adv_i);
   h->d_xs = nullptr; h->d_adv_d = nullptr; h->d_adv_i = nullptr;
+  if (h->d_wacc) hipFree(h->d_wacc);
+  if (h->d_whacc) hipFree(h->d_whacc);
+  h->d_wacc = nullptr; h->d_whacc = nullptr; h->window_count = 0;
   if (h->d_cs) hipFree(h->d_cs);
   if (h->d_ci) hipFree(h->d_ci);
   if (h->d_ipt) hipFree(h->d_ipt);
@@ -815,6 +820,63 @@ int mckpp_hip_load_restart(mckpp_hip_handle h, const char *path)
   ok = ok && hipMemcpy(h->d_ci, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
   fclose(f);
   if (!ok) return fail("mckpp_hip_load_restart: %s is truncated or unreadable", path);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Output-window reductions
+// ---------------------------------------------------------------------------
+int mckpp_hip_window_reset(mckpp_hip_handle h)
+{
+  if (!h) return fail("null handle");
+  h->window_count = 0;
+  return 0;
+}
+
+int mckpp_hip_window_accumulate(mckpp_hip_handle h)
+{
+  if (!h) return fail("null handle");
+  if (h->ncol == 0) return 0;
+  HIPCHK(hipSetDevice(h->device));
+  const size_t nelem = (size_t)h->ncol * h->ld;
+  if (!h->d_wacc) {
+    HIPCHK(hipMalloc(&h->d_wacc, 12 * nelem * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_whacc, 3 * (size_t)h->ncol * sizeof(double)));
+  }
+  HIPCHK(mckpp_launch_window_accumulate(h->d_prof[P_U], h->d_prof[P_V], h->d_prof[P_T], h->d_prof[P_S], h->d_wacc,
+                                        nelem, h->d_cs, h->d_whacc, (int)h->ncol, h->window_count == 0, h->stream));
+  h->window_count += 1;
+  return 0;
+}
+
+int mckpp_hip_window_fetch(mckpp_hip_handle h, int field, int op, double *out)
+{
+  if (!h || !out) return fail("mckpp_hip_window_fetch: null argument");
+  if (field < 0 || field > 4 || op < 0 || op > 2) return fail("mckpp_hip_window_fetch: field %d / op %d", field, op);
+  if (h->window_count == 0) return fail("mckpp_hip_window_fetch: empty window");
+  if (h->ncol == 0) return 0;
+  HIPCHK(hipSetDevice(h->device));
+  const size_t nelem = (size_t)h->ncol * h->ld;
+  if (ensure_stage(h, 2 * nelem + (size_t)h->npts * h->nzp1)) return -1;
+  double *tmp = h->d_stage + (size_t)h->npts * h->nzp1;   // behind the region down_rows stages into
+  if (field < 4) {
+    const double *src = h->d_wacc + ((size_t)field * 3 + op) * nelem;
+    if (op == 0) {
+      HIPCHK(mckpp_launch_window_mean(src, tmp, nelem, (double)h->window_count, h->stream));
+      src = tmp;
+    }
+    // reuse the row scatter: stage region [0, npts*nzp1) is free, tmp lives behind it
+    const size_t n = (size_t)h->npts * h->nzp1;
+    if (h->ncol < h->npts) HIPCHK(hipMemcpyAsync(h->d_stage, out, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(mckpp_launch_scatter_rows(src, h->ld, 0, h->d_ipt, h->ncol, h->d_stage, h->npts, h->nzp1, 0, h->stream));
+    HIPCHK(hipMemcpyAsync(out, h->d_stage, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  } else {
+    std::vector<double> hv((size_t)h->ncol);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(hv.data(), h->d_whacc + (size_t)op * h->ncol, hv.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t c = 0; c < h->ncol; ++c) out[h->ipt[c]] = (op == 0) ? hv[c] / (double)h->window_count : hv[c];
+  }
   return 0;
 }
 

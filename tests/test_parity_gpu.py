@@ -346,3 +346,41 @@ def test_restart_roundtrip_n2(mk, tmp_path):
     with pytest.raises(mk.MckppHipError, match="nz=60"):
         mk.MckppHip(kc3).load_restart(rst, ncol)
     ctx2.close()
+
+
+def test_output_window_reductions_n4(mk):
+    """running mean/min/max over an output window, accumulated on the device after
+    each step, against the same reductions of the per-step downloads (with a land mask)."""
+    ncol, nz, nsteps = 300, 60, 5
+    kc, k3 = cm.make_hip_case(ncol, nz, land_every=4)
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    cm.set_forcing_3d(k3, cm.synth.forcing(ncol, "bench"))
+    ctx.set_forcing(k3.sflux)
+    ctx.window_reset()
+    hist = {n: [] for n in ("U", "V", "T", "S", "hmix")}
+    for nt in range(1, nsteps + 1):
+        ctx.step(nt, 1)
+        ctx.window_accumulate()
+        ctx.download(k3, mk.api.F_PROFILES | mk.api.F_SCALARS)
+        hist["U"].append(k3.U[:, :, 0].copy()); hist["V"].append(k3.U[:, :, 1].copy())
+        hist["T"].append(k3.X[:, :, 0].copy()); hist["S"].append(k3.X[:, :, 1].copy())
+        hist["hmix"].append(k3.hmix.copy())
+    ocean = k3.run_physics != 0
+    for f, name in enumerate(("U", "V", "T", "S", "hmix")):
+        stack = np.stack(hist[name])
+        shape = stack.shape[1:]
+        for op, red in enumerate((None, np.min, np.max)):
+            out = np.full(shape, -7.0, order="F")
+            ctx.window_fetch(f, op, out)
+            if op == 0:
+                acc = np.zeros(shape)
+                for x in stack:
+                    acc = acc + x
+                ref = acc / nsteps
+            else:
+                ref = red(stack, axis=0)
+            assert np.array_equal(out[ocean], ref[ocean]), (name, op)
+            assert np.all(out[~ocean] == -7.0)            # land untouched
+    ctx.window_reset()
+    with pytest.raises(mk.MckppHipError, match="empty window"):
+        ctx.window_fetch(2, 0, np.zeros((ncol, nz + 1), order="F"))
