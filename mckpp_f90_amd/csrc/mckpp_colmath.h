@@ -180,12 +180,14 @@ __device__ __forceinline__ void wscale_dev(const mckpp_kparams &p, const wscale_
   }
 }
 
-// Jerlov tables, src/mckpp_physics_swfrac_mod.F90:59-61
+// Jerlov tables, src/mckpp_physics_swfrac_mod.F90:59-61 (constant memory: indexed by a run-time water type)
+static __constant__ double jer_rfac_c[6] = {0, 0.58, 0.62, 0.67, 0.77, 0.78};
+static __constant__ double jer_a1_c[6] = {0, 0.35, 0.6, 1.0, 1.5, 1.4};
+static __constant__ double jer_a2_c[6] = {0, 23.0, 20.0, 17.0, 14.0, 7.9};
+
 __device__ __forceinline__ double swfrac_dev(double fact, double z, int jw)
 {
-  const double rfac[6] = {0, 0.58, 0.62, 0.67, 0.77, 0.78};
-  const double a1[6] = {0, 0.35, 0.6, 1.0, 1.5, 1.4};
-  const double a2[6] = {0, 23.0, 20.0, 17.0, 14.0, 7.9};
+  const double *rfac = jer_rfac_c, *a1 = jer_a1_c, *a2 = jer_a2_c;
   const double rmin = -80.;
   double r1 = dmax2(z * fact / a1[jw], rmin);
   double r2 = dmax2(z * fact / a2[jw], rmin);

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
   constexpr int NA = wg_na<LPL>();
   constexpr int SS = wg_slot_stride<LPL, EXT>();
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: LDS row bases stay scalar
   const int nz = p.nz, nzp1 = p.nzp1;
   double *c_zm = lds, *c_hm = lds + NA, *c_t0 = lds + 2 * NA, *c_t1 = lds + 3 * NA;
   double *slots = lds + 4 * NA;
@@ -95,7 +95,6 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
 
   // ---- per-slot register state -------------------------------------------
   double U[LPL], V[LPL], T[LPL], S[LPL];
-  double Uo[LPL], Vo[LPL], To[LPL], So[LPL];
   double talpha[LPL], sbeta[LPL];
   double xt[LPL];   // EXT: tinc_fcorr of the latest pass (overrides.F90:87-88 adds to it)
   int kk[LPL];
@@ -106,7 +105,6 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     act[j] = k <= nzp1;
     actz[j] = k <= nz;
     U[j] = V[j] = T[j] = S[j] = 0.0;
-    Uo[j] = Vo[j] = To[j] = So[j] = 0.0;
     talpha[j] = sbeta[j] = 0.0;
     xt[j] = 0.0;
   }
@@ -128,6 +126,12 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     return v;
   };
   auto put = [&](int slot, double v) { if (lane == 0) sc[slot] = v; };
+  // start-of-step profiles Uo/Xo (ocnstep_mod.F90:82-83) are the column's own U,V,T,S rows, which
+  // nothing overwrites before finalize: re-read them (L2) where needed instead of pinning registers
+  auto load_old = [&](const double *src, double (&x)[LPL]) {
+    FORJ x[j] = act[j] ? src[(size_t)col * p.ld + lane + 64 * j] : 0.0;
+  };
+  auto old_bottom = [&](const double *src) -> double { return src[(size_t)col * p.ld + (nzp1 - 1)]; };
   auto rowoff = [&]() -> size_t { return (size_t)col * p.ld; };
   auto csrow = [&]() -> double * { return p.cs + (size_t)col * MCKPP_CS; };
 
@@ -171,7 +175,6 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       size_t o = rowoff() + lane + 64 * j;
       U[j] = act[j] ? p.U[o] : 0.0; V[j] = act[j] ? p.V[o] : 0.0;
       T[j] = act[j] ? p.T[o] : 0.0; S[j] = act[j] ? p.S[o] : 0.0;
-      Uo[j] = U[j]; Vo[j] = V[j]; To[j] = T[j]; So[j] = S[j];
     }
     if (p.mode == MCKPP_MODE_STEP) extrapolate();
     if (p.mode == MCKPP_MODE_INIT) l_initflag = 1;   // initialize_ocean.F90:59
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
   // Level k of this lane: relaxation / flux corrections / prescribed advection (rhsmod,
   // solvers.F90:176-335, salinity only).  Also leaves tinc_fcorr in xt and writes the
   // correction diagnostics when this may be the last pass.
-  auto ext_rhs = [&](int k, int j, int kmixe, double &rhsT, double &rhsS) {
+  auto ext_rhs = [&](int k, int j, int kmixe, double To_k, double So_k, double &rhsT, double &rhsS) {
     const double dto = p.dto;
     const double *xs = p.xs + (size_t)col * MCKPP_XS;
     const double *aRho = row(R_RHO), *aCp = row(R_CP);
@@ -406,8 +409,8 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
         const double relax_sst = xs[XS_RELAX_SST], SST0 = xs[XS_SST0];
         double fc = 0.0;
         if (relax_sst > 1.e-10) {
-          if (!p.L_RELAX_CALCONLY) rhsT = rhsT + dto * relax_sst * (SST0 - To[j]) * p.dm[kmixe] / c_hm[1];
-          fc = relax_sst * (SST0 - To[j]) * p.dm[kmixe] * rhok * cpk;
+          if (!p.L_RELAX_CALCONLY) rhsT = rhsT + dto * relax_sst * (SST0 - To_k) * p.dm[kmixe] / c_hm[1];
+          fc = relax_sst * (SST0 - To_k) * p.dm[kmixe] * rhok * cpk;
         }
         csrow()[CS_FCORR] = fc;
       }
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     }
     double tinc = 0.;                                           // :133-160
     if (p.L_FCORR_WITHZ && !p.L_FCORR) tinc = dto * p.fcorr_withz[oin] / (rhok * cpk);
-    if (p.L_RELAX_OCNT) tinc = tinc + dto * xs[XS_RELAX_OCNT] * (p.ocnT_clim[oin] - To[j]);
+    if (p.L_RELAX_OCNT) tinc = tinc + dto * xs[XS_RELAX_OCNT] * (p.ocnT_clim[oin] - To_k);
     rhsT = rhsT + tinc;
     xt[j] = tinc;
     const double ocnTcorr = tinc * rhok * cpk / dto;
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     }
     double sinc = 0.;                                           // :187-213
     if (p.L_SFCORR_WITHZ && !p.L_SFCORR) sinc = dto * p.sfcorr_withz[oin];
-    if (p.L_RELAX_SAL) sinc = sinc + dto * xs[XS_RELAX_SAL] * (p.sal_clim[oin] - So[j]);
+    if (p.L_RELAX_SAL) sinc = sinc + dto * xs[XS_RELAX_SAL] * (p.sal_clim[oin] - So_k);
     rhsS = rhsS + sinc;
     if (maybe_final()) {
       const size_t o = rowoff() + k;
@@ -621,8 +624,9 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     }
     if (!do_ocnint) return;
     WAVE_LDS_SYNC();
-    const double Uo_np = first_lane(bcast_level(Uo, lane_np, j_np)), To_np = first_lane(bcast_level(To, lane_np, j_np)),
-                 So_np = first_lane(bcast_level(So, lane_np, j_np));
+    double Uo[LPL], Vo[LPL], To[LPL], So[LPL];
+    load_old(p.U, Uo); load_old(p.V, Vo); load_old(p.T, To); load_old(p.S, So);
+    const double Uo_np = old_bottom(p.U), To_np = old_bottom(p.T), So_np = old_bottom(p.S);
     const double dto = p.dto, tri1_nz = first_lane(c_t1[nz]), hm1 = first_lane(c_hm[1]);
     const double wU0_1 = first_lane(sc[C_WU01]), wX0_1 = first_lane(sc[C_WX01]), wX0_2 = first_lane(sc[C_WX02]),
                  wXNT0 = first_lane(sc[C_WXNT0]);
@@ -655,12 +659,12 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       else
         rhsS = So[j] + dto / hk * (wX0_2 * (difs[j] * ghat[j] - ds_m1 * gh_m1) + 0.0 - 0.0);
       if (k == nz && nz > 1) rhsS = rhsS + So_np * tri1_nz * difs[j];
-      if constexpr (EXT) ext_rhs(k, j, kbl, rhsT, rhsS);
+      if constexpr (EXT) ext_rhs(k, j, kbl, To[j], So[j], rhsT, rhsS);
       yU[k] = rhsU; yT[k] = rhsT; yS[k] = rhsS;
     }
     FORJ if (kk[j] == nzp1) { yU[nzp1] = Uo[j]; yT[nzp1] = To[j]; yS[nzp1] = So[j]; }   // solvers.F90:159
     if constexpr (EXT) {   // tinc_fcorr / ocnTcorr / sinc_fcorr / scorr of level nzp1 (ocnint_mod.F90:153-160, 207-213)
-      FORJ if (kk[j] == nzp1) { double t = 0.0, s2 = 0.0; ext_rhs(nzp1, j, kbl, t, s2); }
+      FORJ if (kk[j] == nzp1) { double t = 0.0, s2 = 0.0; ext_rhs(nzp1, j, kbl, To[j], So[j], t, s2); }
     }
   };
 
@@ -668,7 +672,9 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
   auto phaseE = [&]() {
     const double *yU = row(R_YU);
     double *yV = row(R_YV);
-    const double Vo_np = first_lane(bcast_level(Vo, lane_np, j_np));
+    double Uo[LPL], Vo[LPL];
+    load_old(p.U, Uo); load_old(p.V, Vo);
+    const double Vo_np = old_bottom(p.V);
     const double dto = p.dto, tri1_nz = first_lane(c_t1[nz]), hm1 = first_lane(c_hm[1]), f = first_lane(sc[C_F]),
                  wU0_2 = first_lane(sc[C_WU02]);
     FORJ {
@@ -922,6 +928,8 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     }
     if (!comp_flag) {
       double *t0 = row(R_YU), *t1 = row(R_YT), *t2 = row(R_YS), *t3 = row(R_GM);
+      double Uo[LPL], Vo[LPL], To[LPL], So[LPL];
+      load_old(p.U, Uo); load_old(p.V, Vo); load_old(p.T, To); load_old(p.S, So);
       WAVE_LDS_SYNC();
       FORJ if (act[j]) {
         int k = kk[j];
