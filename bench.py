@@ -78,7 +78,7 @@ def cpu_baseline(ncol_total, nz, warmup, nsteps, stride):
     dt = time.perf_counter() - t0
     return {
         "value": n * nsteps / dt, "unit": "column-steps/s", "cores": cores, "kind": "port",
-        "sample": f"every {stride}th column of the {ncol_total}-column workload ({n} columns), "
+        "sample": f"every {stride}th column ({n} of {ncol_total}) of the workload, "
                   f"model steps {warmup + 1}-{warmup + nsteps} (the steps the GPU leg times), {dt:.1f} s, "
                   f"{cores} OpenMP threads, dynamic schedule",
         "mean_passes_per_column_step_last_step": float(ob["npasses"].mean()),
@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--nz", type=int, default=60)
     ap.add_argument("--diag", type=int, default=1, help="write the per-step diagnostic fields (reference behaviour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-stride", type=int, default=7)
+    ap.add_argument("--cpu-stride", type=int, default=1)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -384,3 +384,81 @@ def test_output_window_reductions_n4(mk):
     ctx.window_reset()
     with pytest.raises(mk.MckppHipError, match="empty window"):
         ctx.window_fetch(2, 0, np.zeros((ncol, nz + 1), order="F"))
+
+
+def test_config5_terramaris_shape_land_masked(mk):
+    """BASELINE configs[4] shape: the shipped namelist's grid (run/3D_ocn.nml:2-4,23: 453 x 319 points,
+    nz=69, nztmax=83, dto=1200 s) with a synthetic ~35 % land mask (lsm.nc / kpp_vgrid.nc are not in
+    the container: stretched grid and closed-form profiles instead).  Ocean columns are compacted on
+    upload; a strided sample of them is checked bit for bit against the oracle."""
+    from oracle import orc
+
+    nx, ny, nz = 453, 319, 69
+    npts = nx * ny
+    import mckpp_f90_amd as m
+
+    zm, hm, dm = cm.grid_for(nz, "stretched")
+    kc = m.KppConstFields(nz, nztmax=83, dto=1200.0, zm=zm[1:nz + 2], hm=hm[1:nz + 2], dm=dm)
+    m.mckpp_physics_lookup(kc)
+    col = cm.synth.columns(npts, nz, zm=zm)
+    k3 = m.Kpp3dFields(npts, kc)
+    k3.U[:, :, 0] = col["U"]; k3.U[:, :, 1] = col["V"]; k3.X[:, :, 0] = col["T"]; k3.X[:, :, 1] = col["S"]
+    k3.U_init[...] = k3.U
+    for k in ("f", "Sref", "SSref", "Ssurf", "ocdepth"):
+        getattr(k3, k)[:] = col[k]
+    k3.sflux[:, :, 4, 0] = 1e-20
+    ij = np.arange(npts)
+    land = ((ij * 2654435761) % 100) < 35                     # ~35 % land, scattered
+    k3.run_physics[land] = 0
+    k3.l_ocean[land] = 0
+    ctx = m.mckpp_initialize_ocean_model(k3, kc)
+    assert ctx.ncolumns == int((~land).sum())
+    sf = cm.synth.forcing(npts, "bench")
+    cm.set_forcing_3d(k3, sf)
+    for nt in (1, 2):
+        m.mckpp_physics_driver(k3, kc, nt)
+    assert np.all(k3.hmix[land] == 0) and np.all(k3.hmix[~land] > 0) and np.all(np.isfinite(k3.X))
+    ocean = np.nonzero(~land)[0][::211]
+    oc, ob = cm.make_oracle(len(ocean), nz, exp_mode=1, grid="stretched", dto=1200.0, index=ocean, ntotal=npts)
+    for nt in (1, 2):
+        orc.physics_driver(oc, ob, nt)
+
+    class _Sub:
+        pass
+
+    sub = _Sub()
+    for n in ("U", "X", "Us", "Xs", "hmixd", "hmix", "kmix", "Tref", "uref", "vref", "Ssurf", "reset_flag"):
+        setattr(sub, n, getattr(k3, n)[ocean])
+    _assert_bitexact(cm.compare(sub, ob, nz, cm.PROFILE_FIELDS + cm.SCALAR_FIELDS + ["hmixd0", "hmixd1"]), "config5 sample")
+
+
+def test_config4_100_levels_slice(mk):
+    """BASELINE configs[3] per-GPU slice (1e5 x 100 over 8 GPUs = 12,500 columns x 100 levels per
+    GPU), several steps: two levels per lane (LPL=2) path, sample checked against the oracle."""
+    from oracle import orc
+
+    ncol, nz, nsteps = 12500, 100, 3
+    kc, k3 = cm.make_hip_case(ncol, nz)
+    ctx = mk.MckppHip(kc)
+    ctx.upload(k3)
+    ctx.init_ocean(0)
+    cm.set_forcing_3d(k3, cm.synth.forcing(ncol, "bench"))
+    ctx.set_forcing(k3.sflux)
+    ctx.step(1, nsteps)
+    ctx.download(k3)
+    st, nf, npass = ctx.status()
+    assert np.all(np.isfinite(k3.X)) and npass.min() >= 6
+    idx = np.arange(0, ncol, 125)
+    oc, ob = cm.make_oracle(len(idx), nz, exp_mode=1, index=idx, ntotal=ncol)
+    for nt in range(1, nsteps + 1):
+        orc.physics_driver(oc, ob, nt)
+
+    class _Sub:
+        pass
+
+    sub = _Sub()
+    for n in ("U", "X", "Us", "Xs", "hmixd", "hmix", "kmix", "Tref", "uref", "vref", "Ssurf", "reset_flag"):
+        setattr(sub, n, getattr(k3, n)[idx])
+    _assert_bitexact(cm.compare(sub, ob, nz, cm.PROFILE_FIELDS + cm.SCALAR_FIELDS + ["hmixd0", "hmixd1"]), "config4 sample")
+    assert np.array_equal(st[idx], ob["status"]) and np.array_equal(npass[idx], ob["npasses"])
+    ctx.close()
