@@ -1167,10 +1167,11 @@ hipError_t mckpp_launch_column_kernel_wg(const mckpp_kparams &p, const mckpp_kpa
   int W, per_cu;
   switch (lpl) {
     case 1: W = 4; per_cu = 5; break;   // 30.6 KB LDS and <=96 VGPRs per wave: 20 waves per CU
-    case 2: W = 4; per_cu = 2; break;
+    case 2: W = 2; per_cu = 5; break;   // 27 KB LDS per workgroup, <=168 VGPRs
     default: W = 4; per_cu = 1; break;
   }
   if (lpl == 1 && (envW == 4 || envW == 8)) { W = envW; per_cu = (W == 8) ? 2 : 5; }
+  if (lpl == 2 && (envW == 2 || envW == 4)) { W = envW; per_cu = (W == 2) ? 5 : 2; }
   if (envB > 0) per_cu = envB;
   int nblocks = num_cu * per_cu;
   const int groups = (p.ncol + W - 1) / W;
@@ -1195,7 +1196,9 @@ hipError_t mckpp_launch_column_kernel_wg(const mckpp_kparams &p, const mckpp_kpa
       if (per_cu >= 4) return launch_wg<1, 4, 4>(p, dp, nblocks, stream);   // 128-VGPR build
       if (per_cu == 3) return launch_wg<1, 4, 3>(p, dp, nblocks, stream);   // 168-VGPR build
       return launch_wg<1, 4, 2>(p, dp, nblocks, stream);
-    case 2: return launch_wg<2, 4, 2>(p, dp, nblocks, stream);
+    case 2:
+      if (W == 2) return (per_cu >= 6) ? launch_wg<2, 2, 4>(p, dp, nblocks, stream) : launch_wg<2, 2, 3>(p, dp, nblocks, stream);
+      return launch_wg<2, 4, 2>(p, dp, nblocks, stream);
     case 3: return launch_wg<3, 4, 1>(p, dp, nblocks, stream);
     default: return hipErrorInvalidValue;
   }
