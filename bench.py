@@ -203,7 +203,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "k_column_wg<LPL=%d> (cooperative, persistent)" % ((nz + 3 + 63) // 64),
+                "kernel": ctx.kernel_name + " (cooperative, persistent)",
                 "kernel_avg_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": balg * ncol,
             },
         }

@@ -210,6 +210,10 @@ int mckpp_hip_status(mckpp_hip_handle h, int32_t *per_col, int64_t *n_flagged,
  * stream, from HIP events recorded around the kernel: total ms and launches. */
 int mckpp_hip_last_kernel_ms(mckpp_hip_handle h, double *ms, int32_t *nlaunch);
 
+/* Name of the column kernel this context launches for its grid and switches
+ * ("k_column_wg<1>", "k_column_mw<2>", ...); static storage, never NULL. */
+const char *mckpp_hip_kernel_name(mckpp_hip_handle h);
+
 /* Number of device-resident (run_physics) columns. */
 int64_t mckpp_hip_ncolumns(mckpp_hip_handle h);
 

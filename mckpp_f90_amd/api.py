@@ -104,6 +104,8 @@ def _bind(lib):
     lib.mckpp_hip_download.argtypes = [C.c_void_p, C.POINTER(_StateC), C.c_uint32]
     lib.mckpp_hip_status.argtypes = [C.c_void_p, _ip, C.POINTER(C.c_int64), _ip]
     lib.mckpp_hip_last_kernel_ms.argtypes = [C.c_void_p, _dp, _ip]
+    lib.mckpp_hip_kernel_name.argtypes = [C.c_void_p]
+    lib.mckpp_hip_kernel_name.restype = C.c_char_p
     lib.mckpp_hip_ncolumns.argtypes = [C.c_void_p]
     lib.mckpp_hip_ncolumns.restype = C.c_int64
     lib.mckpp_hip_eos_batch.argtypes = [C.c_void_p, C.c_int64] + [_dp] * 7
@@ -328,6 +330,10 @@ class MckppHip:
         nl = C.c_int32(0)
         _chk(_lib().mckpp_hip_last_kernel_ms(self._h, C.byref(ms), C.byref(nl)))
         return ms.value, nl.value
+
+    @property
+    def kernel_name(self):
+        return _lib().mckpp_hip_kernel_name(self._h).decode()
 
     @property
     def ncolumns(self):

@@ -73,6 +73,9 @@ size_t mckpp_column_kernel_lds_bytes(int nzp1);
 // `dp` is a device copy of `p` (every field but ntime is read from it; ntime is passed by value)
 hipError_t mckpp_launch_column_kernel_wg(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu,
                                          hipStream_t stream);
+// deep-column kernel (mckpp_kernels_mw.hip): WPS waves per column, one level per lane
+hipError_t mckpp_launch_column_kernel_mw(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu,
+                                         hipStream_t stream);
 hipError_t mckpp_launch_eos_batch(int64_t n, const double *s, const double *t, const double *p,
                                   double *alpha, double *beta, double *sig0, double *cp,
                                   hipStream_t stream);

@@ -183,10 +183,17 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   h->ld = 64 * lpl;
   h->ldc = 64 * lpl + 8;
   h->num_cu = prop.multiProcessorCount;
-  if (const char *kv = getenv("MCKPP_KERNEL")) h->kernel_variant = (strcmp(kv, "v1") == 0) ? 1 : 2;
   h->ext = c->LDD || c->L_RELAX_SST || c->L_FCORR || c->L_FCORR_WITHZ || c->L_SFCORR || c->L_SFCORR_WITHZ ||
            c->L_RELAX_SAL || c->L_RELAX_OCNT || c->L_NO_FREEZE || c->L_NO_ISOTHERM || c->L_DAMP_CURR ||
            c->clim_present || c->L_ADVECT;
+  // deep columns (more than 62 levels) with the default physics run one level per lane over
+  // several waves (mckpp_kernels_mw.hip); MCKPP_KERNEL=v1|wg|mw overrides (experiments, tests)
+  if (lpl > 1 && !h->ext) h->kernel_variant = 3;
+  if (const char *kv = getenv("MCKPP_KERNEL")) {
+    if (strcmp(kv, "v1") == 0) h->kernel_variant = 1;
+    else if (strcmp(kv, "wg") == 0) h->kernel_variant = 2;
+    else if (strcmp(kv, "mw") == 0 && !h->ext) h->kernel_variant = 3;
+  }
   if (h->ext && h->kernel_variant == 1) {
     delete h;
     return fail("mckpp_hip_init: MCKPP_KERNEL=v1 carries the default physics only");
@@ -567,7 +574,8 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode)
       HIPCHK(mckpp_launch_column_kernel(p, h->stream));
     } else {
       HIPCHK(hipMemsetAsync(h->d_qhead, 0, sizeof(int), h->stream));
-      HIPCHK(mckpp_launch_column_kernel_wg(p, h->d_params, h->num_cu, h->stream));
+      if (h->kernel_variant == 3) HIPCHK(mckpp_launch_column_kernel_mw(p, h->d_params, h->num_cu, h->stream));
+      else HIPCHK(mckpp_launch_column_kernel_wg(p, h->d_params, h->num_cu, h->stream));
     }
   }
   HIPCHK(hipEventRecord(h->ev1, h->stream));
@@ -601,6 +609,17 @@ int mckpp_hip_synchronize(mckpp_hip_handle h)
     }
   }
   return 0;
+}
+
+const char *mckpp_hip_kernel_name(mckpp_hip_handle h)
+{
+  if (!h) return "none";
+  static const char *names[4][3] = {{"", "", ""},
+                                    {"k_column<1>", "k_column<2>", "k_column<3>"},
+                                    {"k_column_wg<1>", "k_column_wg<2>", "k_column_wg<3>"},
+                                    {"k_column_mw<1>", "k_column_mw<2>", "k_column_mw<3>"}};
+  if (h->ext && h->kernel_variant == 2) return h->lpl == 1 ? "k_column_wg<1,EXT>" : h->lpl == 2 ? "k_column_wg<2,EXT>" : "k_column_wg<3,EXT>";
+  return names[h->kernel_variant][h->lpl - 1];
 }
 
 int mckpp_hip_last_kernel_ms(mckpp_hip_handle h, double *ms, int32_t *nlaunch)

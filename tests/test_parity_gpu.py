@@ -462,3 +462,110 @@ def test_config4_100_levels_slice(mk):
     _assert_bitexact(cm.compare(sub, ob, nz, cm.PROFILE_FIELDS + cm.SCALAR_FIELDS + ["hmixd0", "hmixd1"]), "config4 sample")
     assert np.array_equal(st[idx], ob["status"]) and np.array_equal(npass[idx], ob["npasses"])
     ctx.close()
+
+
+# ---- kernel variants -------------------------------------------------------------------------
+# The library holds three implementations of the same column step: k_column (one wave per
+# column), k_column_wg (cooperative, several levels per lane for deep columns) and k_column_mw
+# (cooperative, one level per lane over several waves).  MCKPP_KERNEL selects one at init; every
+# variant must reproduce the oracle's bits on every shape it accepts.
+
+@pytest.fixture
+def kernel_env(monkeypatch):
+    def set_variant(v):
+        if v is None:
+            monkeypatch.delenv("MCKPP_KERNEL", raising=False)
+        else:
+            monkeypatch.setenv("MCKPP_KERNEL", v)
+    return set_variant
+
+
+def test_default_kernel_selection(mk, kernel_env):
+    kernel_env(None)
+    for nz, want in [(40, "k_column_wg<1>"), (61, "k_column_wg<1>"), (62, "k_column_mw<2>"), (69, "k_column_mw<2>"),
+                     (125, "k_column_mw<2>"), (126, "k_column_mw<3>"), (150, "k_column_mw<3>")]:
+        kc = mk.KppConstFields(nz)
+        mk.mckpp_physics_lookup(kc)
+        ctx = mk.MckppHip(kc)
+        assert ctx.kernel_name == want, (nz, ctx.kernel_name)
+        ctx.close()
+    kc = mk.KppConstFields(69)
+    kc.LDD = True
+    mk.mckpp_physics_lookup(kc)
+    ctx = mk.MckppHip(kc)
+    assert ctx.kernel_name == "k_column_wg<2,EXT>"     # optional physics stays on the cooperative kernel
+    ctx.close()
+
+
+@pytest.mark.parametrize("variant", ["v1", "wg", "mw"])
+@pytest.mark.parametrize("nz,ncol,nsteps,grid", [(40, 70, 2, "uniform"), (61, 67, 2, "uniform"), (62, 67, 2, "uniform"),
+                                                 (69, 131, 2, "stretched"), (125, 35, 2, "uniform"),
+                                                 (126, 35, 2, "uniform"), (150, 41, 2, "uniform")])
+def test_every_kernel_variant_bitexact(mk, kernel_env, variant, nz, ncol, nsteps, grid):
+    """Same inputs through each implementation; 61/62 and 125/126 levels straddle the points where a
+    column stops fitting one (two) wave(s) with its two virtual equation-of-state slots."""
+    kernel_env(variant)
+    out, k3, ob, kc, oc = _run_both(mk, ncol, nz, nsteps, grid=grid, land_every=5, jerlov_mix=True)
+    want = {"v1": "k_column<", "wg": "k_column_wg<", "mw": "k_column_mw<"}[variant]
+    assert kc._hip_ctx.kernel_name.startswith(want), kc._hip_ctx.kernel_name
+    for tag, res in out:
+        _assert_bitexact(res, f"{variant} nz={nz} {tag}")
+
+
+@pytest.mark.parametrize("variant,nz", [("mw", 40), ("mw", 69), ("mw", 150), ("wg", 69)])
+def test_instability_trap_every_variant(mk, kernel_env, variant, nz):
+    """The retry round of the deep-column kernel (cross-wave violation counts and rmsd sums)."""
+    from oracle import orc
+
+    kernel_env(variant)
+    ncol = 45
+    oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1)
+    kc, k3 = cm.make_hip_case(ncol, nz)
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    orc.init_ocean(oc, ob, 0)
+    bad = np.arange(0, ncol, 4)
+    deep = np.arange(2, ncol, 8)          # violation only below level 64: seen by the second wave alone
+    k3.U[bad, 0:4, 0] = 50.0
+    ob["U"][bad, 1:5] = 50.0
+    if nz > 66:
+        k3.U[deep, 65:67, 0] = -40.0
+        ob["U"][deep, 66:68] = -40.0
+    ctx.upload(k3)
+    sf = cm.synth.forcing(ncol, "bench")
+    ob["sflux"] = sf
+    cm.set_forcing_3d(k3, sf)
+    flagged = set()
+    for nt in (1, 2):
+        mk.mckpp_physics_driver(k3, kc, nt)
+        orc.physics_driver(oc, ob, nt)
+        st, nf, npass = ctx.status()
+        assert np.array_equal(st, ob["status"]) and np.array_equal(npass, ob["npasses"])
+        _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS), f"trap {variant} nz={nz} step {nt}")
+        flagged |= set(np.nonzero(st & 4)[0].tolist())
+    assert set(bad.tolist()) <= flagged
+    if nz > 66:
+        assert set(deep.tolist()) <= flagged
+
+
+def test_config2_pass_every_variant(mk, kernel_env):
+    """configs[1]-style single vmix+ocnint pass on the deep-column kernel."""
+    from oracle import orc
+
+    fields = ["U", "V", "T", "S", "hmix", "kmix", "uref", "vref", "rho", "cp", "buoy", "difm", "difs", "dift",
+              "ghat", "Rig", "dbloc", "Shsq", "wXNT1"]
+    for variant, nz in [("mw", 60), ("mw", 100), ("mw", 150)]:
+        kernel_env(variant)
+        ncol = 300
+        oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1)
+        kc, k3 = cm.make_hip_case(ncol, nz)
+        sf = cm.synth.forcing(ncol, "bench")
+        ob["sflux"] = sf
+        cm.set_forcing_3d(k3, sf)
+        ctx = mk.MckppHip(kc)
+        assert ctx.kernel_name.startswith("k_column_mw<")
+        ctx.upload(k3)
+        ctx.vmix_pass(1)
+        ctx.download(k3)
+        orc.vmix_batch(oc, ob, 1)
+        _assert_bitexact(cm.compare(k3, ob, nz, fields), f"pass {variant} nz={nz}")
+        ctx.close()
