@@ -160,6 +160,18 @@ int mckpp_hip_fluxes(mckpp_hip_handle h, int ntime, const double *taux, const do
                      const double *swf, const double *lwf, const double *lhf, const double *shf,
                      const double *rain, const double *snow, int l_rest, double flsn, double el);
 
+/* mckpp_physics_overrides_bottomtemp (src/mckpp_physics_overrides.F90:12-24),
+ * which mckpp_physics_driver calls after the column loop when
+ * kpp_const_fields%L_VARY_BOTTOM_TEMP (src/mckpp_physics_driver_mod.F90:67-71):
+ *   tinc_fcorr(ipt,NZP1) = bottom_temp(ipt) - X(ipt,NZP1,1)
+ *   ocnTcorr(ipt,NZP1)   = tinc_fcorr(ipt,NZP1)*rho(ipt,NZP1)*cp(ipt,NZP1)/dto
+ *   X(ipt,NZP1,1)        = bottom_temp(ipt)
+ * on every device-resident column.  `bottom_temp` is kpp_3d_fields%bottom_temp
+ * (npts, 3D ordering).  Needs the diagnostics on (rho, cp of the last vmix).
+ * Land points are not resident and stay untouched (the reference also rewrites
+ * their X(:,NZP1,1), which nothing reads). */
+int mckpp_hip_bottomtemp(mckpp_hip_handle h, const double *bottom_temp);
+
 /* Enable/disable writing of the MCKPP_F_DIAG fields by step/init (default on). */
 int mckpp_hip_set_diagnostics(mckpp_hip_handle h, int on);
 

@@ -97,6 +97,7 @@ def _bind(lib):
     lib.mckpp_hip_save_restart.argtypes = [C.c_void_p, C.c_char_p]
     lib.mckpp_hip_load_restart.argtypes = [C.c_void_p, C.c_char_p]
     lib.mckpp_hip_fluxes.argtypes = [C.c_void_p, C.c_int] + [_dp] * 8 + [C.c_int, C.c_double, C.c_double]
+    lib.mckpp_hip_bottomtemp.argtypes = [C.c_void_p, _dp]
     lib.mckpp_hip_init_ocean.argtypes = [C.c_void_p, C.c_int]
     lib.mckpp_hip_step.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.mckpp_hip_vmix_pass.argtypes = [C.c_void_p, C.c_int]
@@ -147,6 +148,7 @@ class KppConstFields:
         self.iso_bot, self.iso_thresh, self.dt_uvdamp = 2, 0.002, 360
         self.maxmodeadv = 6
         self.L_ADVECT = 0
+        self.L_VARY_BOTTOM_TEMP = 0
         for s in _SWITCHES:
             setattr(self, s, 0)
         self.LKPP = self.LRI = self.L_SSref = 1
@@ -221,6 +223,7 @@ class Kpp3dFields:
         self.dbloc = _f((npts, nz))
         self.swfrac = _f((npts, nzp1))
         self.swdk_opt = _f((npts, nz + 1))
+        self.bottom_temp = _f((npts,))
         for n in ("relax_sst", "SST0", "fcorr_twod", "relax_sal", "relax_ocnT", "fcorr"):
             setattr(self, n, _f((npts,)))
         for n in ("fcorr_withz", "sfcorr_withz", "ocnT_clim", "sal_clim", "tinc_fcorr", "sinc_fcorr", "ocnTcorr", "scorr"):
@@ -276,6 +279,11 @@ class MckppHip:
         arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (taux, tauy, swf, lwf, lhf, shf, rain, snow)]
         _chk(_lib().mckpp_hip_fluxes(self._h, int(ntime), *[a.ctypes.data_as(_dp) for a in arrs], int(l_rest),
                                      float(flsn), float(el)))
+
+    def bottomtemp(self, bottom_temp):
+        bt = np.ascontiguousarray(bottom_temp, dtype=np.float64)
+        assert bt.shape == (self._npts_cache,)
+        _chk(_lib().mckpp_hip_bottomtemp(self._h, bt.ctypes.data_as(_dp)))
 
     def save_restart(self, path):
         _chk(_lib().mckpp_hip_save_restart(self._h, str(path).encode()))
@@ -385,6 +393,8 @@ def mckpp_physics_driver(kpp_3d_fields, kpp_const_fields, ntime, device=0, downl
     if new_forcing:
         ctx.set_forcing(kpp_3d_fields.sflux)
     ctx.step(ntime, 1)
+    if kpp_const_fields.L_VARY_BOTTOM_TEMP:     # src/mckpp_physics_driver_mod.F90:67-71
+        ctx.bottomtemp(kpp_3d_fields.bottom_temp)
     if download:
         ctx.download(kpp_3d_fields, F_ALL)
     return ctx

@@ -80,6 +80,7 @@ hipError_t mckpp_launch_eos_batch(int64_t n, const double *s, const double *t, c
                                   double *alpha, double *beta, double *sig0, double *cp,
                                   hipStream_t stream);
 hipError_t mckpp_launch_exp_batch(int64_t n, const double *x, double *y, hipStream_t stream);
+hipError_t mckpp_launch_bottomtemp(const mckpp_kparams &p, const double *bt, hipStream_t stream);
 hipError_t mckpp_launch_fluxes(const mckpp_kparams &p, int ntime, const double *f8, int l_rest, double flsn,
                                double el, hipStream_t stream);
 hipError_t mckpp_launch_window_accumulate(const double *u, const double *v, const double *t, const double *s,

@@ -893,6 +893,22 @@ __global__ void k_fluxes(mckpp_kparams p, int ntime, const double *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------
+// mckpp_physics_overrides_bottomtemp, src/mckpp_physics_overrides.F90:12-24:
+// prescribed temperature of the bottom grid point; one thread per column.
+// ---------------------------------------------------------------------------
+__global__ void k_bottomtemp(mckpp_kparams p, const double *__restrict__ bt)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= p.ncol) return;
+  const size_t ro = (size_t)c * p.ld;
+  const double b = bt[c];
+  const double tinc = b - p.T[ro + p.nzp1 - 1];                                   // :16
+  p.tinc_fcorr[ro + p.nzp1] = tinc;
+  p.ocnTcorr[ro + p.nzp1] = tinc * p.rho[ro + p.nzp1] * p.cp[ro + p.nzp1] / p.dto;   // :17-19
+  p.T[ro + p.nzp1 - 1] = b;                                                       // :20
+}
+
+// ---------------------------------------------------------------------------
 // Output-window reductions: running sum / min / max of the
 // profile rows and of hmix, replacing XIOS's temporal operations
 // (run/iodef.xml:91-116) so only reduced fields leave the device.  Pure
@@ -1003,6 +1019,13 @@ hipError_t mckpp_launch_fluxes(const mckpp_kparams &p, int ntime, const double *
   if (p.ncol <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_fluxes, dim3((unsigned)((p.ncol + 255) / 256)), dim3(256), 0, stream, p, ntime, f8, l_rest,
                      flsn, el);
+  return hipGetLastError();
+}
+
+hipError_t mckpp_launch_bottomtemp(const mckpp_kparams &p, const double *bt, hipStream_t stream)
+{
+  if (p.ncol <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_bottomtemp, dim3((unsigned)((p.ncol + 255) / 256)), dim3(256), 0, stream, p, bt);
   return hipGetLastError();
 }
 

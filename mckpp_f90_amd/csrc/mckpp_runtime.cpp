@@ -514,6 +514,27 @@ int mckpp_hip_fluxes(mckpp_hip_handle h, int ntime, const double *taux, const do
   return 0;
 }
 
+int mckpp_hip_bottomtemp(mckpp_hip_handle h, const double *bottom_temp)
+{
+  if (!h || !bottom_temp) return fail("mckpp_hip_bottomtemp: null argument");
+  if (h->ncol == 0) return 0;
+  if (!h->diag) return fail("mckpp_hip_bottomtemp: needs the diagnostics on (rho, cp of the last vmix)");
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->d_ext_out[O_TINC]) {   // default-physics contexts carry no correction rows until someone needs them
+    const size_t rowbytes = (size_t)h->ncol * h->ld * sizeof(double);
+    for (auto &p : h->d_ext_out) { HIPCHK(hipMalloc(&p, rowbytes)); HIPCHK(hipMemsetAsync(p, 0, rowbytes, h->stream)); }
+  }
+  std::vector<double> bt((size_t)h->ncol);
+  for (int64_t c = 0; c < h->ncol; ++c) bt[(size_t)c] = bottom_temp[h->ipt[c]];
+  if (ensure_stage(h, bt.size())) return -1;
+  HIPCHK(hipMemcpyAsync(h->d_stage, bt.data(), bt.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  mckpp_kparams p;
+  fill_params(h, p, 0, MCKPP_MODE_STEP);
+  HIPCHK(mckpp_launch_bottomtemp(p, h->d_stage, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 int mckpp_hip_set_diagnostics(mckpp_hip_handle h, int on)
 {
   if (!h) return fail("null handle");
@@ -726,7 +747,7 @@ int mckpp_hip_download(mckpp_hip_handle h, mckpp_state_ptrs_c *s, uint32_t mask)
     if (s->Rig && down_rows(h, h->d_diag[D_RIG], 1, nz, s->Rig)) return -1;
     if (s->Shsq && down_rows(h, h->d_diag[D_SHSQ], 1, nz, s->Shsq)) return -1;
     if (s->dbloc && down_rows(h, h->d_diag[D_DBLOC], 1, nz, s->dbloc)) return -1;
-    if (h->ext) {
+    if (h->d_ext_out[O_TINC]) {
       if (s->tinc_fcorr && down_rows(h, h->d_ext_out[O_TINC], 1, nzp1, s->tinc_fcorr)) return -1;
       if (s->sinc_fcorr && down_rows(h, h->d_ext_out[O_SINC], 1, nzp1, s->sinc_fcorr)) return -1;
       if (s->ocnTcorr && down_rows(h, h->d_ext_out[O_OCNTCORR], 1, nzp1, s->ocnTcorr)) return -1;

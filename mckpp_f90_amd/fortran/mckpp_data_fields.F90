@@ -27,6 +27,7 @@ module mckpp_data_fields
     ! optional relaxation / flux-correction inputs and outputs (allocate the ones a switch needs:
     ! mckpp_allocate_3d_optional); same names and shapes as the reference
     real(c_double), allocatable :: relax_sst(:), SST0(:), fcorr_twod(:), relax_sal(:), relax_ocnT(:), fcorr(:)
+    real(c_double), allocatable :: bottom_temp(:)   ! reference :68, read when L_VARY_BOTTOM_TEMP
     real(c_double), allocatable :: fcorr_withz(:,:), sfcorr_withz(:,:), ocnT_clim(:,:), sal_clim(:,:)
     real(c_double), allocatable :: tinc_fcorr(:,:), sinc_fcorr(:,:), ocnTcorr(:,:), scorr(:,:), advection(:,:,:)
     integer(c_int), allocatable :: nmodeadv(:,:), modeadv(:,:,:)
@@ -102,6 +103,8 @@ contains
   subroutine mckpp_allocate_3d_optional()
     associate (s => kpp_3d_fields)
       allocate (s%relax_sst(npts), s%SST0(npts), s%fcorr_twod(npts), s%relax_sal(npts), s%relax_ocnT(npts), s%fcorr(npts))
+      allocate (s%bottom_temp(npts))
+      s%bottom_temp = 0
       allocate (s%fcorr_withz(npts,nzp1), s%sfcorr_withz(npts,nzp1), s%ocnT_clim(npts,nzp1), s%sal_clim(npts,nzp1))
       allocate (s%tinc_fcorr(npts,nzp1), s%sinc_fcorr(npts,nzp1), s%ocnTcorr(npts,nzp1), s%scorr(npts,nzp1))
       allocate (s%nmodeadv(npts,2), s%modeadv(npts,maxmodeadv,2), s%advection(npts,maxmodeadv,2))

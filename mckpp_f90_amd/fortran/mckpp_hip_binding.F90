@@ -91,6 +91,12 @@ module mckpp_hip_binding
       real(c_double), value :: flsn, el
       integer(c_int) :: rc
     end function
+    function mckpp_hip_bottomtemp(handle, bottom_temp) bind(C, name="mckpp_hip_bottomtemp") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: handle
+      real(c_double), intent(in) :: bottom_temp(*)
+      integer(c_int) :: rc
+    end function
     function mckpp_hip_save_restart(handle, path) bind(C, name="mckpp_hip_save_restart") result(rc)
       import :: c_int, c_ptr, c_char
       type(c_ptr), value :: handle

@@ -17,11 +17,15 @@ contains
     ! forcing written by mckpp_fluxes into sflux(:,1:6,5,0) (src/mckpp_fluxes_mod.F90:62-69)
     call mckpp_hip_check(mckpp_hip_set_forcing(mckpp_hip_handle, kpp_3d_fields%sflux), 'mckpp_hip_set_forcing')
     call mckpp_hip_check(mckpp_hip_step(mckpp_hip_handle, int(ntime, c_int), 1_c_int), 'mckpp_hip_step')
-    call mckpp_hip_pull_state(mckpp_hip_output_mask)
+    ! mckpp_physics_overrides_bottomtemp after the column loop (src/mckpp_physics_driver_mod.F90:67-71)
     if (kpp_const_fields%L_VARY_BOTTOM_TEMP) then
-      write (0, '(a)') 'MCKPP-HIP ERROR: L_VARY_BOTTOM_TEMP is not supported by the device path'
-      error stop 1
+      if (.not. allocated(kpp_3d_fields%bottom_temp)) then
+        write (0, '(a)') 'MCKPP-HIP ERROR: L_VARY_BOTTOM_TEMP needs kpp_3d_fields%bottom_temp (mckpp_allocate_3d_optional)'
+        error stop 1
+      end if
+      call mckpp_hip_check(mckpp_hip_bottomtemp(mckpp_hip_handle, kpp_3d_fields%bottom_temp), 'mckpp_hip_bottomtemp')
     end if
+    call mckpp_hip_pull_state(mckpp_hip_output_mask)
   end subroutine mckpp_physics_driver
 
   subroutine mckpp_physics_finalize()

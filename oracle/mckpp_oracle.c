@@ -1496,6 +1496,20 @@ void orc_vmix_batch(const orc_const *c, orc_batch *b, int ntime, int nthreads)
 }
 
 /* mckpp_fluxes.  mckpp_fluxes_mod.F90:35-89 (forcing arrays given, l_fluxdata semantics left to the caller) */
+/* mckpp_physics_overrides_bottomtemp, overrides.F90:12-24 (called by the driver after the column
+ * loop when L_VARY_BOTTOM_TEMP, physics_driver_mod.F90:67-71) */
+void orc_bottomtemp(const orc_const *c, orc_batch *b, const double *bottom_temp)
+{
+  const int nzp1 = c->nz + 1;
+  for (long col = 0; col < b->ncol; col++) {
+    const long o = col * b->ld + nzp1;
+    const double tinc = bottom_temp[col] - b->T[o];                      /* :16 */
+    if (b->tinc_fcorr) b->tinc_fcorr[o] = tinc;
+    if (b->ocnTcorr) b->ocnTcorr[o] = tinc * b->rho[o] * b->cp[o] / c->dto;   /* :17-19 */
+    b->T[o] = bottom_temp[col];                                          /* :20 */
+  }
+}
+
 void orc_fluxes(const orc_const *c, orc_batch *b, int ntime, const double *taux_in, const double *tauy,
                 const double *swf, const double *lwf, const double *lhf, const double *shf, const double *rain,
                 const double *snow, int l_rest, double flsn, double el)

@@ -140,6 +140,8 @@ void orc_physics_driver(const orc_const *c, orc_batch *b, int ntime, int nthread
 void orc_fluxes(const orc_const *c, orc_batch *b, int ntime, const double *taux, const double *tauy,
                 const double *swf, const double *lwf, const double *lhf, const double *shf, const double *rain,
                 const double *snow, int l_rest, double flsn, double el);
+/* mckpp_physics_overrides_bottomtemp (overrides.F90:12-24) */
+void orc_bottomtemp(const orc_const *c, orc_batch *b, const double *bottom_temp);
 /* one vmix + ocnint pass on every column (config-2 style kernel-level check) */
 void orc_vmix_batch(const orc_const *c, orc_batch *b, int ntime, int nthreads);
 

@@ -88,6 +88,7 @@ def lib():
         L.orc_batch_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
         for fn in ("orc_init_ocean", "orc_physics_driver", "orc_vmix_batch"):
             getattr(L, fn).argtypes = [C.POINTER(OrcConst), C.c_void_p, C.c_int, C.c_int]
+        L.orc_bottomtemp.argtypes = [C.POINTER(OrcConst), C.c_void_p, C.POINTER(C.c_double)]
         L.orc_fluxes.argtypes = [C.POINTER(OrcConst), C.c_void_p, C.c_int] + [C.POINTER(C.c_double)] * 8 + [C.c_int, C.c_double, C.c_double]
         _lib = L
     return _lib
@@ -248,6 +249,16 @@ def physics_driver(const, batch, ntime, nthreads=0):
 
 def vmix_batch(const, batch, ntime, nthreads=0):
     _run("orc_vmix_batch", const, batch, ntime, nthreads)
+
+
+def bottomtemp(const, batch, bottom_temp):
+    L = lib()
+    h = batch.handle()
+    bt = np.ascontiguousarray(bottom_temp, dtype=np.float64)
+    try:
+        L.orc_bottomtemp(const.ptr, h, _dp(bt))
+    finally:
+        L.orc_batch_free(h)
 
 
 def fluxes(const, batch, ntime, taux, tauy, swf, lwf, lhf, shf, rain, snow, l_rest=0, flsn=334000.0, el=2.5e6):

@@ -147,3 +147,43 @@ def test_prescribed_advection_modes(mk, grid):
         ob["advection"][:, 1, :] = k3.advection[:, :, 1]
     nz = 60 if grid == "uniform" else 69
     _case(mk, 70, nz, dict(L_ADVECT=1), prep, grid=grid)
+
+
+@pytest.mark.parametrize("nz,switches", [(40, {}), (69, {}), (40, dict(L_FCORR_WITHZ=1))])
+def test_vary_bottom_temp(mk, nz, switches):
+    """L_VARY_BOTTOM_TEMP: mckpp_physics_overrides_bottomtemp after the column loop
+    (src/mckpp_physics_driver_mod.F90:67-71, src/mckpp_physics_overrides.F90:12-24), on the default
+    kernels (which carry no correction rows of their own) and next to an ocnint correction switch."""
+    from oracle import orc
+
+    ncol = 77
+    oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1, **switches)
+    kc, k3 = cm.make_hip_case(ncol, nz, land_every=6)
+    for k, v in switches.items():
+        setattr(kc, k, v)
+    kc.L_VARY_BOTTOM_TEMP = 1
+    if switches:
+        z = np.arange(nz + 1)[None, :]
+        _set2(k3, ob, "fcorr_withz", 5.0 * np.exp(-z / 10.0) * np.linspace(-1, 1, ncol)[:, None])
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    orc.init_ocean(oc, ob, 0)
+    active = np.nonzero(k3.run_physics)[0]
+    sf = cm.synth.forcing(ncol, "bench")
+    ob["sflux"] = sf
+    cm.set_forcing_3d(k3, sf)
+    for nt in (1, 2, 3):
+        bt = np.asarray(k3.X[:, nz, 0]) + 0.25 * np.sin(np.arange(ncol) + nt)
+        k3.bottom_temp[:] = bt
+        ctx = mk.mckpp_physics_driver(k3, kc, nt)
+        orc.physics_driver(oc, ob, nt)
+        orc.bottomtemp(oc, ob, bt)
+        res = cm.compare(k3, ob, nz, FIELDS, active)
+        bad = {k: v for k, v in res.items() if v[2] != 0}
+        assert not bad, f"bottomtemp {switches} step {nt}: {bad}"
+        assert np.array_equal(k3.X[active, nz, 0], bt[active])
+        assert np.any(k3.ocnTcorr[active, nz] != 0)
+    land = np.nonzero(k3.run_physics == 0)[0]
+    assert np.all(k3.tinc_fcorr[land] == 0)
+    ctx.set_diagnostics(0)
+    with pytest.raises(mk.MckppHipError):
+        ctx.bottomtemp(k3.bottom_temp)

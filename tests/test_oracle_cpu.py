@@ -208,3 +208,21 @@ def test_fluxes_assembly():
     assert np.allclose(w[:, 0], -200.0 / (ob["rho"][:, 0] * ob["cp"][:, 0]), rtol=1e-15)
     orc.fluxes(oc, ob, 2, 0 * one, 0 * one, 200 * one, 0 * one, -150 * one, 0 * one, 6e-5 * one, 0 * one)
     assert np.all(ob["sflux"][:, 0] == 1e-10)
+
+
+def test_bottomtemp_override():
+    """overrides.F90:12-24: the increment, its heat-flux equivalent and the overwritten bottom point."""
+    from oracle import orc
+
+    ncol, nz = 9, 40
+    oc, ob = cm.make_oracle(ncol, nz, exp_mode=0)
+    ob["sflux"] = cm.synth.forcing(ncol, "bench")
+    orc.physics_driver(oc, ob, 1)
+    t_old = ob["T"][:, nz + 1].copy()
+    rho, cp = ob["rho"][:, nz + 1].copy(), ob["cp"][:, nz + 1].copy()
+    bt = t_old + np.linspace(-0.5, 0.5, ncol)
+    orc.bottomtemp(oc, ob, bt)
+    assert np.array_equal(ob["T"][:, nz + 1], bt)
+    assert np.array_equal(ob["tinc_fcorr"][:, nz + 1], bt - t_old)
+    assert np.array_equal(ob["ocnTcorr"][:, nz + 1], (bt - t_old) * rho * cp / 3600.0)
+    assert np.all(ob["tinc_fcorr"][:, 1:nz + 1] == 0)
