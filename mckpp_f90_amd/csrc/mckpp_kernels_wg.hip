@@ -42,8 +42,9 @@ enum { S_EMPTY = 0, S_ACTIVE = 1, S_DONE = 2 };
 
 // per-slot scalar record in LDS (wave-uniform values that cross phases)
 enum { C_B0 = 0, C_B0SOL, C_USTAR, C_WU01, C_WU02, C_WX01, C_WX02, C_WXNT0, C_UREFNZ, C_VREFNZ,
-       C_HBL, C_F, C_HMIXE, C_HMIXN, C_RHO0CP0, C_COUNT = 16 };
+       C_HBL, C_F, C_HMIXE, C_HMIXN, C_RHO0CP0, C_RRC /* refined 1/(rho0 cp0) */, C_COUNT = 16 };
 
+#define WG_CONST_DOUBLES(NA_) (6 * (NA_))   // zm, hm, tri0, tri1, rdz (+misc), dtohk rows
 template <int LPL>
 __host__ __device__ constexpr int wg_na() { return 64 * LPL + 3; }   // == 3 (mod 32): bank-spread rows
 template <int LPL, bool EXT = false>
@@ -73,7 +74,12 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: LDS row bases stay scalar
   const int nz = p.nz, nzp1 = p.nzp1;
   double *c_zm = lds, *c_hm = lds + NA, *c_t0 = lds + 2 * NA, *c_t1 = lds + 3 * NA;
-  double *slots = lds + 4 * NA;
+  // grid-constant quotients and refined reciprocals (div_fast, mckpp_colmath.h), built once per workgroup:
+  //   c_rdz[k] ~ 1/(zm(k)-zm(k+1)),  c_dtohk[k] = dto/hm(k),  c_misc = {~1/hm(1), ~1/vonk} in the two unused
+  //   tail entries of c_rdz.  (LDS is what limits residency: 5 workgroups of 31.9 KB per CU, allocated in
+  //   1280-byte granules, so there is no room for a third table.)
+  double *c_rdz = lds + 4 * NA, *c_dtohk = lds + 5 * NA, *c_misc = c_rdz + (NA - 2);
+  double *slots = lds + WG_CONST_DOUBLES(NA);
   double *my = slots + wave * SS;
   double *screc = slots + W * SS;   // [W][C_COUNT]
   double *sc = screc + wave * C_COUNT;
@@ -89,7 +95,10 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     c_hm[i] = p.hm[i];
     c_t0[i] = p.tri0[i];
     c_t1[i] = p.tri1[i];
+    if (i < NA - 2) c_rdz[i] = rcp_refine(p.zm[i] - p.zm[i + 1]);
+    c_dtohk[i] = p.dto / p.hm[i];
   }
+  if (threadIdx.x == 0) { c_misc[0] = rcp_refine(p.hm[1]); c_misc[1] = rcp_refine(p.vonk); }
   if (threadIdx.x < W) { sact[threadIdx.x] = 0; sbad[threadIdx.x] = 0; }
   __syncthreads();
 
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       cp[j] = cpsw_dev(Sin, Tin, Pin);
       talpha[j] = al;
       sbeta[j] = be;
-      buoy[j] = -p.grav * s0 / 1000.;
+      buoy[j] = div_fast(-p.grav * s0, 1000., 1. / 1000.);
     }
     const double rhoh2o = first_lane(bcast_level(rho, lane_v1, j_v1)), rhob = first_lane(bcast_level(rho, lane_v2, j_v2));
     const double rho0 = first_lane(rho[0]), cp0 = first_lane(cp[0]);
@@ -227,20 +236,23 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     const double sflux1 = cs[CS_SFLUX1], sflux2 = cs[CS_SFLUX2], sflux3 = cs[CS_SFLUX3],
                  sflux4 = cs[CS_SFLUX4], sflux5 = cs[CS_SFLUX5], sflux6 = cs[CS_SFLUX6];
     const double Ssurf = cs[CS_SSURF];
-    const double wU0_1 = first_lane(-sflux1 / rho0);   // verticalmixing_mod.F90:81-100
-    const double wU0_2 = first_lane(-sflux2 / rho0);
+    const double r_rho0 = rcp_refine(rho0), rho0cp0 = rho0 * cp0, r_rc = rcp_refine(rho0cp0);
+    const double wU0_1 = first_lane(div_fast(-sflux1, rho0, r_rho0));   // verticalmixing_mod.F90:81-100
+    const double wU0_2 = first_lane(div_fast(-sflux2, rho0, r_rho0));
     const double tau = __builtin_sqrt(sflux1 * sflux1 + sflux2 * sflux2) + 1.e-16;
-    const double ustar = first_lane(__builtin_sqrt(tau / rho0));
-    const double wX0_1 = first_lane(-sflux4 / rho0 / cp0);
-    const double wX0_2 = first_lane(Ssurf * sflux6 / rhoh2o + (Ssurf - p.sice) * sflux5 / rhob);
+    const double ustar = first_lane(__builtin_sqrt(div_fast(tau, rho0, r_rho0)));
+    const double wX0_1 = first_lane(div_fast(div_fast(-sflux4, rho0, r_rho0), cp0, rcp_refine(cp0)));
+    const double wX0_2 = first_lane(div_fast(Ssurf * sflux6, rhoh2o, rcp_refine(rhoh2o)) +
+                                    div_fast((Ssurf - p.sice) * sflux5, rhob, rcp_refine(rhob)));
     const double B0 = first_lane(-p.grav * (talpha0 * wX0_1 - sbeta0 * wX0_2));
-    const double B0sol = first_lane(p.grav * talpha0 * sflux3 / (rho0 * cp0));
+    const double B0sol = first_lane(div_fast(p.grav * talpha0 * sflux3, rho0cp0, r_rc));
     const wscale_u wu = wscale_prepare_uniform(ustar);
+    const double r_vonk = first_lane(c_misc[1]);
     if (lane == 0) {
       sc[C_B0] = B0; sc[C_B0SOL] = B0sol; sc[C_USTAR] = ustar; sc[C_WU01] = wU0_1; sc[C_WU02] = wU0_2;
-      sc[C_WX01] = wX0_1; sc[C_WX02] = wX0_2; sc[C_RHO0CP0] = rho0 * cp0;
+      sc[C_WX01] = wX0_1; sc[C_WX02] = wX0_2; sc[C_RHO0CP0] = rho0cp0; sc[C_RRC] = r_rc;
       if (ntime >= 1)   // wXNT(0,1), fluxes_mod.F90:110-116
-        sc[C_WXNT0] = -sflux3 * p.swdk_tab[jer * p.ldc] / (rho0 * cp0);
+        sc[C_WXNT0] = div_fast(-sflux3 * p.swdk_tab[jer * p.ldc], rho0cp0, r_rc);
     }
 
     FORJ if (act[j]) { aU[kk[j]] = U[j]; aV[kk[j]] = V[j]; aB[kk[j]] = buoy[j]; }
@@ -266,12 +278,14 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       const double U1 = first_lane(aU[1]), V1 = first_lane(aV[1]), Bu1 = first_lane(aB[1]);
       double zref[LPL], ur[LPL], vr[LPL], br[LPL];
       bool live[LPL];
+      double rzref[LPL];
       FORJ {
         zref[j] = eps01 * zmk[j];
+        rzref[j] = rcp_refine(zref[j]);
         double wz = dmax2(zm1, zref[j]);
-        ur[j] = U1 * wz / zref[j];
-        vr[j] = V1 * wz / zref[j];
-        br[j] = Bu1 * wz / zref[j];
+        ur[j] = div_fast_guarded(U1 * wz, zref[j], rzref[j]);
+        vr[j] = div_fast_guarded(V1 * wz, zref[j], rzref[j]);
+        br[j] = div_fast(Bu1 * wz, zref[j], rzref[j]);
         live[j] = actz[j];
       }
       double zk = zm1, Uk = U1, Vk = V1, Bk = Bu1;
@@ -284,12 +298,13 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
           any = any || live[j];
         }
         if (!__any(any)) break;
+        const double dzk = zk - zk1, rdzk = first_lane(c_rdz[kl]);
         FORJ if (live[j]) {
           double wz = dmin2(zk - zk1, zk - zref[j]);
-          double del = 0.5 * wz / (zk - zk1);
-          ur[j] = ur[j] - wz * (Uk + del * (Uk1 - Uk)) / zref[j];
-          vr[j] = vr[j] - wz * (Vk + del * (Vk1 - Vk)) / zref[j];
-          br[j] = br[j] - wz * (Bk + del * (Bk1 - Bk)) / zref[j];
+          double del = div_fast(0.5 * wz, dzk, rdzk);
+          ur[j] = ur[j] - div_fast_guarded(wz * (Uk + del * (Uk1 - Uk)), zref[j], rzref[j]);
+          vr[j] = vr[j] - div_fast_guarded(wz * (Vk + del * (Vk1 - Vk)), zref[j], rzref[j]);
+          br[j] = br[j] - div_fast(wz * (Bk + del * (Bk1 - Bk)), zref[j], rzref[j]);
         }
         zk = zk1; Uk = Uk1; Vk = Vk1; Bk = Bk1;
       }
@@ -310,7 +325,8 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     FORJ {
       int k = kk[j];
       zdiff[j] = zmk[j] - c_zm[k + 1];
-      Rig[j] = dbloc[j] * zdiff[j] / (shsq[j] + 1.e-16);
+      const double shs = shsq[j] + 1.e-16;
+      Rig[j] = div_fast(dbloc[j] * zdiff[j], shs, rcp_refine(shs));
       if (actz[j]) { aR[k] = Rig[j]; aDb[k] = dbloc[j]; }
       if (k == 1) aR[0] = 0.0;
       if (k == nzp1) aR[k] = 0.0;
@@ -334,9 +350,10 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       double wp1 = (k + 1 <= nz && !((vp1 < 0.0) || (vp1 > Riinfty))) ? 1.0 : 0.0;
       double sm = wm1 * vm1 + 2. * Rig[j] + wp1 * vp1;
       double wait = wm1 + 2.0 + wp1;
-      sm = sm / wait;
+      // wait is 2, 3 or 4: exact reciprocals but for 1/3 (correctly rounded literal)
+      sm = div_fast(sm, wait, wait == 3.0 ? 1. / 3. : (wait == 2.0 ? 0.5 : 0.25));
       double Rigg = dmax2(sm, 0.0);
-      double ratio = dmin2(Rigg / Riinfty, 1.0);
+      double ratio = dmin2(div_fast(Rigg, Riinfty, 1. / Riinfty), 1.0);
       double fri = (1.0 - ratio * ratio);
       fri = fri * fri * fri;
       dm_i[j] = (0.0001 + fri * 0.005);
@@ -384,10 +401,11 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       double wm, ws;
       wscale_dev(p, wu, sg, -zmk[j], bf, wm, ws);
       double dbm1 = aDb[k - 1];
-      double bvsq = 0.5 * (dbm1 / (c_zm[k - 1] - zmk[j]) + dbloc[j] / zdiff[j]);
+      double bvsq = 0.5 * (div_fast(dbm1, c_zm[k - 1] - zmk[j], c_rdz[k - 1]) + div_fast(dbloc[j], zdiff[j], c_rdz[k]));
       double Vtsq = -zmk[j] * ws * __builtin_sqrt(__builtin_fabs(bvsq)) * p.Vtc;
-      double raw = Ritop[j] / (dVsq[j] + Vtsq + epsln16);
-      double dmo = cmonob * ustar * ustar * ustar / p.vonk / (__builtin_fabs(bf) + epsln16);
+      const double rawden = dVsq[j] + Vtsq + epsln16, bfa = __builtin_fabs(bf) + epsln16;
+      double raw = div_fast(Ritop[j], rawden, rcp_refine(rawden));
+      double dmo = div_fast(div_fast(cmonob * ustar * ustar * ustar, p.vonk, r_vonk), bfa, rcp_refine(bfa));
       dmo = st * dmo - (1. - st) * zm_kmp1;
       if (k >= 2 && actz[j]) { aR[k] = raw; aDmo[k] = dmo; }
       if (k == 1) { aR[1] = 0.0; aDmo[1] = -zm_kmp1; }
@@ -481,7 +499,8 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     const double ocdepth = cs[CS_OCDEPTH];
     const double zm_kmp1 = first_lane(c_zm[nzp1]);
     const wscale_u wu = wscale_prepare_uniform(ustar);
-    const double hek = first_lane(cekman * ustar / (__builtin_fabs(f) + epsln16));
+    const double fa = __builtin_fabs(f) + epsln16;
+    const double hek = first_lane(div_fast(cekman * ustar, fa, rcp_refine(fa)));
     double zmk[LPL];
     FORJ zmk[j] = c_zm[kk[j]];
     int kbl = nz;
@@ -525,6 +544,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     bfsfc = first_lane(bfsfc + stable * epsln16);
     const double caseA = first_lane(0.5 + dsign(0.5, -c_zm[kbl] - 0.5 * c_hm[kbl] - hbl));
     double gat1[3], dat1[3], dkm1[3];
+    const double r_hbl = first_lane(rcp_refine(hbl));   // every quotient over hbl below shares it
     {
       double wm, ws;
       double sigma = stable * 1.0 + (1. - stable) * eps01;
@@ -532,34 +552,37 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       int ifx = (int)(caseA + epsln20);
       int kn = ifx * (kbl - 1) + (1 - ifx) * kbl;
       double hmkn = c_hm[kn], hmkn1 = c_hm[kn + 1];
+      const double r_hmkn = rcp_refine(hmkn), r_hmkn1 = rcp_refine(hmkn1);
       double delhat = 0.5 * hmkn - c_zm[kn] - hbl;
-      double R = 1.0 - delhat / hmkn;
+      double R = 1.0 - div_fast(delhat, hmkn, r_hmkn);
       const double *dd[3] = {aDm, aDs, aDt};
       double dp[3], dh[3];
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
-        double dvdzup = (dd[m][kn - 1] - dd[m][kn]) / hmkn;
-        double dvdzdn = (dd[m][kn] - dd[m][kn + 1]) / hmkn1;
+        double dvdzup = div_fast(dd[m][kn - 1] - dd[m][kn], hmkn, r_hmkn);
+        double dvdzdn = div_fast(dd[m][kn] - dd[m][kn + 1], hmkn1, r_hmkn1);
         dp[m] = 0.5 * ((1. - R) * (dvdzup + __builtin_fabs(dvdzup)) + R * (dvdzdn + __builtin_fabs(dvdzdn)));
         dh[m] = dd[m][kn] + dp[m] * delhat;
       }
       double u4 = ((ustar * ustar) * ustar) * ustar;
-      double f1 = stable * 5.0 * bfsfc / (u4 + epsln20);
-      gat1[0] = dh[0] / hbl / (wm + epsln20);
-      dat1[0] = -dp[0] / (wm + epsln20) + f1 * dh[0];
+      const double u4e = u4 + epsln20, wme = wm + epsln20, wse = ws + epsln20;
+      const double r_wme = rcp_refine(wme), r_wse = rcp_refine(wse);
+      double f1 = div_fast(stable * 5.0 * bfsfc, u4e, rcp_refine(u4e));
+      gat1[0] = div_fast(div_fast(dh[0], hbl, r_hbl), wme, r_wme);
+      dat1[0] = div_fast(-dp[0], wme, r_wme) + f1 * dh[0];
       dat1[0] = dmin2(dat1[0], 0.);
-      gat1[1] = dh[1] / hbl / (ws + epsln20);
-      dat1[1] = -dp[1] / (ws + epsln20) + f1 * dh[1];
+      gat1[1] = div_fast(div_fast(dh[1], hbl, r_hbl), wse, r_wse);
+      dat1[1] = div_fast(-dp[1], wse, r_wse) + f1 * dh[1];
       dat1[1] = dmin2(dat1[1], 0.);
-      gat1[2] = dh[2] / hbl / (ws + epsln20);
-      dat1[2] = -dp[2] / (ws + epsln20) + f1 * dh[2];
+      gat1[2] = div_fast(div_fast(dh[2], hbl, r_hbl), wse, r_wse);
+      dat1[2] = div_fast(-dp[2], wse, r_wse) + f1 * dh[2];
       dat1[2] = dmin2(dat1[2], 0.);
 #pragma unroll
       for (int m = 0; m < 3; ++m) { gat1[m] = first_lane(gat1[m]); dat1[m] = first_lane(dat1[m]); }
     }
     {
       double wm, ws;
-      double sig = -c_zm[kbl - 1] / hbl;
+      double sig = div_fast(-c_zm[kbl - 1], hbl, r_hbl);
       double sigma = stable * sig + (1. - stable) * dmin2(sig, eps01);
       wscale_dev(p, wu, sigma, hbl, bfsfc, wm, ws);
       double a1 = sig - 2.;
@@ -578,7 +601,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       const double hk = c_hm[k];
       const double dm_i = aDm[k], ds_i = aDs[k], dt_i = aDt[k];   // interior values of phase A
       double wm, ws;
-      double sig = (-zmk[j] + 0.5 * hk) / hbl;
+      double sig = div_fast(-zmk[j] + 0.5 * hk, hbl, r_hbl);
       double sigma = stable * sig + (1. - stable) * dmin2(sig, eps01);
       wscale_dev(p, wu, sigma, hbl, bfsfc, wm, ws);
       double a1 = sig - 2.;
@@ -590,9 +613,10 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       double b0 = hbl * wm * sig * (1. + sig * Gm);
       double b1 = hbl * ws * sig * (1. + sig * Gs);
       double b2 = hbl * ws * sig * (1. + sig * Gt);
-      double gh = (1. - stable) * p.cg / (ws * hbl + epsln20);
+      const double ghd = ws * hbl + epsln20;
+      double gh = div_fast((1. - stable) * p.cg, ghd, rcp_refine(ghd));
       if (k == kbl - 1 && k <= nz - 1) {   // enhance_mod.F90:10-51
-        double delta = (hbl + zmk[j]) / (zmk[j] - c_zm[k + 1]);
+        double delta = div_fast(hbl + zmk[j], zmk[j] - c_zm[k + 1], c_rdz[k]);
         double omd = 1. - delta;
         double dkmp5 = caseA * dm_i + (1. - caseA) * b0;
         double dstar = (omd * omd) * dkm1[0] + (delta * delta) * dkmp5;
@@ -630,7 +654,8 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     const double dto = p.dto, tri1_nz = first_lane(c_t1[nz]), hm1 = first_lane(c_hm[1]);
     const double wU0_1 = first_lane(sc[C_WU01]), wX0_1 = first_lane(sc[C_WX01]), wX0_2 = first_lane(sc[C_WX02]),
                  wXNT0 = first_lane(sc[C_WXNT0]);
-    const double rho0cp0 = first_lane(sc[C_RHO0CP0]), sflux3 = cs[CS_SFLUX3];
+    const double rho0cp0 = first_lane(sc[C_RHO0CP0]), r_rc = first_lane(sc[C_RRC]), sflux3 = cs[CS_SFLUX3];
+    const double r_hm1 = first_lane(c_misc[0]);
     double *yU = row(R_YU), *yT = row(R_YT), *yS = row(R_YS);
     FORJ {
       int k = kk[j];
@@ -639,25 +664,25 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       const double gh_m1 = (k >= 2) ? aGh[k - 1] : 0.0;
       double wxnt = 0.0, wxnt_m1 = 0.0;   // wXNT(k,1), wXNT(k-1,1), fluxes_mod.F90:110-116
       if (ntime >= 1) {
-        wxnt = -sflux3 * p.swdk_tab[jer * p.ldc + k] / rho0cp0;
-        wxnt_m1 = -sflux3 * p.swdk_tab[jer * p.ldc + k - 1] / rho0cp0;
+        wxnt = div_fast(-sflux3 * p.swdk_tab[jer * p.ldc + k], rho0cp0, r_rc);
+        wxnt_m1 = div_fast(-sflux3 * p.swdk_tab[jer * p.ldc + k - 1], rho0cp0, r_rc);
       }
       double rhsU;   // ocnint_mod.F90:51-58
-      if (k == 1) rhsU = Uo[j] + dto * (f * .5 * (Vo[j] + V[j]) - wU0_1 / hm1);
+      if (k == 1) rhsU = Uo[j] + dto * (f * .5 * (Vo[j] + V[j]) - div_fast(wU0_1, hm1, r_hm1));
       else rhsU = Uo[j] + dto * f * .5 * (Vo[j] + V[j]);
       if (k == nz) rhsU = rhsU + tri1_nz * difm[j] * Uo_np;
       double rhsT;   // tridrhs, solvers.F90:53-107 (npd = 1)
-      const double hk = c_hm[k];
+      const double dtohk = c_dtohk[k];   // dto/hm(k), the quotient itself tabulated
       if (k == 1)
-        rhsT = To[j] + dto / hk * (wX0_1 * dift[j] * ghat[j] - wX0_1 * 1.0 + wxnt - wXNT0);
+        rhsT = To[j] + dtohk * (wX0_1 * dift[j] * ghat[j] - wX0_1 * 1.0 + wxnt - wXNT0);
       else
-        rhsT = To[j] + dto / hk * (wX0_1 * (dift[j] * ghat[j] - dt_m1 * gh_m1) + wxnt - wxnt_m1);
+        rhsT = To[j] + dtohk * (wX0_1 * (dift[j] * ghat[j] - dt_m1 * gh_m1) + wxnt - wxnt_m1);
       if (k == nz && nz > 1) rhsT = rhsT + To_np * tri1_nz * dift[j];
       double rhsS;
       if (k == 1)
-        rhsS = So[j] + dto / hk * (wX0_2 * difs[j] * ghat[j] - wX0_2 * 1.0 + 0.0 - 0.0);
+        rhsS = So[j] + dtohk * (wX0_2 * difs[j] * ghat[j] - wX0_2 * 1.0 + 0.0 - 0.0);
       else
-        rhsS = So[j] + dto / hk * (wX0_2 * (difs[j] * ghat[j] - ds_m1 * gh_m1) + 0.0 - 0.0);
+        rhsS = So[j] + dtohk * (wX0_2 * (difs[j] * ghat[j] - ds_m1 * gh_m1) + 0.0 - 0.0);
       if (k == nz && nz > 1) rhsS = rhsS + So_np * tri1_nz * difs[j];
       if constexpr (EXT) ext_rhs(k, j, kbl, To[j], So[j], rhsT, rhsS);
       yU[k] = rhsU; yT[k] = rhsT; yS[k] = rhsS;
@@ -676,13 +701,13 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     load_old(p.U, Uo); load_old(p.V, Vo);
     const double Vo_np = old_bottom(p.V);
     const double dto = p.dto, tri1_nz = first_lane(c_t1[nz]), hm1 = first_lane(c_hm[1]), f = first_lane(sc[C_F]),
-                 wU0_2 = first_lane(sc[C_WU02]);
+                 wU0_2 = first_lane(sc[C_WU02]), r_hm1 = first_lane(c_misc[0]);
     FORJ {
       int k = kk[j];
       if (actz[j]) {
         const double un = yU[k];
         double rhsV;
-        if (k == 1) rhsV = Vo[j] - dto * (f * .5 * (Uo[j] + un) + wU0_2 / hm1);
+        if (k == 1) rhsV = Vo[j] - dto * (f * .5 * (Uo[j] + un) + div_fast(wU0_2, hm1, r_hm1));
         else rhsV = Vo[j] - dto * f * .5 * (Uo[j] + un);
         if (k == nz) rhsV = rhsV + tri1_nz * aDm[k] * Vo_np;
         yV[k] = rhsV;
@@ -1127,7 +1152,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
 template <int LPL, int W, bool EXT>
 size_t wg_lds_bytes()
 {
-  return (size_t)(4 * wg_na<LPL>() + W * wg_slot_stride<LPL, EXT>() + W * C_COUNT) * sizeof(double) +
+  return (size_t)(WG_CONST_DOUBLES(wg_na<LPL>()) + W * wg_slot_stride<LPL, EXT>() + W * C_COUNT) * sizeof(double) +
          2 * W * sizeof(int);
 }
 
@@ -1166,12 +1191,12 @@ hipError_t mckpp_launch_column_kernel_wg(const mckpp_kparams &p, const mckpp_kpa
   }
   int W, per_cu;
   switch (lpl) {
-    case 1: W = 4; per_cu = 5; break;   // 30.6 KB LDS and <=96 VGPRs per wave: 20 waves per CU
-    case 2: W = 2; per_cu = 5; break;   // 27 KB LDS per workgroup, <=168 VGPRs
+    case 1: W = 4; per_cu = 5; break;   // 31.9 KB LDS and <=96 VGPRs per wave: 20 waves per CU
+    case 2: W = 2; per_cu = 4; break;   // 33.8 KB LDS per workgroup, <=168 VGPRs
     default: W = 4; per_cu = 1; break;
   }
   if (lpl == 1 && (envW == 4 || envW == 8)) { W = envW; per_cu = (W == 8) ? 2 : 5; }
-  if (lpl == 2 && (envW == 2 || envW == 4)) { W = envW; per_cu = (W == 2) ? 5 : 2; }
+  if (lpl == 2 && (envW == 2 || envW == 4)) { W = envW; per_cu = (W == 2) ? 4 : 2; }
   if (envB > 0) per_cu = envB;
   int nblocks = num_cu * per_cu;
   const int groups = (p.ncol + W - 1) / W;
