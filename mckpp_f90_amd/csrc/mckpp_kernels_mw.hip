@@ -25,7 +25,7 @@ enum { R_DM = 0, R_DT, R_DS, R_GH, R_YU, R_YT, R_YS, R_GM, R_GT, R_GS, R_BETM, R
 enum { R_U = R_YU, R_V = R_YT, R_B = R_YS, R_R = R_GM, R_DB = R_GT, R_DMO = R_GS, R_T = R_BETM };
 enum { S_EMPTY = 0, S_ACTIVE = 1, S_DONE = 2 };
 // per-slot double record
-enum { C_B0 = 0, C_WU01, C_WU02, C_WX01, C_WX02, C_WXNT0, C_UREFNZ, C_VREFNZ, C_RHO0CP0,
+enum { C_B0 = 0, C_WU01, C_WU02, C_WX01, C_WX02, C_WXNT0, C_UREFNZ, C_VREFNZ, C_RHO0CP0, C_RRC,
        X_RHO0, X_CP0, X_TALPHA0, X_SBETA0, X_RHOH2O, X_RHOB,
        X_CAND_HBL,            // + sub (WPS entries)
        C_COUNT = X_CAND_HBL + 4 };
@@ -56,7 +56,9 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
   const bool lead = (sub == 0);            // the wave that owns level 1
   const int nz = p.nz, nzp1 = p.nzp1;
   double *c_zm = lds, *c_hm = lds + NA, *c_t0 = lds + 2 * NA, *c_t1 = lds + 3 * NA;
-  double *slots = lds + 4 * NA;
+  // grid-constant refined reciprocals / quotients for div_fast (see k_column_wg)
+  double *c_rdz = lds + 4 * NA, *c_dtohk = lds + 5 * NA, *c_misc = c_rdz + (NA - 2);
+  double *slots = lds + 6 * NA;
   double *my = slots + slot * SS;
   double *screc = slots + W * SS;
   double *sc = screc + slot * C_COUNT;
@@ -74,7 +76,10 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     c_hm[i] = p.hm[i];
     c_t0[i] = p.tri0[i];
     c_t1[i] = p.tri1[i];
+    if (i < NA - 2) c_rdz[i] = rcp_refine(p.zm[i] - p.zm[i + 1]);
+    c_dtohk[i] = p.dto / p.hm[i];
   }
+  if (threadIdx.x == 0) { c_misc[0] = rcp_refine(p.hm[1]); c_misc[1] = rcp_refine(p.vonk); }
   if (threadIdx.x < W) { sact[threadIdx.x] = 0; sbad[threadIdx.x] = 0; }
   __syncthreads();
 
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     abk80_dev(Sin, Tin, Pin, talpha, sbeta, s0);
     rho = 1000. + s0;
     cp = cpsw_dev(Sin, Tin, Pin);
-    buoy = -p.grav * s0 / 1000.;
+    buoy = div_fast(-p.grav * s0, 1000., 1. / 1000.);
     if (k == 1) { sc[X_RHO0] = rho; sc[X_CP0] = cp; sc[X_TALPHA0] = talpha; sc[X_SBETA0] = sbeta; }
     if (k == nzp1 + 1) sc[X_RHOH2O] = rho;
     if (k == nzp1 + 2) sc[X_RHOB] = rho;
@@ -178,24 +183,27 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     const double sflux1 = cs[CS_SFLUX1], sflux2 = cs[CS_SFLUX2], sflux3 = cs[CS_SFLUX3],
                  sflux4 = cs[CS_SFLUX4], sflux5 = cs[CS_SFLUX5], sflux6 = cs[CS_SFLUX6];
     const double Ssurf = cs[CS_SSURF];
-    const double wU0_1 = first_lane(-sflux1 / rho0);
-    const double wU0_2 = first_lane(-sflux2 / rho0);
+    const double r_rho0 = rcp_refine(rho0), rho0cp0 = rho0 * cp0, r_rc = rcp_refine(rho0cp0);
+    const double wU0_1 = first_lane(div_fast(-sflux1, rho0, r_rho0));
+    const double wU0_2 = first_lane(div_fast(-sflux2, rho0, r_rho0));
     const double tau = __builtin_sqrt(sflux1 * sflux1 + sflux2 * sflux2) + 1.e-16;
-    ustar = first_lane(__builtin_sqrt(tau / rho0));
-    const double wX0_1 = first_lane(-sflux4 / rho0 / cp0);
-    const double wX0_2 = first_lane(Ssurf * sflux6 / rhoh2o + (Ssurf - p.sice) * sflux5 / rhob);
+    ustar = first_lane(__builtin_sqrt(div_fast(tau, rho0, r_rho0)));
+    const double wX0_1 = first_lane(div_fast(div_fast(-sflux4, rho0, r_rho0), cp0, rcp_refine(cp0)));
+    const double wX0_2 = first_lane(div_fast(Ssurf * sflux6, rhoh2o, rcp_refine(rhoh2o)) +
+                                    div_fast((Ssurf - p.sice) * sflux5, rhob, rcp_refine(rhob)));
     B0 = first_lane(-p.grav * (talpha0 * wX0_1 - sbeta0 * wX0_2));
-    B0sol = first_lane(p.grav * talpha0 * sflux3 / (rho0 * cp0));
+    B0sol = first_lane(div_fast(p.grav * talpha0 * sflux3, rho0cp0, r_rc));
     if (lead && lane == 0) {
       sc[C_B0] = B0; sc[C_WU01] = wU0_1; sc[C_WU02] = wU0_2;
-      sc[C_WX01] = wX0_1; sc[C_WX02] = wX0_2; sc[C_RHO0CP0] = rho0 * cp0;
-      if (ntime >= 1) sc[C_WXNT0] = -sflux3 * p.swdk_tab[jer * p.ldc] / (rho0 * cp0);
+      sc[C_WX01] = wX0_1; sc[C_WX02] = wX0_2; sc[C_RHO0CP0] = rho0cp0; sc[C_RRC] = r_rc;
+      if (ntime >= 1) sc[C_WXNT0] = div_fast(-sflux3 * p.swdk_tab[jer * p.ldc], rho0cp0, r_rc);
     }
     const double zm1 = first_lane(c_zm[1]);
     const double U1 = first_lane(aU[1]), V1 = first_lane(aV[1]), Bu1 = first_lane(aB[1]);
-    const double zref = eps01 * zmk;
+    const double zref = eps01 * zmk, rzref = rcp_refine(zref);
     double wz = dmax2(zm1, zref);
-    double ur = U1 * wz / zref, vr = V1 * wz / zref, br = Bu1 * wz / zref;
+    double ur = div_fast_guarded(U1 * wz, zref, rzref), vr = div_fast_guarded(V1 * wz, zref, rzref),
+           br = div_fast(Bu1 * wz, zref, rzref);
     bool live = actz;
     double zk = zm1, Uk = U1, Vk = V1, Bk = Bu1;
     for (int kl = 1; kl <= nz; ++kl) {
@@ -204,11 +212,12 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
       live = live && !(zref >= zk);
       if (!__any(live)) break;
       if (live) {
+        const double dzk = zk - zk1, rdzk = first_lane(c_rdz[kl]);
         double wz2 = dmin2(zk - zk1, zk - zref);
-        double del = 0.5 * wz2 / (zk - zk1);
-        ur = ur - wz2 * (Uk + del * (Uk1 - Uk)) / zref;
-        vr = vr - wz2 * (Vk + del * (Vk1 - Vk)) / zref;
-        br = br - wz2 * (Bk + del * (Bk1 - Bk)) / zref;
+        double del = div_fast(0.5 * wz2, dzk, rdzk);
+        ur = ur - div_fast_guarded(wz2 * (Uk + del * (Uk1 - Uk)), zref, rzref);
+        vr = vr - div_fast_guarded(wz2 * (Vk + del * (Vk1 - Vk)), zref, rzref);
+        br = br - div_fast(wz2 * (Bk + del * (Bk1 - Bk)), zref, rzref);
       }
       zk = zk1; Uk = Uk1; Vk = Vk1; Bk = Bk1;
     }
@@ -219,7 +228,8 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     shsq = (U - uk1) * (U - uk1) + (V - vk1) * (V - vk1);
     if (p.mode != MCKPP_MODE_STEP && k == nz) { sc[C_UREFNZ] = ur; sc[C_VREFNZ] = vr; }
     zdiff = zmk - c_zm[k + 1];
-    Rig = dbloc * zdiff / (shsq + 1.e-16);
+    const double shs = shsq + 1.e-16;
+    Rig = div_fast(dbloc * zdiff, shs, rcp_refine(shs));
     if (actz) { aR[k] = Rig; aDb[k] = dbloc; }
     if (k == 1) aR[0] = 0.0;
     if (k == nzp1) aR[k] = 0.0;
@@ -237,9 +247,9 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     double wp1 = (k + 1 <= nz && !((vp1 < 0.0) || (vp1 > Riinfty))) ? 1.0 : 0.0;
     double sm = wm1 * vm1 + 2. * Rig + wp1 * vp1;
     double wait = wm1 + 2.0 + wp1;
-    sm = sm / wait;
+    sm = div_fast(sm, wait, wait == 3.0 ? 1. / 3. : (wait == 2.0 ? 0.5 : 0.25));
     double Rigg = dmax2(sm, 0.0);
-    double ratio = dmin2(Rigg / Riinfty, 1.0);
+    double ratio = dmin2(div_fast(Rigg, Riinfty, 1. / Riinfty), 1.0);
     double fri = (1.0 - ratio * ratio);
     fri = fri * fri * fri;
     dm_i = (0.0001 + fri * 0.005);
@@ -258,10 +268,11 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     double wm, ws;
     wscale_dev(p, wu, sg, -zmk, bf, wm, ws);
     double dbm1 = aDb[k - 1];
-    double bvsq = 0.5 * (dbm1 / (c_zm[k - 1] - zmk) + dbloc / zdiff);
+    double bvsq = 0.5 * (div_fast(dbm1, c_zm[k - 1] - zmk, c_rdz[k - 1]) + div_fast(dbloc, zdiff, c_rdz[k]));
     double Vtsq = -zmk * ws * __builtin_sqrt(__builtin_fabs(bvsq)) * p.Vtc;
-    double raw = Ritop / (dVsq + Vtsq + epsln16);
-    double dmo = cmonob * ustar * ustar * ustar / p.vonk / (__builtin_fabs(bf) + epsln16);
+    const double rawden = dVsq + Vtsq + epsln16, bfa = __builtin_fabs(bf) + epsln16;
+    double raw = div_fast(Ritop, rawden, rcp_refine(rawden));
+    double dmo = div_fast(div_fast(cmonob * ustar * ustar * ustar, p.vonk, first_lane(c_misc[1])), bfa, rcp_refine(bfa));
     dmo = st * dmo - (1. - st) * zm_kmp1;
     if (k >= 2 && actz) { aR[k] = raw; aDmo[k] = dmo; }
     if (k == 1) { aR[1] = 0.0; aDmo[1] = -zm_kmp1; }
@@ -270,7 +281,8 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     const double f = f_col;
     const double ocdepth = csrow()[CS_OCDEPTH];
     const double zm_kmp1 = first_lane(c_zm[nzp1]);
-    const double hek = first_lane(cekman * ustar / (__builtin_fabs(f) + epsln16));
+    const double fa = __builtin_fabs(f) + epsln16;
+    const double hek = first_lane(div_fast(cekman * ustar, fa, rcp_refine(fa)));
     double swf = p.swfrac_tab[jer * p.ldc + k];
     double bf = B0 + B0sol * (1. - swf);
     double stab = 0.5 + dsign(0.5, bf + epsln16);
@@ -321,6 +333,7 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     bfsfc = first_lane(bfsfc + stable * epsln16);
     const double caseA = first_lane(0.5 + dsign(0.5, -c_zm[kbl] - 0.5 * c_hm[kbl] - hbl));
     double gat1[3], dat1[3], dkm1[3];
+    const double r_hbl = first_lane(rcp_refine(hbl));
     {
       double wm, ws;
       double sigma = stable * 1.0 + (1. - stable) * eps01;
@@ -328,34 +341,37 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
       int ifx = (int)(caseA + epsln20);
       int kn = ifx * (kbl - 1) + (1 - ifx) * kbl;
       double hmkn = c_hm[kn], hmkn1 = c_hm[kn + 1];
+      const double r_hmkn = rcp_refine(hmkn), r_hmkn1 = rcp_refine(hmkn1);
       double delhat = 0.5 * hmkn - c_zm[kn] - hbl;
-      double R = 1.0 - delhat / hmkn;
+      double R = 1.0 - div_fast(delhat, hmkn, r_hmkn);
       const double *dd[3] = {aDm, aDs, aDt};
       double dp[3], dh[3];
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
-        double dvdzup = (dd[m][kn - 1] - dd[m][kn]) / hmkn;
-        double dvdzdn = (dd[m][kn] - dd[m][kn + 1]) / hmkn1;
+        double dvdzup = div_fast(dd[m][kn - 1] - dd[m][kn], hmkn, r_hmkn);
+        double dvdzdn = div_fast(dd[m][kn] - dd[m][kn + 1], hmkn1, r_hmkn1);
         dp[m] = 0.5 * ((1. - R) * (dvdzup + __builtin_fabs(dvdzup)) + R * (dvdzdn + __builtin_fabs(dvdzdn)));
         dh[m] = dd[m][kn] + dp[m] * delhat;
       }
       double u4 = ((ustar * ustar) * ustar) * ustar;
-      double f1 = stable * 5.0 * bfsfc / (u4 + epsln20);
-      gat1[0] = dh[0] / hbl / (wm + epsln20);
-      dat1[0] = -dp[0] / (wm + epsln20) + f1 * dh[0];
+      const double u4e = u4 + epsln20, wme = wm + epsln20, wse = ws + epsln20;
+      const double r_wme = rcp_refine(wme), r_wse = rcp_refine(wse);
+      double f1 = div_fast(stable * 5.0 * bfsfc, u4e, rcp_refine(u4e));
+      gat1[0] = div_fast(div_fast(dh[0], hbl, r_hbl), wme, r_wme);
+      dat1[0] = div_fast(-dp[0], wme, r_wme) + f1 * dh[0];
       dat1[0] = dmin2(dat1[0], 0.);
-      gat1[1] = dh[1] / hbl / (ws + epsln20);
-      dat1[1] = -dp[1] / (ws + epsln20) + f1 * dh[1];
+      gat1[1] = div_fast(div_fast(dh[1], hbl, r_hbl), wse, r_wse);
+      dat1[1] = div_fast(-dp[1], wse, r_wse) + f1 * dh[1];
       dat1[1] = dmin2(dat1[1], 0.);
-      gat1[2] = dh[2] / hbl / (ws + epsln20);
-      dat1[2] = -dp[2] / (ws + epsln20) + f1 * dh[2];
+      gat1[2] = div_fast(div_fast(dh[2], hbl, r_hbl), wse, r_wse);
+      dat1[2] = div_fast(-dp[2], wse, r_wse) + f1 * dh[2];
       dat1[2] = dmin2(dat1[2], 0.);
 #pragma unroll
       for (int m = 0; m < 3; ++m) { gat1[m] = first_lane(gat1[m]); dat1[m] = first_lane(dat1[m]); }
     }
     {
       double wm, ws;
-      double sig = -c_zm[kbl - 1] / hbl;
+      double sig = div_fast(-c_zm[kbl - 1], hbl, r_hbl);
       double sigma = stable * sig + (1. - stable) * dmin2(sig, eps01);
       wscale_dev(p, wu, sigma, hbl, bfsfc, wm, ws);
       double a1 = sig - 2.;
@@ -372,7 +388,7 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
       const double hk = c_hm[k];
       const double dt_i = ds_i;
       double wm, ws;
-      double sig = (-zmk + 0.5 * hk) / hbl;
+      double sig = div_fast(-zmk + 0.5 * hk, hbl, r_hbl);
       double sigma = stable * sig + (1. - stable) * dmin2(sig, eps01);
       wscale_dev(p, wu, sigma, hbl, bfsfc, wm, ws);
       double a1 = sig - 2.;
@@ -384,9 +400,10 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
       double b0 = hbl * wm * sig * (1. + sig * Gm);
       double b1 = hbl * ws * sig * (1. + sig * Gs);
       double b2 = hbl * ws * sig * (1. + sig * Gt);
-      double gh = (1. - stable) * p.cg / (ws * hbl + epsln20);
+      const double ghd = ws * hbl + epsln20;
+      double gh = div_fast((1. - stable) * p.cg, ghd, rcp_refine(ghd));
       if (k == kbl - 1 && k <= nz - 1) {
-        double delta = (hbl + zmk) / (zmk - c_zm[k + 1]);
+        double delta = div_fast(hbl + zmk, zmk - c_zm[k + 1], c_rdz[k]);
         double omd = 1. - delta;
         double dkmp5 = caseA * dm_i + (1. - caseA) * b0;
         double dstar = (omd * omd) * dkm1[0] + (delta * delta) * dkmp5;
@@ -417,28 +434,29 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     const double dto = p.dto, tri1_nz = first_lane(c_t1[nz]), hm1 = first_lane(c_hm[1]);
     const double wU0_1 = first_lane(sc[C_WU01]), wX0_1 = first_lane(sc[C_WX01]), wX0_2 = first_lane(sc[C_WX02]),
                  wXNT0 = first_lane(sc[C_WXNT0]);
-    const double rho0cp0 = first_lane(sc[C_RHO0CP0]), sflux3 = cs[CS_SFLUX3];
+    const double rho0cp0 = first_lane(sc[C_RHO0CP0]), r_rc = first_lane(sc[C_RRC]), sflux3 = cs[CS_SFLUX3];
+    const double r_hm1 = first_lane(c_misc[0]);
     double *yU = row(R_YU), *yT = row(R_YT), *yS = row(R_YS);
     if (actz) {
       const double dt_m1 = aDt[k - 1], ds_m1 = aDs[k - 1];
       const double gh_m1 = (k >= 2) ? aGh[k - 1] : 0.0;
       double wxnt = 0.0, wxnt_m1 = 0.0;
       if (ntime >= 1) {
-        wxnt = -sflux3 * p.swdk_tab[jer * p.ldc + k] / rho0cp0;
-        wxnt_m1 = -sflux3 * p.swdk_tab[jer * p.ldc + k - 1] / rho0cp0;
+        wxnt = div_fast(-sflux3 * p.swdk_tab[jer * p.ldc + k], rho0cp0, r_rc);
+        wxnt_m1 = div_fast(-sflux3 * p.swdk_tab[jer * p.ldc + k - 1], rho0cp0, r_rc);
       }
       double rhsU;
-      if (k == 1) rhsU = Uo + dto * (f * .5 * (Vo + V) - wU0_1 / hm1);
+      if (k == 1) rhsU = Uo + dto * (f * .5 * (Vo + V) - div_fast(wU0_1, hm1, r_hm1));
       else rhsU = Uo + dto * f * .5 * (Vo + V);
       if (k == nz) rhsU = rhsU + tri1_nz * difm * Uo_np;
       double rhsT;
-      const double hk = c_hm[k];
-      if (k == 1) rhsT = To + dto / hk * (wX0_1 * dift * ghat - wX0_1 * 1.0 + wxnt - wXNT0);
-      else rhsT = To + dto / hk * (wX0_1 * (dift * ghat - dt_m1 * gh_m1) + wxnt - wxnt_m1);
+      const double dtohk = c_dtohk[k];
+      if (k == 1) rhsT = To + dtohk * (wX0_1 * dift * ghat - wX0_1 * 1.0 + wxnt - wXNT0);
+      else rhsT = To + dtohk * (wX0_1 * (dift * ghat - dt_m1 * gh_m1) + wxnt - wxnt_m1);
       if (k == nz && nz > 1) rhsT = rhsT + To_np * tri1_nz * dift;
       double rhsS;
-      if (k == 1) rhsS = So + dto / hk * (wX0_2 * difs * ghat - wX0_2 * 1.0 + 0.0 - 0.0);
-      else rhsS = So + dto / hk * (wX0_2 * (difs * ghat - ds_m1 * gh_m1) + 0.0 - 0.0);
+      if (k == 1) rhsS = So + dtohk * (wX0_2 * difs * ghat - wX0_2 * 1.0 + 0.0 - 0.0);
+      else rhsS = So + dtohk * (wX0_2 * (difs * ghat - ds_m1 * gh_m1) + 0.0 - 0.0);
       if (k == nz && nz > 1) rhsS = rhsS + So_np * tri1_nz * difs;
       yU[k] = rhsU; yT[k] = rhsT; yS[k] = rhsS;
     }
@@ -448,13 +466,13 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     const double Uo = ld_old(p.U), Vo = ld_old(p.V);
     const double Vo_np = old_bottom(p.V);
     const double dto = p.dto, tri1_nz = first_lane(c_t1[nz]), hm1 = first_lane(c_hm[1]), f = f_col,
-                 wU0_2 = first_lane(sc[C_WU02]);
+                 wU0_2 = first_lane(sc[C_WU02]), r_hm1 = first_lane(c_misc[0]);
     const double *yU = row(R_YU);
     double *yV = row(R_YV);
     if (actz) {
       const double un = yU[k];
       double rhsV;
-      if (k == 1) rhsV = Vo - dto * (f * .5 * (Uo + un) + wU0_2 / hm1);
+      if (k == 1) rhsV = Vo - dto * (f * .5 * (Uo + un) + div_fast(wU0_2, hm1, r_hm1));
       else rhsV = Vo - dto * f * .5 * (Uo + un);
       if (k == nz) rhsV = rhsV + tri1_nz * aDm[k] * Vo_np;
       yV[k] = rhsV;
@@ -789,7 +807,7 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
 template <int WPS, int W>
 size_t mw_lds_bytes()
 {
-  return (size_t)(4 * mw_na<WPS>() + W * mw_slot_stride<WPS>() + W * C_COUNT) * sizeof(double) +
+  return (size_t)(6 * mw_na<WPS>() + W * mw_slot_stride<WPS>() + W * C_COUNT) * sizeof(double) +
          (size_t)(W * I_COUNT + 2 * W) * sizeof(int);
 }
 
