@@ -73,12 +73,14 @@ __device__ __forceinline__ double div_fast(double n, double d, double r)
   return __builtin_amdgcn_div_fixup(res, d, n);
 }
 
+// |x| < 2^-961 and x != 0: the numerators div_fast must not see (frexp's exponent of 0 is 0)
+__device__ __forceinline__ bool tiny_nonzero(double x) { return __builtin_amdgcn_frexp_exp(x) < -960; }
+
 // div_fast for numerators that can legitimately be tiny non-zero numbers (velocities that have
 // diffused down a deep column): those take the full IEEE sequence.
 __device__ __forceinline__ double div_fast_guarded(double n, double d, double r)
 {
-  const int ex = __builtin_amdgcn_frexp_exp(n);   // 0 for n == 0
-  if (__builtin_expect(ex < -960, 0)) return n / d;
+  if (__builtin_expect(tiny_nonzero(n), 0)) return n / d;
   return div_fast(n, d, r);
 }
 

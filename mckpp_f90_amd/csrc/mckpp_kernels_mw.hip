@@ -15,6 +15,7 @@
 #include "mckpp_colmath.h"
 
 #include <cstdio>
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -511,30 +512,52 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
         double *betm = base + R_BETM * NA, *rbm = base + R_RB * NA;
         int bad = 0;
         double dm1 = d[1], t1m1 = c_t1[1];
-        double bet = 1. + t1m1 * dm1;
-        double ynum = y[1];
-        double di_n = d[2], t0_n = c_t0[2], t1_n = c_t1[2], rhs_n = y[2];
-        for (int i = 2; i <= nz; ++i) {
-          const double di = di_n, t0 = t0_n, t1 = t1_n, rhs = rhs_n;
-          if (i < nz) { di_n = d[i + 1]; t0_n = c_t0[i + 1]; t1_n = c_t1[i + 1]; rhs_n = y[i + 1]; }
+        double bet = 1. + t1m1 * dm1;   // cc(1)
+        double ynum = y[1];             // y(1) = rhs(1)/bet, formed in the next level's step
+        // One level of the skewed sweep.  The serial wave shares its SIMD with four busy waves, so
+        // the sweep's time is its instruction count: the common case is one straight basic block
+        // (pivot chain bet -> 1/bet -> gam -> bet' interleaved with the solution chain, both on
+        // div_fast), and the two conditions that need other arithmetic - a zero pivot, or a tiny
+        // non-zero solution numerator that div_fast must not see - are detected at the end of the
+        // level before and sent through the slow copy of the step (IEEE sequences), practically never.
+        unsigned long long rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum));   // wave mask, lives in SGPRs
+        auto level = [&](int i, double di, double t0, double t1, double rhs, auto slow) {
+          if (slow.value && bet == 0.) { bad = 1; bet = 1.E-12; }   // solvers.F90:140-151 would stop here
           const double clm1 = -t1m1 * dm1;
           const double cu = -t0 * dm1;
           const double cc = 1. + t1 * di + t0 * dm1;
           const double rb = rcp_refine(bet);
-          const double g = div_by_refined(clm1, bet, rb);
-          const double yprev = div_by_refined(ynum, bet, rb);
+          const double g = slow.value ? div_by_refined(clm1, bet, rb) : div_fast(clm1, bet, rb);
+          const double yprev = slow.value ? div_by_refined(ynum, bet, rb) : div_fast(ynum, bet, rb);
           if (sys == 0) { betm[i - 1] = bet; rbm[i - 1] = rb; }
           y[i - 1] = yprev;
           gm[i] = g;
           bet = cc - cu * g;
-          if (bet == 0.) { bad = 1; bet = 1.E-12; }
           ynum = rhs - cu * yprev;
+          rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum)) | __builtin_amdgcn_ballot_w64(bet == 0.);
           dm1 = di; t1m1 = t1;
+        };
+        auto step = [&](int i, double di, double t0, double t1, double rhs) {
+          if (__builtin_expect(rare != 0ull, 0)) level(i, di, t0, t1, rhs, std::true_type{});
+          else level(i, di, t0, t1, rhs, std::false_type{});
+        };
+        {   // two levels per trip; each half's operands are fetched while the other half runs
+          int i = 2;
+          double a_d = d[2], a_t0 = c_t0[2], a_t1 = c_t1[2], a_r = y[2];
+          for (; i + 1 <= nz; i += 2) {
+            const double b_d = d[i + 1], b_t0 = c_t0[i + 1], b_t1 = c_t1[i + 1], b_r = y[i + 1];
+            step(i, a_d, a_t0, a_t1, a_r);
+            if (i + 2 <= nz) { a_d = d[i + 2]; a_t0 = c_t0[i + 2]; a_t1 = c_t1[i + 2]; a_r = y[i + 2]; }
+            step(i + 1, b_d, b_t0, b_t1, b_r);
+          }
+          if (i <= nz) step(i, a_d, a_t0, a_t1, a_r);
         }
+        if (bet == 0.) { bad = 1; bet = 1.E-12; }
         const double rbl = rcp_refine(bet);
         double yy = div_by_refined(ynum, bet, rbl);
         y[nz] = yy;
         if (sys == 0) { betm[nz] = bet; rbm[nz] = rbl; }
+        // back substitution, operands fetched four levels ahead
         int i = nz - 1;
         for (; i >= 4; i -= 4) {
           const double y0 = y[i], y1 = y[i - 1], y2 = y[i - 2], y3 = y[i - 3];
@@ -553,7 +576,7 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
       }
     }
   };
-  auto thomas_v = [&]() {
+  auto thomas_v = [&]() {   // V on the stored momentum factorisation (bet, refined 1/bet, gam)
     if (wv == 0 && lane < W && sact[lane]) {
       double *base = slots + lane * SS;
       const double *d = base + R_DM * NA, *gm = base + R_GM * NA, *betm = base + R_BETM * NA,
@@ -562,14 +585,36 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
       double yy = div_by_refined(y[1], betm[1], rbm[1]);
       y[1] = yy;
       double dm1 = d[1];
-      double rhs_n = y[2], t0_n = c_t0[2], b_n = betm[2], r_n = rbm[2], d_n = d[2];
-      for (int i = 2; i <= nz; ++i) {
-        const double rhs = rhs_n, t0 = t0_n, b = b_n, r = r_n, di = d_n;
-        if (i < nz) { rhs_n = y[i + 1]; t0_n = c_t0[i + 1]; b_n = betm[i + 1]; r_n = rbm[i + 1]; d_n = d[i + 1]; }
+      // Here the quotient is the dependent chain itself, so it takes div_fast unconditionally; a tiny
+      // non-zero numerator is noticed at the end of its level and the quotient is redone (IEEE
+      // sequence) at the top of the next one, before anything has used it.  Two levels per trip.
+      double nprev = 0.0, bprev = 1.0;
+      unsigned long long rare = 0ull;   // wave mask of lanes whose last numerator was tiny
+      auto vstep = [&](int i, double rhs, double t0, double b, double r, double di) {
+        if (__builtin_expect(rare != 0ull, 0)) {
+          if (tiny_nonzero(nprev)) { yy = nprev / bprev; y[i - 1] = yy; }
+        }
         const double cu = -t0 * dm1;
-        yy = div_by_refined(rhs - cu * yy, b, r);
+        const double n = rhs - cu * yy;
+        yy = div_fast(n, b, r);
+        rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(n));
         y[i] = yy;
+        nprev = n; bprev = b;
         dm1 = di;
+      };
+      {
+        int i = 2;
+        double a_rhs = y[2], a_t0 = c_t0[2], a_b = betm[2], a_r = rbm[2], a_d = d[2];
+        for (; i + 1 <= nz; i += 2) {
+          const double b_rhs = y[i + 1], b_t0 = c_t0[i + 1], b_b = betm[i + 1], b_r = rbm[i + 1], b_d = d[i + 1];
+          vstep(i, a_rhs, a_t0, a_b, a_r, a_d);
+          if (i + 2 <= nz) { a_rhs = y[i + 2]; a_t0 = c_t0[i + 2]; a_b = betm[i + 2]; a_r = rbm[i + 2]; a_d = d[i + 2]; }
+          vstep(i + 1, b_rhs, b_t0, b_b, b_r, b_d);
+        }
+        if (i <= nz) vstep(i, a_rhs, a_t0, a_b, a_r, a_d);
+      }
+      if (__builtin_expect(rare != 0ull, 0)) {
+        if (tiny_nonzero(nprev)) { yy = nprev / bprev; y[nz] = yy; }
       }
       int i = nz - 1;
       for (; i >= 4; i -= 4) {

@@ -571,3 +571,43 @@ def test_config2_pass_every_variant(mk, kernel_env):
         orc.vmix_batch(oc, ob, 1)
         _assert_bitexact(cm.compare(k3, ob, nz, fields), f"pass {variant} nz={nz}")
         ctx.close()
+
+
+@pytest.mark.parametrize("variant,nz", [("v1", 40), ("wg", 40), ("wg", 60), ("mw", 40), ("mw", 69), ("wg", 69)])
+def test_tiny_and_denormal_velocities_take_the_ieee_paths(mk, kernel_env, variant, nz):
+    """The kernels drop the v_div_scale rescaling where operand ranges are known and guard the
+    quotients whose numerators can be tiny non-zero numbers (velocities diffused down a deep column):
+    reference-level averages, Thomas solution numerators.  Profiles of 1e-290 ... denormal velocities
+    (and an almost-vanishing wind stress) push those guards into their IEEE fallbacks; the results
+    must still be the oracle's bits."""
+    from oracle import orc
+
+    kernel_env(variant)
+    ncol = 48
+    oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1)
+    kc, k3 = cm.make_hip_case(ncol, nz)
+    scale = np.array([1e-290, 3e-300, 7e-306, 5e-310, 2e-318, 4.9e-324])[np.arange(ncol) % 6]
+    prof = np.cos(0.37 * np.arange(nz + 1))[None, :] * scale[:, None]
+    k3.U[:, :, 0] = prof
+    k3.U[:, :, 1] = -0.5 * prof[:, ::-1]
+    k3.U_init[:] = k3.U
+    ob["U"][:, 1:nz + 2] = k3.U[:, :, 0]
+    ob["V"][:, 1:nz + 2] = k3.U[:, :, 1]
+    ob["U_init"][:, 1:nz + 2] = k3.U[:, :, 0]
+    ob["V_init"][:, 1:nz + 2] = k3.U[:, :, 1]
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    orc.init_ocean(oc, ob, 0)
+    _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS), f"tiny {variant} init")
+    sf = cm.synth.forcing(ncol, "bench")
+    sf[::2, 0] = 1e-300      # taux: wU(0,1) = -taux/rho tiny, drives tiny momentum right-hand sides
+    sf[::2, 1] = -3e-310     # tauy
+    ob["sflux"] = sf
+    cm.set_forcing_3d(k3, sf)
+    for nt in (1, 2):
+        mk.mckpp_physics_driver(k3, kc, nt)
+        orc.physics_driver(oc, ob, nt)
+        st, nf, npass = ctx.status()
+        assert np.array_equal(st, ob["status"]) and np.array_equal(npass, ob["npasses"])
+        _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS), f"tiny {variant} nz={nz} step {nt}")
+    u = np.abs(k3.U[:, :, 0])
+    assert np.any((u > 0) & (u < 1e-292))     # the guarded range was really exercised
