@@ -183,6 +183,22 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # instruction-issue side of the story (the kernel is not HBM-bound): committed PMC counters of
+        # the same workload, per launch; profiles/r01/README.md says how they were collected
+        issue = None
+        pf = os.path.join(ROOT, "profiles", "r01", "pmc_sq_final.json")
+        if os.path.exists(pf) and ncol == 100000 and nz == 60:
+            try:
+                c = json.load(open(pf))["counters"]
+                issue = {
+                    "source": "profiles/r01/pmc_sq_final.json (rocprofv3 --pmc, same workload, 6 passes per column)",
+                    "valu_wave_instructions_per_launch": c["SQ_INSTS_VALU"],
+                    "valu_instructions_per_column_pass": c["SQ_INSTS_VALU"] / (ncol * 6.0),
+                    "valu_active_over_wave_busy": c["SQ_ACTIVE_INST_VALU"] / c["SQ_ACTIVE_INST_ANY"],
+                    "lds_bank_conflict_cycles": c["SQ_LDS_BANK_CONFLICT"],
+                }
+            except Exception:
+                issue = None
         out = {
             "metric": "column-steps/s at 1e5 cols x 60 levels, 1/2/4/8 GPU; % HBM roofline",
             "value": ntotal * a.steps / dt,
@@ -205,6 +221,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": ctx.kernel_name + " (cooperative, persistent)",
                 "kernel_avg_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": balg * ncol,
+                "note": "fp64 instruction-issue bound, not HBM-bound (DESIGN.md section 6)", "issue": issue,
             },
         }
         if world == 1 and not a.no_cpu_baseline:
