@@ -19,6 +19,9 @@ __device__ __forceinline__ double dsign(double a, double b) { return __builtin_c
 __device__ __forceinline__ double bcast(double x, int src_lane) { return __shfl(x, src_lane, 64); }
 __device__ __forceinline__ double first_lane(double x)
 {
+#ifdef MCKPP_NO_FIRSTLANE
+  return x;
+#endif
   int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
   int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
   return __hiloint2double(hi, lo);
