@@ -264,5 +264,18 @@ __device__ __forceinline__ double swfrac_dev(double fact, double z, int jw)
   return rfac[jw] * mckpp_exp(r1) + (1. - rfac[jw]) * mckpp_exp(r2);
 }
 
+// The same value for a wave-uniform depth with the two bands evaluated side by side: even lanes
+// take the first band, odd lanes the second, so the exp polynomial is issued once instead of twice.
+__device__ __forceinline__ double swfrac_dev_wave(double fact, double z, int jw, int lane)
+{
+  const double rmin = -80.;
+  const bool second = (lane & 1) != 0;
+  const double a = second ? jer_a2_c[jw] : jer_a1_c[jw], ra = second ? jer_ra2_c[jw] : jer_ra1_c[jw];
+  const double e = mckpp_exp(dmax2(div_fast(z * fact, a, ra), rmin));
+  const double e1 = first_lane(e);
+  const double e2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(e), 1), __builtin_amdgcn_readlane(__double2loint(e), 1));
+  return jer_rfac_c[jw] * e1 + (1. - jer_rfac_c[jw]) * e2;
+}
+
 
 }  // namespace mckpp_dev

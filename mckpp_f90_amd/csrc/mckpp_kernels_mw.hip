@@ -328,7 +328,7 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
       }
     }
     const wscale_u wu = wscale_prepare_uniform(ustar);
-    double bfsfc = swfrac_dev(-1.0, hbl, jer);
+    double bfsfc = swfrac_dev_wave(-1.0, hbl, jer, lane);
     bfsfc = B0 + B0sol * (1. - bfsfc);
     const double stable = first_lane(0.5 + dsign(0.5, bfsfc));
     bfsfc = first_lane(bfsfc + stable * epsln16);

@@ -291,8 +291,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       }
       double zk = zm1, Uk = U1, Vk = V1, Bk = Bu1;
       for (int kl = 1; kl <= nz; ++kl) {
-        const double zk1 = first_lane(c_zm[kl + 1]), Uk1 = first_lane(aU[kl + 1]), Vk1 = first_lane(aV[kl + 1]),
-                     Bk1 = first_lane(aB[kl + 1]);
+        const double zk1 = c_zm[kl + 1], Uk1 = aU[kl + 1], Vk1 = aV[kl + 1], Bk1 = aB[kl + 1];   // LDS broadcasts
         bool any = false;
         FORJ {
           live[j] = live[j] && !(zref[j] >= zk);
@@ -539,7 +538,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
         }
       }
     }
-    double bfsfc = swfrac_dev(-1.0, hbl, jer);
+    double bfsfc = swfrac_dev_wave(-1.0, hbl, jer, lane);
     bfsfc = B0 + B0sol * (1. - bfsfc);
     const double stable = first_lane(0.5 + dsign(0.5, bfsfc));
     bfsfc = first_lane(bfsfc + stable * epsln16);
