@@ -12,7 +12,7 @@
 //
 // Results are bit-identical to k_column_wg / k_column and to the CPU oracle.
 // Default physics only (the optional-physics build stays on k_column_wg).
-#include "mckpp_colmath.h"
+#include "mckpp_sweeps.h"
 
 #include <cstdio>
 #include <type_traits>
@@ -22,8 +22,6 @@ namespace {
 
 using namespace mckpp_dev;
 
-enum { R_DM = 0, R_DT, R_DS, R_GH, R_YU, R_YT, R_YS, R_GM, R_GT, R_GS, R_BETM, R_YV, R_RB, R_COUNT };
-enum { R_U = R_YU, R_V = R_YT, R_B = R_YS, R_R = R_GM, R_DB = R_GT, R_DMO = R_GS, R_T = R_BETM };
 enum { S_EMPTY = 0, S_ACTIVE = 1, S_DONE = 2 };
 // per-slot double record
 enum { C_B0 = 0, C_WU01, C_WU02, C_WX01, C_WX02, C_WXNT0, C_UREFNZ, C_VREFNZ, C_RHO0CP0, C_RRC,
@@ -97,7 +95,7 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
 
   int state = S_EMPTY, col = 0;
   int old = 0, newi = 1, jer = 3, l_initflag = 0, status = 0, npass = 0, npass_try = 0, iconv = 0;
-  int comp_flag = 0, kmixe = 0, kmixn = 0, kbl_pass = 0, nreset = 0;
+  int comp_flag = 0, kmixn = 0, kbl_pass = 0, nreset = 0;
   // wave-uniform doubles every wave of a slot carries identically (no LDS hand-off, so no race)
   double f_col = 0, hmixe = 0, hmixn = 0, hbl_pass = 0;
   const double lambda = 0.5;
@@ -483,155 +481,10 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
   };
 
   // serial phases (identical to k_column_wg, rows are just longer)
-  auto scan_rib = [&]() {
-    if (wv == 0 && lane < W && sact[lane]) {
-      double *r = slots + lane * SS + R_R * NA;
-      double rb = 0.0;
-      int kq = 2;
-      for (; kq + 3 <= nz; kq += 4) {
-        const double a0 = r[kq], a1 = r[kq + 1], a2 = r[kq + 2], a3 = r[kq + 3];
-        rb = dmax2(a0, rb + epsln16); const double b0 = rb;
-        rb = dmax2(a1, rb + epsln16); const double b1 = rb;
-        rb = dmax2(a2, rb + epsln16); const double b2 = rb;
-        rb = dmax2(a3, rb + epsln16);
-        r[kq] = b0; r[kq + 1] = b1; r[kq + 2] = b2; r[kq + 3] = rb;
-      }
-      for (; kq <= nz; ++kq) {
-        rb = dmax2(r[kq], rb + epsln16);
-        r[kq] = rb;
-      }
-    }
-  };
-  auto thomas_uts = [&]() {
-    if (wv == 0 && lane < 3 * W) {
-      const int sl = lane / 3, sys = lane - 3 * sl;
-      if (sact[sl]) {
-        double *base = slots + sl * SS;
-        const double *d = base + (R_DM + sys) * NA;
-        double *y = base + (R_YU + sys) * NA, *gm = base + (R_GM + sys) * NA;
-        double *betm = base + R_BETM * NA, *rbm = base + R_RB * NA;
-        int bad = 0;
-        double dm1 = d[1], t1m1 = c_t1[1];
-        double bet = 1. + t1m1 * dm1;   // cc(1)
-        double ynum = y[1];             // y(1) = rhs(1)/bet, formed in the next level's step
-        // One level of the skewed sweep.  The serial wave shares its SIMD with four busy waves, so
-        // the sweep's time is its instruction count: the common case is one straight basic block
-        // (pivot chain bet -> 1/bet -> gam -> bet' interleaved with the solution chain, both on
-        // div_fast), and the two conditions that need other arithmetic - a zero pivot, or a tiny
-        // non-zero solution numerator that div_fast must not see - are detected at the end of the
-        // level before and sent through the slow copy of the step (IEEE sequences), practically never.
-        unsigned long long rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum));   // wave mask, lives in SGPRs
-        auto level = [&](int i, double di, double t0, double t1, double rhs, auto slow) {
-          if (slow.value && bet == 0.) { bad = 1; bet = 1.E-12; }   // solvers.F90:140-151 would stop here
-          const double clm1 = -t1m1 * dm1;
-          const double cu = -t0 * dm1;
-          const double cc = 1. + t1 * di + t0 * dm1;
-          const double rb = rcp_refine(bet);
-          const double g = slow.value ? div_by_refined(clm1, bet, rb) : div_fast(clm1, bet, rb);
-          const double yprev = slow.value ? div_by_refined(ynum, bet, rb) : div_fast(ynum, bet, rb);
-          if (sys == 0) { betm[i - 1] = bet; rbm[i - 1] = rb; }
-          y[i - 1] = yprev;
-          gm[i] = g;
-          bet = cc - cu * g;
-          ynum = rhs - cu * yprev;
-          rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum)) | __builtin_amdgcn_ballot_w64(bet == 0.);
-          dm1 = di; t1m1 = t1;
-        };
-        auto step = [&](int i, double di, double t0, double t1, double rhs) {
-          if (__builtin_expect(rare != 0ull, 0)) level(i, di, t0, t1, rhs, std::true_type{});
-          else level(i, di, t0, t1, rhs, std::false_type{});
-        };
-        {   // two levels per trip; each half's operands are fetched while the other half runs
-          int i = 2;
-          double a_d = d[2], a_t0 = c_t0[2], a_t1 = c_t1[2], a_r = y[2];
-          for (; i + 1 <= nz; i += 2) {
-            const double b_d = d[i + 1], b_t0 = c_t0[i + 1], b_t1 = c_t1[i + 1], b_r = y[i + 1];
-            step(i, a_d, a_t0, a_t1, a_r);
-            if (i + 2 <= nz) { a_d = d[i + 2]; a_t0 = c_t0[i + 2]; a_t1 = c_t1[i + 2]; a_r = y[i + 2]; }
-            step(i + 1, b_d, b_t0, b_t1, b_r);
-          }
-          if (i <= nz) step(i, a_d, a_t0, a_t1, a_r);
-        }
-        if (bet == 0.) { bad = 1; bet = 1.E-12; }
-        const double rbl = rcp_refine(bet);
-        double yy = div_by_refined(ynum, bet, rbl);
-        y[nz] = yy;
-        if (sys == 0) { betm[nz] = bet; rbm[nz] = rbl; }
-        // back substitution, operands fetched four levels ahead
-        int i = nz - 1;
-        for (; i >= 4; i -= 4) {
-          const double y0 = y[i], y1 = y[i - 1], y2 = y[i - 2], y3 = y[i - 3];
-          const double g0 = gm[i + 1], g1 = gm[i], g2 = gm[i - 1], g3 = gm[i - 2];
-          yy = y0 - g0 * yy; const double r0 = yy;
-          yy = y1 - g1 * yy; const double r1 = yy;
-          yy = y2 - g2 * yy; const double r2 = yy;
-          yy = y3 - g3 * yy;
-          y[i] = r0; y[i - 1] = r1; y[i - 2] = r2; y[i - 3] = yy;
-        }
-        for (; i >= 1; --i) {
-          yy = y[i] - gm[i + 1] * yy;
-          y[i] = yy;
-        }
-        if (bad) sbad[sl] = 1;
-      }
-    }
-  };
-  auto thomas_v = [&]() {   // V on the stored momentum factorisation (bet, refined 1/bet, gam)
-    if (wv == 0 && lane < W && sact[lane]) {
-      double *base = slots + lane * SS;
-      const double *d = base + R_DM * NA, *gm = base + R_GM * NA, *betm = base + R_BETM * NA,
-                   *rbm = base + R_RB * NA;
-      double *y = base + R_YV * NA;
-      double yy = div_by_refined(y[1], betm[1], rbm[1]);
-      y[1] = yy;
-      double dm1 = d[1];
-      // Here the quotient is the dependent chain itself, so it takes div_fast unconditionally; a tiny
-      // non-zero numerator is noticed at the end of its level and the quotient is redone (IEEE
-      // sequence) at the top of the next one, before anything has used it.  Two levels per trip.
-      double nprev = 0.0, bprev = 1.0;
-      unsigned long long rare = 0ull;   // wave mask of lanes whose last numerator was tiny
-      auto vstep = [&](int i, double rhs, double t0, double b, double r, double di) {
-        if (__builtin_expect(rare != 0ull, 0)) {
-          if (tiny_nonzero(nprev)) { yy = nprev / bprev; y[i - 1] = yy; }
-        }
-        const double cu = -t0 * dm1;
-        const double n = rhs - cu * yy;
-        yy = div_fast(n, b, r);
-        rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(n));
-        y[i] = yy;
-        nprev = n; bprev = b;
-        dm1 = di;
-      };
-      {
-        int i = 2;
-        double a_rhs = y[2], a_t0 = c_t0[2], a_b = betm[2], a_r = rbm[2], a_d = d[2];
-        for (; i + 1 <= nz; i += 2) {
-          const double b_rhs = y[i + 1], b_t0 = c_t0[i + 1], b_b = betm[i + 1], b_r = rbm[i + 1], b_d = d[i + 1];
-          vstep(i, a_rhs, a_t0, a_b, a_r, a_d);
-          if (i + 2 <= nz) { a_rhs = y[i + 2]; a_t0 = c_t0[i + 2]; a_b = betm[i + 2]; a_r = rbm[i + 2]; a_d = d[i + 2]; }
-          vstep(i + 1, b_rhs, b_t0, b_b, b_r, b_d);
-        }
-        if (i <= nz) vstep(i, a_rhs, a_t0, a_b, a_r, a_d);
-      }
-      if (__builtin_expect(rare != 0ull, 0)) {
-        if (tiny_nonzero(nprev)) { yy = nprev / bprev; y[nz] = yy; }
-      }
-      int i = nz - 1;
-      for (; i >= 4; i -= 4) {
-        const double y0 = y[i], y1 = y[i - 1], y2 = y[i - 2], y3 = y[i - 3];
-        const double g0 = gm[i + 1], g1 = gm[i], g2 = gm[i - 1], g3 = gm[i - 2];
-        yy = y0 - g0 * yy; const double r0 = yy;
-        yy = y1 - g1 * yy; const double r1 = yy;
-        yy = y2 - g2 * yy; const double r2 = yy;
-        yy = y3 - g3 * yy;
-        y[i] = r0; y[i - 1] = r1; y[i - 2] = r2; y[i - 3] = yy;
-      }
-      for (; i >= 1; --i) {
-        yy = y[i] - gm[i + 1] * yy;
-        y[i] = yy;
-      }
-    }
-  };
+  // ---- serial phases (mckpp_sweeps.h), run by one wave for all slots of the workgroup ----
+  auto scan_rib = [&]() { if (wv == 0) serial_scan_rib<W>(slots, SS, NA, nz, sact, lane); };
+  auto thomas_uts = [&]() { if (wv == 0) serial_thomas_uts<W>(slots, SS, NA, nz, c_t0, c_t1, sact, sbad, lane); };
+  auto thomas_v = [&]() { if (wv == 0) serial_thomas_v<W>(slots, SS, NA, nz, c_t0, sact, lane); };
 
   // ---- ocnstep control after a pass (ocnstep_mod.F90:122-192); every wave of the slot
   // takes the same decision from the same replicated values
@@ -643,7 +496,7 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     ++npass;
     if (p.mode != MCKPP_MODE_STEP) { fin = F_FINAL; return; }
     ++npass_try;
-    if (npass_try <= 3) { hmixe = hbl_pass; kmixe = kbl_pass; return; }   // compulsory passes
+    if (npass_try <= 3) { hmixe = hbl_pass; return; }   // compulsory passes
     hmixn = hbl_pass;
     kmixn = kbl_pass;
     double tol = p.hmixtolfrac * c_hm[kmixn];
@@ -651,8 +504,8 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     if (__builtin_fabs(hmixn - hmixe) > tol) iconv = 0;
     else iconv = iconv + 1;
     if (iconv < 3) {
-      if (npass_try < p.itermax) { hmixe = hmixn; kmixe = kmixn; return; }
-      else if (hmixn > hmixe) { hmixe = hmixn; kmixe = kmixn; return; }
+      if (npass_try < p.itermax) { hmixe = hmixn; return; }
+      else if (hmixn > hmixe) { hmixe = hmixn; return; }
     }
     if (npass_try > (p.itermax + 1)) status |= 2;
     fin = F_TRAP;

@@ -1,0 +1,187 @@
+// mckpp_sweeps.h - the serial recurrences of a vmix + ocnint pass, shared by the cooperative
+// column kernels (mckpp_kernels_wg.hip, mckpp_kernels_mw.hip).
+//
+// After a workgroup barrier ONE wave runs these for all W column slots of its workgroup with a
+// lane per (slot[, system]): the recurrences stay serial and bit-faithful, but their instruction
+// stream is paid once per workgroup instead of once per column.  The rows live in the slots'
+// LDS blocks: slot s starts at slots + s*SS, row r at + r*NA, element k at + k (reference index).
+#ifndef MCKPP_SWEEPS_H
+#define MCKPP_SWEEPS_H
+#include "mckpp_colmath.h"
+
+#include <type_traits>
+
+namespace mckpp_dev {
+
+// per-slot LDS rows common to both kernels (each NA doubles)
+enum { R_DM = 0, R_DT, R_DS, R_GH, R_YU, R_YT, R_YS, R_GM, R_GT, R_GS, R_BETM, R_YV, R_RB, R_COUNT };
+// vmix scratch aliases (dead before the Thomas rows are built)
+enum { R_U = R_YU, R_V = R_YT, R_B = R_YS, R_R = R_GM, R_DB = R_GT, R_DMO = R_GS, R_T = R_BETM };
+
+// Rib(ku) = MAX(Rib(ku), Rib(ka)+epsln), bldepth_mod.F90:137; W lanes
+template <int W>
+__device__ __forceinline__ void serial_scan_rib(double *slots, int SS, int NA, int nz, const int *sact, int lane)
+{
+  const double epsln16 = 1.e-16;
+  if (lane < W && sact[lane]) {
+    double *r = slots + lane * SS + R_R * NA;
+    double rb = 0.0;
+    int k = 2;
+    for (; k + 3 <= nz; k += 4) {
+      const double a0 = r[k], a1 = r[k + 1], a2 = r[k + 2], a3 = r[k + 3];
+      rb = dmax2(a0, rb + epsln16); const double b0 = rb;
+      rb = dmax2(a1, rb + epsln16); const double b1 = rb;
+      rb = dmax2(a2, rb + epsln16); const double b2 = rb;
+      rb = dmax2(a3, rb + epsln16);
+      r[k] = b0; r[k + 1] = b1; r[k + 2] = b2; r[k + 3] = rb;
+    }
+    for (; k <= nz; ++k) {
+      rb = dmax2(r[k], rb + epsln16);
+      r[k] = rb;
+    }
+  }
+}
+
+// tridcof + tridmat (solvers.F90:14-44, 112-161), skewed by one level: iteration i forms
+// gam(i) = cl(i-1)/bet(i-1) and y(i-1) = num(i-1)/bet(i-1) over the same denominator.  3W lanes
+template <int W>
+__device__ __forceinline__ void serial_thomas_uts(double *slots, int SS, int NA, int nz, const double *c_t0,
+                                                  const double *c_t1, const int *sact, int *sbad, int lane)
+{
+  if (lane < 3 * W) {
+    const int sl = lane / 3, sys = lane - 3 * sl;
+    if (sact[sl]) {
+      double *base = slots + sl * SS;
+      const double *d = base + (R_DM + sys) * NA;
+      double *y = base + (R_YU + sys) * NA, *gm = base + (R_GM + sys) * NA;
+      double *betm = base + R_BETM * NA, *rbm = base + R_RB * NA;
+      int bad = 0;
+      double dm1 = d[1], t1m1 = c_t1[1];
+      double bet = 1. + t1m1 * dm1;   // cc(1)
+      double ynum = y[1];             // y(1) = rhs(1)/bet, formed in the next level's step
+      // One level of the skewed sweep.  The serial wave shares its SIMD with four busy waves, so
+      // the sweep's time is its instruction count: the common case is one straight basic block
+      // (pivot chain bet -> 1/bet -> gam -> bet' interleaved with the solution chain, both on
+      // div_fast), and the two conditions that need other arithmetic - a zero pivot, or a tiny
+      // non-zero solution numerator that div_fast must not see - are detected at the end of the
+      // level before and sent through the slow copy of the step (IEEE sequences), practically never.
+      unsigned long long rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum));   // wave mask, lives in SGPRs
+      auto level = [&](int i, double di, double t0, double t1, double rhs, auto slow) {
+        if (slow.value && bet == 0.) { bad = 1; bet = 1.E-12; }   // solvers.F90:140-151 would stop here
+        const double clm1 = -t1m1 * dm1;
+        const double cu = -t0 * dm1;
+        const double cc = 1. + t1 * di + t0 * dm1;
+        const double rb = rcp_refine(bet);
+        const double g = slow.value ? div_by_refined(clm1, bet, rb) : div_fast(clm1, bet, rb);
+        const double yprev = slow.value ? div_by_refined(ynum, bet, rb) : div_fast(ynum, bet, rb);
+        if (sys == 0) { betm[i - 1] = bet; rbm[i - 1] = rb; }
+        y[i - 1] = yprev;
+        gm[i] = g;
+        bet = cc - cu * g;
+        ynum = rhs - cu * yprev;
+        rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum)) | __builtin_amdgcn_ballot_w64(bet == 0.);
+        dm1 = di; t1m1 = t1;
+      };
+      auto step = [&](int i, double di, double t0, double t1, double rhs) {
+        if (__builtin_expect(rare != 0ull, 0)) level(i, di, t0, t1, rhs, std::true_type{});
+        else level(i, di, t0, t1, rhs, std::false_type{});
+      };
+      {   // two levels per trip; each half's operands are fetched while the other half runs
+        int i = 2;
+        double a_d = d[2], a_t0 = c_t0[2], a_t1 = c_t1[2], a_r = y[2];
+        for (; i + 1 <= nz; i += 2) {
+          const double b_d = d[i + 1], b_t0 = c_t0[i + 1], b_t1 = c_t1[i + 1], b_r = y[i + 1];
+          step(i, a_d, a_t0, a_t1, a_r);
+          if (i + 2 <= nz) { a_d = d[i + 2]; a_t0 = c_t0[i + 2]; a_t1 = c_t1[i + 2]; a_r = y[i + 2]; }
+          step(i + 1, b_d, b_t0, b_t1, b_r);
+        }
+        if (i <= nz) step(i, a_d, a_t0, a_t1, a_r);
+      }
+      if (bet == 0.) { bad = 1; bet = 1.E-12; }
+      const double rbl = rcp_refine(bet);
+      double yy = div_by_refined(ynum, bet, rbl);
+      y[nz] = yy;
+      if (sys == 0) { betm[nz] = bet; rbm[nz] = rbl; }
+      // back substitution, operands fetched four levels ahead
+      int i = nz - 1;
+      for (; i >= 4; i -= 4) {
+        const double y0 = y[i], y1 = y[i - 1], y2 = y[i - 2], y3 = y[i - 3];
+        const double g0 = gm[i + 1], g1 = gm[i], g2 = gm[i - 1], g3 = gm[i - 2];
+        yy = y0 - g0 * yy; const double r0 = yy;
+        yy = y1 - g1 * yy; const double r1 = yy;
+        yy = y2 - g2 * yy; const double r2 = yy;
+        yy = y3 - g3 * yy;
+        y[i] = r0; y[i - 1] = r1; y[i - 2] = r2; y[i - 3] = yy;
+      }
+      for (; i >= 1; --i) {
+        yy = y[i] - gm[i + 1] * yy;
+        y[i] = yy;
+      }
+      if (bad) sbad[sl] = 1;
+    }
+  }
+}
+
+// V on the stored momentum factorisation (bet, refined 1/bet, gam); W lanes
+template <int W>
+__device__ __forceinline__ void serial_thomas_v(double *slots, int SS, int NA, int nz, const double *c_t0,
+                                                const int *sact, int lane)
+{
+  if (lane < W && sact[lane]) {
+    double *base = slots + lane * SS;
+    const double *d = base + R_DM * NA, *gm = base + R_GM * NA, *betm = base + R_BETM * NA,
+                 *rbm = base + R_RB * NA;
+    double *y = base + R_YV * NA;
+    double yy = div_by_refined(y[1], betm[1], rbm[1]);
+    y[1] = yy;
+    double dm1 = d[1];
+    // Here the quotient is the dependent chain itself, so it takes div_fast unconditionally; a tiny
+    // non-zero numerator is noticed at the end of its level and the quotient is redone (IEEE
+    // sequence) at the top of the next one, before anything has used it.  Two levels per trip.
+    double nprev = 0.0, bprev = 1.0;
+    unsigned long long rare = 0ull;   // wave mask of lanes whose last numerator was tiny
+    auto vstep = [&](int i, double rhs, double t0, double b, double r, double di) {
+      if (__builtin_expect(rare != 0ull, 0)) {
+        if (tiny_nonzero(nprev)) { yy = nprev / bprev; y[i - 1] = yy; }
+      }
+      const double cu = -t0 * dm1;
+      const double n = rhs - cu * yy;
+      yy = div_fast(n, b, r);
+      rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(n));
+      y[i] = yy;
+      nprev = n; bprev = b;
+      dm1 = di;
+    };
+    {
+      int i = 2;
+      double a_rhs = y[2], a_t0 = c_t0[2], a_b = betm[2], a_r = rbm[2], a_d = d[2];
+      for (; i + 1 <= nz; i += 2) {
+        const double b_rhs = y[i + 1], b_t0 = c_t0[i + 1], b_b = betm[i + 1], b_r = rbm[i + 1], b_d = d[i + 1];
+        vstep(i, a_rhs, a_t0, a_b, a_r, a_d);
+        if (i + 2 <= nz) { a_rhs = y[i + 2]; a_t0 = c_t0[i + 2]; a_b = betm[i + 2]; a_r = rbm[i + 2]; a_d = d[i + 2]; }
+        vstep(i + 1, b_rhs, b_t0, b_b, b_r, b_d);
+      }
+      if (i <= nz) vstep(i, a_rhs, a_t0, a_b, a_r, a_d);
+    }
+    if (__builtin_expect(rare != 0ull, 0)) {
+      if (tiny_nonzero(nprev)) { yy = nprev / bprev; y[nz] = yy; }
+    }
+    int i = nz - 1;
+    for (; i >= 4; i -= 4) {
+      const double y0 = y[i], y1 = y[i - 1], y2 = y[i - 2], y3 = y[i - 3];
+      const double g0 = gm[i + 1], g1 = gm[i], g2 = gm[i - 1], g3 = gm[i - 2];
+      yy = y0 - g0 * yy; const double r0 = yy;
+      yy = y1 - g1 * yy; const double r1 = yy;
+      yy = y2 - g2 * yy; const double r2 = yy;
+      yy = y3 - g3 * yy;
+      y[i] = r0; y[i - 1] = r1; y[i - 2] = r2; y[i - 3] = yy;
+    }
+    for (; i >= 1; --i) {
+      yy = y[i] - gm[i + 1] * yy;
+      y[i] = yy;
+    }
+  }
+}
+
+}  // namespace mckpp_dev
+#endif
