@@ -160,6 +160,21 @@ int mckpp_hip_fluxes(mckpp_hip_handle h, int ntime, const double *taux, const do
                      const double *swf, const double *lwf, const double *lhf, const double *shf,
                      const double *rain, const double *snow, int l_rest, double flsn, double el);
 
+/* Forced runs without per-step host traffic.  mckpp_hip_set_flux_series keeps `nrec`
+ * successive records of the eight surface forcing fields on the device (layout
+ * fields[rec][8][npts], field order and meaning as mckpp_hip_fluxes: what
+ * kpp_3d_fields%taux..snow hold after the reference's flux reader at each
+ * update); record 0 of the array is flux update number `rec0` of the run.
+ * mckpp_hip_run_forced then is the reference's time loop without output
+ * (src/mckpp_ocean_model_3D.F90:38-58): for nt = nt_first .. nt_first+nsteps-1
+ *   IF (MOD(nt-1, ndtocn) == 0) mckpp_fluxes with record (nt-1)/ndtocn
+ *   mckpp_physics_driver
+ * all on the context's stream; it fails before launching anything if a needed
+ * record is not resident.  l_rest, flsn, el as for mckpp_hip_fluxes. */
+int mckpp_hip_set_flux_series(mckpp_hip_handle h, int rec0, int nrec, const double *fields);
+int mckpp_hip_run_forced(mckpp_hip_handle h, int nt_first, int nsteps, int ndtocn, int l_rest,
+                         double flsn, double el);
+
 /* mckpp_physics_overrides_bottomtemp (src/mckpp_physics_overrides.F90:12-24),
  * which mckpp_physics_driver calls after the column loop when
  * kpp_const_fields%L_VARY_BOTTOM_TEMP (src/mckpp_physics_driver_mod.F90:67-71):

@@ -98,6 +98,8 @@ def _bind(lib):
     lib.mckpp_hip_load_restart.argtypes = [C.c_void_p, C.c_char_p]
     lib.mckpp_hip_fluxes.argtypes = [C.c_void_p, C.c_int] + [_dp] * 8 + [C.c_int, C.c_double, C.c_double]
     lib.mckpp_hip_bottomtemp.argtypes = [C.c_void_p, _dp]
+    lib.mckpp_hip_set_flux_series.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
+    lib.mckpp_hip_run_forced.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
     lib.mckpp_hip_init_ocean.argtypes = [C.c_void_p, C.c_int]
     lib.mckpp_hip_step.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.mckpp_hip_vmix_pass.argtypes = [C.c_void_p, C.c_int]
@@ -279,6 +281,16 @@ class MckppHip:
         arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (taux, tauy, swf, lwf, lhf, shf, rain, snow)]
         _chk(_lib().mckpp_hip_fluxes(self._h, int(ntime), *[a.ctypes.data_as(_dp) for a in arrs], int(l_rest),
                                      float(flsn), float(el)))
+
+    def set_flux_series(self, rec0, fields):
+        """fields[nrec, 8, npts]: taux, tauy, swf, lwf, lhf, shf, rain, snow at successive flux updates."""
+        f = np.ascontiguousarray(fields, dtype=np.float64)
+        assert f.ndim == 3 and f.shape[1] == 8 and f.shape[2] == self._npts_cache
+        _chk(_lib().mckpp_hip_set_flux_series(self._h, int(rec0), int(f.shape[0]), f.ctypes.data_as(_dp)))
+
+    def run_forced(self, nt_first, nsteps, ndtocn, l_rest=0, flsn=334000.0, el=2.5e6):
+        _chk(_lib().mckpp_hip_run_forced(self._h, int(nt_first), int(nsteps), int(ndtocn), int(l_rest),
+                                         float(flsn), float(el)))
 
     def bottomtemp(self, bottom_temp):
         bt = np.ascontiguousarray(bottom_temp, dtype=np.float64)

@@ -86,6 +86,8 @@ struct mckpp_hip_ctx {
   unsigned long long *d_dbg = nullptr;
   mckpp_kparams *d_params = nullptr;   // device copy of the kernel parameter block
   int num_cu = 256;
+  double *d_series = nullptr;   // [nrec][8][ncol] forcing records (mckpp_hip_set_flux_series)
+  int series_rec0 = 0, series_nrec = 0;
   int kernel_variant = 2;   // 2: cooperative workgroup kernel, 1: one wave per column (MCKPP_KERNEL=v1)
   double *d_stage = nullptr;
   size_t stage_elems = 0;
@@ -277,6 +279,8 @@ static void free_state(mckpp_hip_ctx *h)
   if (h->d_adv_d) hipFree(h->d_adv_d);
   if (h->d_adv_i) hipFree(h->d_adv_i);
   h->d_xs = nullptr; h->d_adv_d = nullptr; h->d_adv_i = nullptr;
+  if (h->d_series) hipFree(h->d_series);
+  h->d_series = nullptr; h->series_nrec = 0;
   if (h->d_wacc) hipFree(h->d_wacc);
   if (h->d_whacc) hipFree(h->d_whacc);
   h->d_wacc = nullptr; h->d_whacc = nullptr; h->window_count = 0;
@@ -576,7 +580,9 @@ static void fill_params(mckpp_hip_ctx *h, mckpp_kparams &p, int ntime, int mode)
   p.Rig = h->d_diag[D_RIG]; p.dbloc = h->d_diag[D_DBLOC]; p.Shsq = h->d_diag[D_SHSQ];
 }
 
-static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode)
+struct forced_run { int ndtocn, l_rest; double flsn, el; };
+
+static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode, const forced_run *forced = nullptr)
 {
   if (!h) return fail("null handle");
   if (h->ncol == 0) { h->nlaunch = 0; h->timed = false; return 0; }
@@ -591,6 +597,11 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode)
   for (int i = 0; i < nsteps; ++i) {
     mckpp_kparams p;
     fill_params(h, p, ntime + i, mode);
+    if (forced && (ntime + i - 1) % forced->ndtocn == 0) {   // ocean_model_3D.F90:44-48
+      const int rec = (ntime + i - 1) / forced->ndtocn - h->series_rec0;
+      HIPCHK(mckpp_launch_fluxes(p, ntime + i, h->d_series + (size_t)rec * 8 * (size_t)h->ncol, forced->l_rest,
+                                 forced->flsn, forced->el, h->stream));
+    }
     if (h->kernel_variant == 1) {
       HIPCHK(mckpp_launch_column_kernel(p, h->stream));
     } else {
@@ -612,6 +623,45 @@ int mckpp_hip_step(mckpp_hip_handle h, int ntime, int nsteps)
   return run(h, ntime, nsteps, MCKPP_MODE_STEP);
 }
 int mckpp_hip_vmix_pass(mckpp_hip_handle h, int ntime) { return run(h, ntime, 1, MCKPP_MODE_PASS); }
+
+int mckpp_hip_set_flux_series(mckpp_hip_handle h, int rec0, int nrec, const double *fields)
+{
+  if (!h || !fields) return fail("mckpp_hip_set_flux_series: null argument");
+  if (nrec < 1 || rec0 < 0) return fail("mckpp_hip_set_flux_series: rec0=%d nrec=%d", rec0, nrec);
+  if (!h->ipt.size() && h->ncol) return fail("mckpp_hip_set_flux_series: upload the state first");
+  HIPCHK(hipSetDevice(h->device));
+  if (h->d_series) { HIPCHK(hipFree(h->d_series)); h->d_series = nullptr; h->series_nrec = 0; }
+  h->series_rec0 = rec0;
+  h->series_nrec = nrec;
+  if (h->ncol == 0) return 0;
+  const size_t n = (size_t)nrec * 8 * (size_t)h->ncol;
+  std::vector<double> f(n);
+  for (int r = 0; r < nrec; ++r)
+    for (int m = 0; m < 8; ++m) {
+      const double *src = fields + ((size_t)r * 8 + m) * (size_t)h->npts;
+      double *dst = f.data() + ((size_t)r * 8 + m) * (size_t)h->ncol;
+      for (int64_t c = 0; c < h->ncol; ++c) dst[c] = src[h->ipt[c]];
+    }
+  HIPCHK(hipMalloc(&h->d_series, n * sizeof(double)));
+  HIPCHK(hipMemcpy(h->d_series, f.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int mckpp_hip_run_forced(mckpp_hip_handle h, int nt_first, int nsteps, int ndtocn, int l_rest, double flsn, double el)
+{
+  if (!h) return fail("null handle");
+  if (nt_first < 1 || nsteps < 0 || ndtocn < 1)
+    return fail("mckpp_hip_run_forced: nt_first=%d nsteps=%d ndtocn=%d", nt_first, nsteps, ndtocn);
+  if (nsteps == 0) return 0;
+  // every flux update of the span must be resident before anything is launched
+  const int first_upd = (nt_first - 1 + ndtocn - 1) / ndtocn, last_upd = (nt_first + nsteps - 2) / ndtocn;
+  if (first_upd <= last_upd &&
+      (h->series_nrec == 0 || first_upd < h->series_rec0 || last_upd >= h->series_rec0 + h->series_nrec))
+    return fail("mckpp_hip_run_forced: steps %d..%d need flux records %d..%d, resident are %d..%d", nt_first,
+                nt_first + nsteps - 1, first_upd, last_upd, h->series_rec0, h->series_rec0 + h->series_nrec - 1);
+  const forced_run fr{ndtocn, l_rest, flsn, el};
+  return run(h, nt_first, nsteps, MCKPP_MODE_STEP, &fr);
+}
 
 int mckpp_hip_synchronize(mckpp_hip_handle h)
 {

@@ -91,6 +91,21 @@ module mckpp_hip_binding
       real(c_double), value :: flsn, el
       integer(c_int) :: rc
     end function
+    function mckpp_hip_set_flux_series(handle, rec0, nrec, fields) bind(C, name="mckpp_hip_set_flux_series") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: handle
+      integer(c_int), value :: rec0, nrec
+      real(c_double), intent(in) :: fields(*)
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_run_forced(handle, nt_first, nsteps, ndtocn, l_rest, flsn, el) &
+        bind(C, name="mckpp_hip_run_forced") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: handle
+      integer(c_int), value :: nt_first, nsteps, ndtocn, l_rest
+      real(c_double), value :: flsn, el
+      integer(c_int) :: rc
+    end function
     function mckpp_hip_bottomtemp(handle, bottom_temp) bind(C, name="mckpp_hip_bottomtemp") result(rc)
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: handle

@@ -611,3 +611,47 @@ def test_tiny_and_denormal_velocities_take_the_ieee_paths(mk, kernel_env, varian
         _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS), f"tiny {variant} nz={nz} step {nt}")
     u = np.abs(k3.U[:, :, 0])
     assert np.any((u > 0) & (u < 1e-292))     # the guarded range was really exercised
+
+
+@pytest.mark.parametrize("nz,ndtocn", [(40, 1), (60, 3), (69, 2)])
+def test_forced_run_from_resident_flux_series(mk, nz, ndtocn):
+    """mckpp_hip_run_forced: the reference's time loop (src/mckpp_ocean_model_3D.F90:38-58 - mckpp_fluxes
+    every ndtocn steps, then mckpp_physics_driver) from flux records kept on the device, with no host
+    traffic between steps.  Must equal the oracle driven the same way, including a start in the middle
+    of a forcing interval, and must refuse a span whose records are not resident."""
+    from oracle import orc
+
+    ncol, nsteps = 130, 7
+    oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1)
+    kc, k3 = cm.make_hip_case(ncol, nz, land_every=9)
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    orc.init_ocean(oc, ob, 0)
+    active = np.nonzero(k3.run_physics)[0]
+    rng = np.random.default_rng(7)
+    nrec = (nsteps + ndtocn - 1) // ndtocn
+    series = np.empty((nrec, 8, ncol))
+    for r in range(nrec):
+        day = max(0.0, np.sin(2 * np.pi * (r * ndtocn) / 24.0))
+        series[r] = [rng.uniform(-0.2, 0.3, ncol), rng.uniform(-0.1, 0.1, ncol), 800.0 * day * np.ones(ncol),
+                     rng.uniform(-80, -20, ncol), rng.uniform(-300, 0, ncol), rng.uniform(-40, 10, ncol),
+                     rng.uniform(0, 1e-4, ncol), np.zeros(ncol)]
+    names = ("taux", "tauy", "swf", "lwf", "lhf", "shf", "rain", "snow")
+    ctx.set_flux_series(0, series)
+    first = 3                                  # steps 1..3, then 4..7: the second call starts mid-interval
+    ctx.run_forced(1, first, ndtocn)
+    ctx.run_forced(first + 1, nsteps - first, ndtocn)
+    ctx.download(k3)
+    for nt in range(1, nsteps + 1):
+        if (nt - 1) % ndtocn == 0:
+            orc.fluxes(oc, ob, nt, **dict(zip(names, series[(nt - 1) // ndtocn])))
+        orc.physics_driver(oc, ob, nt)
+    st, nf, npass = ctx.status()
+    assert np.array_equal(st[active], ob["status"][active]) and np.array_equal(npass[active], ob["npasses"][active])
+    assert np.array_equal(k3.sflux[active, 0:6, 4, 0], ob["sflux"][active])
+    _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS, active), f"forced run nz={nz} ndtocn={ndtocn}")
+    # records beyond the resident window
+    with pytest.raises(mk.MckppHipError):
+        ctx.run_forced(nsteps + 1, 2 * ndtocn + 1, ndtocn)
+    ctx.set_flux_series(5, series[:1])
+    with pytest.raises(mk.MckppHipError):
+        ctx.run_forced(1, 1, ndtocn)
