@@ -249,6 +249,10 @@ int mckpp_hip_eos_batch(mckpp_hip_handle h, int64_t n, const double *s,
                         const double *t, const double *p, double *alpha,
                         double *beta, double *sig0, double *cp);
 int mckpp_hip_exp_batch(mckpp_hip_handle h, int64_t n, const double *x, double *y);
+/* The kernels' exact-division helpers on n operand pairs: q4[0..n) = div_fast,
+ * q4[n..2n) = div_fast_guarded, q4[2n..3n) = div_by_refined, q4[3n..4n) = the
+ * compiler's IEEE n/d (csrc/mckpp_colmath.h); for the tests. */
+int mckpp_hip_div_batch(mckpp_hip_handle h, int64_t n, const double *num, const double *den, double *q4);
 
 #ifdef __cplusplus
 }

@@ -113,6 +113,7 @@ def _bind(lib):
     lib.mckpp_hip_ncolumns.restype = C.c_int64
     lib.mckpp_hip_eos_batch.argtypes = [C.c_void_p, C.c_int64] + [_dp] * 7
     lib.mckpp_hip_exp_batch.argtypes = [C.c_void_p, C.c_int64, _dp, _dp]
+    lib.mckpp_hip_div_batch.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp]
     lib._mckpp_bound = True
     return lib
 
@@ -365,6 +366,13 @@ class MckppHip:
         _chk(_lib().mckpp_hip_eos_batch(self._h, n, *[np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(_dp) for a in (s, t, p)],
                                         *[o.ctypes.data_as(_dp) for o in out]))
         return out
+
+    def div_batch(self, num, den):
+        num = np.ascontiguousarray(num, dtype=np.float64)
+        den = np.ascontiguousarray(den, dtype=np.float64)
+        q = np.zeros((4, len(num)))
+        _chk(_lib().mckpp_hip_div_batch(self._h, len(num), num.ctypes.data_as(_dp), den.ctypes.data_as(_dp), q.ctypes.data_as(_dp)))
+        return q
 
     def exp_batch(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)

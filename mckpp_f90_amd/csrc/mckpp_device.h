@@ -79,6 +79,7 @@ hipError_t mckpp_launch_column_kernel_mw(const mckpp_kparams &p, const mckpp_kpa
 hipError_t mckpp_launch_eos_batch(int64_t n, const double *s, const double *t, const double *p,
                                   double *alpha, double *beta, double *sig0, double *cp,
                                   hipStream_t stream);
+hipError_t mckpp_launch_div_batch(int64_t n, const double *num, const double *den, double *q, hipStream_t stream);
 hipError_t mckpp_launch_exp_batch(int64_t n, const double *x, double *y, hipStream_t stream);
 hipError_t mckpp_launch_bottomtemp(const mckpp_kparams &p, const double *bt, hipStream_t stream);
 hipError_t mckpp_launch_fluxes(const mckpp_kparams &p, int ntime, const double *f8, int l_rest, double flsn,

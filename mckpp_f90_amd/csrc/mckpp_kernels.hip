@@ -797,6 +797,19 @@ __global__ void k_eos_batch(int64_t n, const double *s, const double *t, const d
   cp[i] = cpsw_dev(s[i], t[i], p[i]);
 }
 
+// the exact-division helpers of mckpp_colmath.h, one quotient per thread:
+// q[0] = div_fast, q[1] = div_fast_guarded, q[2] = div_by_refined, q[3] = the compiler's n / d
+__global__ void k_div_batch(int64_t n, const double *num, const double *den, double *q)
+{
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double a = num[i], d = den[i], r = rcp_refine(d);
+  q[i] = div_fast(a, d, r);
+  q[n + i] = div_fast_guarded(a, d, r);
+  q[2 * n + i] = div_by_refined(a, d, r);
+  q[3 * n + i] = a / d;
+}
+
 __global__ void k_exp_batch(int64_t n, const double *x, double *y)
 {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -981,6 +994,12 @@ hipError_t mckpp_launch_eos_batch(int64_t n, const double *s, const double *t, c
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_eos_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, s, t, p,
                      alpha, beta, sig0, cp);
+  return hipGetLastError();
+}
+
+hipError_t mckpp_launch_div_batch(int64_t n, const double *num, const double *den, double *q, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_div_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, num, den, q);
   return hipGetLastError();
 }
 

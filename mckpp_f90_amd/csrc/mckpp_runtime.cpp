@@ -1015,6 +1015,24 @@ int mckpp_hip_eos_batch(mckpp_hip_handle h, int64_t n, const double *s, const do
   return 0;
 }
 
+int mckpp_hip_div_batch(mckpp_hip_handle h, int64_t n, const double *num, const double *den, double *q4)
+{
+  if (!h) return fail("null handle");
+  if (n <= 0) return 0;
+  HIPCHK(hipSetDevice(h->device));
+  double *d = nullptr;
+  const size_t nb = (size_t)n * sizeof(double);
+  HIPCHK(hipMalloc(&d, 6 * nb));
+  hipError_t e = hipMemcpy(d, num, nb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + n, den, nb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = mckpp_launch_div_batch(n, d, d + n, d + 2 * n, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipMemcpy(q4, d + 2 * n, 4 * nb, hipMemcpyDeviceToHost);
+  hipFree(d);
+  HIPCHK(e);
+  return 0;
+}
+
 int mckpp_hip_exp_batch(mckpp_hip_handle h, int64_t n, const double *x, double *y)
 {
   if (!h) return fail("null handle");

@@ -655,3 +655,58 @@ def test_forced_run_from_resident_flux_series(mk, nz, ndtocn):
     ctx.set_flux_series(5, series[:1])
     with pytest.raises(mk.MckppHipError):
         ctx.run_forced(1, 1, ndtocn)
+
+
+def test_exact_division_helpers_against_ieee(mk):
+    """csrc/mckpp_colmath.h: div_fast (no operand rescaling) must return the IEEE quotient wherever the
+    kernels use it - normal denominators, numerators zero or >= 2^-960 in magnitude - including signed
+    zeros, infinities and NaN; div_fast_guarded and div_by_refined must return it for every operand
+    pair, denormals and extreme exponent gaps included.  The reference quotient is numpy's (the host
+    CPU's IEEE division); the compiler's own device n/d is checked against it too."""
+    kc = mk.KppConstFields(40)
+    mk.mckpp_physics_lookup(kc)
+    ctx = mk.MckppHip(kc)
+    rng = np.random.default_rng(99)
+    n = 1_000_000
+
+    def bits(x):
+        return np.ascontiguousarray(x).view(np.int64)
+
+    def same(a, b):   # bitwise, any NaN equal to any NaN
+        return np.all((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b)))
+
+    # 1. the ranges div_fast is used on: 52 random mantissa bits, exponents within +-300 of each other
+    num = np.ldexp(rng.uniform(1, 2, n), rng.integers(-300, 300, n)) * rng.choice([-1.0, 1.0], n)
+    den = np.ldexp(rng.uniform(1, 2, n), rng.integers(-300, 300, n)) * rng.choice([-1.0, 1.0], n)
+    num[:1000] = 0.0
+    num[1000:2000] = -0.0
+    num[2000:2100] = np.inf
+    num[2100:2200] = -np.inf
+    num[2200:2300] = np.nan
+    with np.errstate(all="ignore"):
+        ref = num / den
+    q = ctx.div_batch(num, den)
+    for i, name in enumerate(("div_fast", "div_fast_guarded", "div_by_refined", "device n/d")):
+        assert same(q[i], ref), name
+    # 2. hard cases for the final rounding: quotients of neighbouring doubles and near-ties
+    base = rng.uniform(1, 2, n)
+    num2 = np.nextafter(base, 3.0) * rng.integers(1, 1 << 20, n)
+    den2 = base * rng.integers(1, 1 << 20, n)
+    q = ctx.div_batch(num2, den2)
+    for i in range(4):
+        assert same(q[i], num2 / den2), i
+    # 3. everything, for the guarded / robust forms: tiny and denormal numerators, denormal and huge
+    #    denominators, zero denominators, exponent gaps beyond 768
+    num3 = np.ldexp(rng.uniform(1, 2, n), rng.integers(-1074, 1023, n)) * rng.choice([-1.0, 1.0], n)
+    den3 = np.ldexp(rng.uniform(1, 2, n), rng.integers(-1074, 1023, n)) * rng.choice([-1.0, 1.0], n)
+    den3[:500] = 0.0
+    num3[:250] = 0.0
+    with np.errstate(all="ignore"):
+        ref3 = num3 / den3
+    q = ctx.div_batch(num3, den3)
+    assert same(q[2], ref3), "div_by_refined, full range"
+    assert same(q[3], ref3), "device n/d, full range"
+    tame_den = (np.abs(den3) > 2.0 ** -1000) & (np.abs(den3) < 2.0 ** 1000) & \
+               (np.abs(np.log2(np.abs(num3) + 1e-320) - np.log2(np.abs(den3) + 1e-320)) < 700)
+    assert same(q[1][tame_den], ref3[tame_den]), "div_fast_guarded, tame denominators and any numerator"
+    ctx.close()
