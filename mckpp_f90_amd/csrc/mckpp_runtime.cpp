@@ -380,6 +380,11 @@ int mckpp_hip_upload(mckpp_hip_handle h, const mckpp_state_ptrs_c *s)
       }
     }
   }
+  if (ipt != h->ipt && h->d_series) {   // resident flux records were compacted with the previous land mask
+    hipFree(h->d_series);
+    h->d_series = nullptr;
+    h->series_nrec = 0;
+  }
   h->ipt = ipt;
   if (ncol == 0) return 0;
   HIPCHK(hipMemcpyAsync(h->d_ipt, ipt.data(), (size_t)ncol * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -628,7 +633,7 @@ int mckpp_hip_set_flux_series(mckpp_hip_handle h, int rec0, int nrec, const doub
 {
   if (!h || !fields) return fail("mckpp_hip_set_flux_series: null argument");
   if (nrec < 1 || rec0 < 0) return fail("mckpp_hip_set_flux_series: rec0=%d nrec=%d", rec0, nrec);
-  if (!h->ipt.size() && h->ncol) return fail("mckpp_hip_set_flux_series: upload the state first");
+  if (h->npts <= 0) return fail("mckpp_hip_set_flux_series: upload the state first (the records are compacted to the resident columns)");
   HIPCHK(hipSetDevice(h->device));
   if (h->d_series) { HIPCHK(hipFree(h->d_series)); h->d_series = nullptr; h->series_nrec = 0; }
   h->series_rec0 = rec0;
@@ -892,6 +897,11 @@ int mckpp_hip_load_restart(mckpp_hip_handle h, const char *path)
     HIPCHK(hipMalloc(&h->d_cs, (size_t)h->ncol * MCKPP_CS * sizeof(double)));
     HIPCHK(hipMalloc(&h->d_ci, (size_t)h->ncol * MCKPP_CI * sizeof(int)));
     HIPCHK(hipMalloc(&h->d_ipt, (size_t)h->ncol * sizeof(int)));
+  }
+  if (ipt != h->ipt && h->d_series) {   // resident flux records were compacted with the previous land mask
+    hipFree(h->d_series);
+    h->d_series = nullptr;
+    h->series_nrec = 0;
   }
   h->ipt = ipt;
   const size_t rowelems = (size_t)h->ncol * h->ld;
