@@ -14,9 +14,10 @@ program kpp_driver
   use mckpp_initialize_ocean, only: mckpp_initialize_ocean_model
   use mckpp_physics_driver_mod, only: mckpp_physics_driver, mckpp_physics_finalize
   use mckpp_physics_ocnstep_mod, only: mckpp_physics_ocnstep
+  use mckpp_fluxes_mod, only: mckpp_fluxes
   implicit none
   character(len=512) :: fin, fout
-  integer :: u, nt, nsteps, ncol, nlev, use_1d, ipt
+  integer :: u, nt, nsteps, ncol, nlev, use_1d, ipt, flags
   integer(c_int) :: hdr(8)
   real(c_double), allocatable :: sf6(:,:), mask(:)
   type(kpp_1d_type) :: q
@@ -27,6 +28,7 @@ program kpp_driver
   open (newunit=u, file=trim(fin), access='stream', form='unformatted', status='old')
   read (u) hdr
   ncol = hdr(1); nlev = hdr(2); nsteps = hdr(3); use_1d = hdr(4)
+  flags = hdr(6)   ! 1: forcing through mckpp_fluxes (constant forcing, L_FLUXDATA=.F.) every step; 2: L_VARY_BOTTOM_TEMP
   call mckpp_set_dimensions(ncol, 1, nlev, hdr(5))
   call mckpp_allocate_const_fields()
   call mckpp_allocate_3d_fields()
@@ -42,6 +44,11 @@ program kpp_driver
   kpp_3d_fields%run_physics = mask > 0.5_c_double
   kpp_3d_fields%l_ocean = kpp_3d_fields%run_physics
   kpp_3d_fields%U_init = kpp_3d_fields%U
+  if (iand(flags, 2) /= 0) then
+    call mckpp_allocate_3d_optional()
+    kpp_const_fields%L_VARY_BOTTOM_TEMP = .true.
+    kpp_3d_fields%bottom_temp = kpp_3d_fields%X(:, nzp1, 1) + 0.125_c_double
+  end if
   kpp_3d_fields%sflux = 0
   kpp_3d_fields%sflux(:, :, 5, 0) = 1e-20_c_double      ! mckpp_initialize_fluxes, src/mckpp_fluxes_mod.F90:19-32
 
@@ -53,6 +60,7 @@ program kpp_driver
   call cpu_time(t0)
   do nt = 1, nsteps
     call mckpp_update_time(nt)
+    if (iand(flags, 1) /= 0) call mckpp_fluxes()      ! ndtocn = 1 (src/mckpp_ocean_model_3D.F90:44-48)
     if (use_1d == 0) then
       call mckpp_physics_driver()
     else

@@ -14,10 +14,10 @@ import common as cm
 DRIVER = os.path.join(cm.ROOT, "mckpp_f90_amd", "kpp_driver")
 
 
-def _write_case(path, kc, k3, sf6, nsteps, use_1d):
+def _write_case(path, kc, k3, sf6, nsteps, use_1d, flags=0):
     npts, nz = k3.npts, kc.nz
     with open(path, "wb") as f:
-        np.array([npts, nz, nsteps, use_1d, kc.nztmax, 0, 0, 0], dtype=np.int32).tofile(f)
+        np.array([npts, nz, nsteps, use_1d, kc.nztmax, flags, 0, 0], dtype=np.int32).tofile(f)
         np.array([kc.dto]).tofile(f)
         for a in (kc.zm, kc.hm, kc.dm):
             np.asarray(a, dtype=np.float64).tofile(f)
@@ -76,3 +76,34 @@ def test_fortran_driver_matches_cabi_path(built, tmp_path, ncol, nz, nsteps, use
         mk.mckpp_physics_driver(k3, kc, nt)
     for n in ("U", "X", "Us", "Xs", "hmix", "kmix", "hmixd", "Tref", "Ssurf", "old", "new_", "difm", "ghat", "rho"):
         assert np.array_equal(got[n], getattr(k3, n)), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [1, 2, 3])
+def test_fortran_fluxes_and_bottomtemp_wrappers(built, tmp_path, flags):
+    """mckpp_fluxes (constant forcing, L_FLUXDATA=.F., src/mckpp_fluxes_mod.F90:41-49) every step and
+    the L_VARY_BOTTOM_TEMP override, through the Fortran modules, against the same calls on the C-ABI."""
+    import mckpp_f90_amd as mk
+
+    ncol, nz, nsteps = 77, 40, 3
+    kc, k3 = cm.make_hip_case(ncol, nz, land_every=6)
+    sf = cm.synth.forcing(ncol, "bench")
+    _write_case(tmp_path / "case.bin", kc, k3, sf, nsteps, 0, flags)
+    r = subprocess.run([DRIVER, str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = _read_out(tmp_path / "out.bin", kc, ncol)
+    if flags & 2:
+        kc.L_VARY_BOTTOM_TEMP = 1
+        k3.bottom_temp[:] = np.asarray(k3.X[:, nz, 0]) + 0.125
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    cm.set_forcing_3d(k3, sf)
+    one = np.ones(ncol)
+    for nt in range(1, nsteps + 1):
+        if flags & 1:
+            ctx.fluxes(nt, 0.01 * one, 0 * one, 200 * one, 0 * one, -150 * one, 0 * one, 6e-5 * one, 0 * one)
+        mk.mckpp_physics_driver(k3, kc, nt, new_forcing=not (flags & 1))
+    for n in ("U", "X", "Us", "Xs", "hmix", "kmix", "hmixd", "Tref", "Ssurf", "old", "new_", "difm", "ghat", "rho"):
+        assert np.array_equal(got[n], getattr(k3, n)), n
+    if flags & 2:
+        act = np.nonzero(k3.run_physics)[0]
+        assert np.array_equal(got["X"][act, nz, 0], k3.bottom_temp[act])
