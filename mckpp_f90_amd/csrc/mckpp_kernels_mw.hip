@@ -11,7 +11,8 @@
 // sub-phases in lock-step; 14 s_barriers per pass) instead of a wave-local fence.
 //
 // Results are bit-identical to k_column_wg / k_column and to the CPU oracle.
-// Default physics only (the optional-physics build stays on k_column_wg).
+// EXT=true carries the optional physics (two more LDS rows for rho/cp, four more
+// barriers in the finish round for the cross-wave counts of check_profile).
 #include "mckpp_sweeps.h"
 
 #include <cstdio>
@@ -29,25 +30,27 @@ enum { C_B0 = 0, C_WU01, C_WU02, C_WX01, C_WX02, C_WXNT0, C_UREFNZ, C_VREFNZ, C_
        X_CAND_HBL,            // + sub (WPS entries)
        C_COUNT = X_CAND_HBL + 4 };
 // per-slot int record
-enum { I_COL = 0, I_CAND_KBL /* + sub */, I_NVIOL = I_CAND_KBL + 4 /* + sub */, I_OVER = I_NVIOL + 4, I_COUNT = I_OVER + 4 };
+enum { I_COL = 0, I_CAND_KBL /* + sub */, I_NVIOL = I_CAND_KBL + 4 /* + sub */, I_OVER = I_NVIOL + 4,
+       I_NU = I_OVER + 4 /* + sub */, I_NV = I_NU + 4, I_NF = I_NV + 4, I_COUNT = I_NF + 4 };
+enum { R_RHO = R_COUNT, R_CP, R_COUNT_EXT };   // rho, cp rows of the optional-physics build
 
 template <int WPS>
 __host__ __device__ constexpr int mw_na() { return 64 * WPS + 3; }
-template <int WPS>
+template <int WPS, bool EXT = false>
 __host__ __device__ constexpr int mw_slot_stride()
 {
-  int s = R_COUNT * mw_na<WPS>();
+  int s = (EXT ? R_COUNT_EXT : R_COUNT) * mw_na<WPS>();
   while (s % 32 != 9) ++s;
   return s;
 }
 
-template <int WPS, int W, int MINW>
+template <int WPS, int W, int MINW, bool EXT>
 __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kparams *__restrict__ pp, const int ntime)
 {
   const mckpp_kparams &p = *pp;
   extern __shared__ double lds[];
   constexpr int NA = mw_na<WPS>();
-  constexpr int SS = mw_slot_stride<WPS>();
+  constexpr int SS = mw_slot_stride<WPS, EXT>();
   constexpr int NW = WPS * W;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -91,7 +94,8 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
   double U = 0, V = 0, T = 0, S = 0, talpha = 0, sbeta = 0;
   // values that cross sub-phases of one pass
   double rho = 0, cp = 0, buoy = 0, Ritop = 0, dVsq = 0, dbloc = 0, shsq = 0, Rig = 0, zdiff = 0, zmk = 0;
-  double dm_i = 0, ds_i = 0, difm = 0, difs = 0, dift = 0, ghat = 0;
+  double dm_i = 0, ds_i = 0, dt_i = 0, difm = 0, difs = 0, dift = 0, ghat = 0;
+  double alphaDT = 0, betaDS = 0, xt = 0;   // EXT: LDD inputs; tinc_fcorr of the latest pass (overrides.F90:87-88)
 
   int state = S_EMPTY, col = 0;
   int old = 0, newi = 1, jer = 3, l_initflag = 0, status = 0, npass = 0, npass_try = 0, iconv = 0;
@@ -172,6 +176,12 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     if (k == nzp1 + 1) sc[X_RHOH2O] = rho;
     if (k == nzp1 + 2) sc[X_RHOB] = rho;
     if (act) { aU[k] = U; aV[k] = V; aB[k] = buoy; }
+    if constexpr (EXT) {
+      if (act) { row(R_RHO)[k] = rho; row(R_CP)[k] = cp; }
+      if (p.LDD && act) {   // neighbours for alphaDT, betaDS (T is already in aT)
+        row(R_YV)[k] = talpha; row(R_RB)[k] = sbeta; row(R_GH)[k] = S;
+      }
+    }
   };
   double B0 = 0, B0sol = 0, ustar = 0;   // wave-uniform, recomputed identically by every wave of the slot
   auto A3 = [&]() {   // surface fluxes, reference-level loop, Ri pieces
@@ -220,6 +230,13 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
       }
       zk = zk1; Uk = Uk1; Vk = Vk1; Bk = Bk1;
     }
+    if constexpr (EXT) {
+      alphaDT = 0.0; betaDS = 0.0;
+      if (p.LDD) {   // verticalmixing_mod.F90:103-108
+        alphaDT = 0.5 * (talpha + row(R_YV)[k + 1]) * (T - aT[k + 1]);
+        betaDS = 0.5 * (sbeta + row(R_RB)[k + 1]) * (S - row(R_GH)[k + 1]);
+      }
+    }
     const double bk1 = aB[k + 1], uk1 = aU[k + 1], vk1 = aV[k + 1];
     Ritop = (zref - zmk) * (br - buoy);
     dbloc = buoy - bk1;
@@ -253,8 +270,31 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     fri = fri * fri * fri;
     dm_i = (0.0001 + fri * 0.005);
     ds_i = (0.00001 + fri * 0.005);
-    if (actz) { aDm[k] = dm_i; aDs[k] = ds_i; aDt[k] = ds_i; }
-    if (k == nz) { aDm[k + 1] = dm_i; aDs[k + 1] = ds_i; aDt[k + 1] = ds_i; }
+    if constexpr (EXT) {
+      dt_i = ds_i;   // dift = difs, rimix_mod.F90:95-97 (the default build keeps one register for both)
+      if (p.LDD) {   // ddmix_mod.F90:12-52
+        const double Rrho0 = 1.9, dsfmax = 1.0e-4;
+        const double aDT = alphaDT, bDS = betaDS;
+        if ((aDT > bDS) && (bDS > 0.)) {
+          double Rrho = dmin2(aDT / bDS, Rrho0);
+          double rr = ((Rrho - 1) / (Rrho0 - 1));
+          double diffdd = 1.0 - rr * rr;
+          diffdd = dsfmax * diffdd * diffdd * diffdd;
+          dt_i = dt_i + diffdd * 0.8 / Rrho;
+          ds_i = ds_i + diffdd;
+        } else if ((aDT < 0.0) && (bDS < 0.0) && (aDT < bDS)) {
+          double Rrho = aDT / bDS;
+          double diffdd = 1.5e-6 * 9.0 * 0.101 * mckpp_exp(4.6 * mckpp_exp(-0.54 * (1 / Rrho - 1)));
+          double prandtl = 0.15 * Rrho;
+          if (Rrho > 0.5) prandtl = (1.85 - 0.85 / Rrho) * Rrho;
+          dt_i = dt_i + diffdd;
+          ds_i = ds_i + prandtl * diffdd;
+        }
+      }
+    }
+    const double dt_l = EXT ? dt_i : ds_i;
+    if (actz) { aDm[k] = dm_i; aDs[k] = ds_i; aDt[k] = dt_l; }
+    if (k == nz) { aDm[k + 1] = dm_i; aDs[k + 1] = ds_i; aDt[k + 1] = dt_l; }
     if (k == 1) { aDm[0] = 0.0; aDs[0] = 0.0; aDt[0] = 0.0; }
   };
   auto A5 = [&]() {   // bldepth, level-parallel part
@@ -385,7 +425,7 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     }
     {
       const double hk = c_hm[k];
-      const double dt_i = ds_i;
+      const double dt_l = EXT ? dt_i : ds_i;
       double wm, ws;
       double sig = div_fast(-zmk + 0.5 * hk, hbl, r_hbl);
       double sigma = stable * sig + (1. - stable) * dmin2(sig, eps01);
@@ -410,13 +450,13 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
         dkmp5 = caseA * ds_i + (1. - caseA) * b1;
         dstar = (omd * omd) * dkm1[1] + (delta * delta) * dkmp5;
         b1 = omd * ds_i + delta * dstar;
-        dkmp5 = caseA * dt_i + (1. - caseA) * b2;
+        dkmp5 = caseA * dt_l + (1. - caseA) * b2;
         dstar = (omd * omd) * dkm1[2] + (delta * delta) * dkmp5;
-        b2 = omd * dt_i + delta * dstar;
+        b2 = omd * dt_l + delta * dstar;
         gh = (1. - caseA) * gh;
       }
       if (k < kbl) { difm = b0; difs = b1; dift = b2; ghat = gh; }
-      else { difm = dm_i; difs = ds_i; dift = dt_i; ghat = 0.; }
+      else { difm = dm_i; difs = ds_i; dift = dt_l; ghat = 0.; }
       if (k >= nz) { difm = 0.0001; difs = 0.00001; dift = 0.00001; ghat = 0.0; }
     }
     hbl_pass = hbl;
@@ -424,6 +464,82 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
   };
   auto C3 = [&]() {   // final diffusivities into the rows the Thomas lanes (and finalize) read
     if (act) { aDm[k] = difm; aDs[k] = difs; aDt[k] = dift; aGh[k] = ghat; }
+  };
+  // ---- optional terms of the T and S right-hand sides (ocnint_mod.F90:97-215), level k of this lane:
+  // relaxation / flux corrections / prescribed advection (rhsmod, solvers.F90:176-335, salinity only)
+  auto ext_rhs = [&](int kmixe, double To_k, double So_k, double &rhsT, double &rhsS) {
+    const double dto = p.dto;
+    const double *xs = p.xs + (size_t)col * MCKPP_XS;
+    const double *aRho = row(R_RHO), *aCp = row(R_CP);
+    const double rhok = aRho[k], cpk = aCp[k];
+    const size_t oin = rowoff() + (k - 1);
+    if (k == 1) {
+      if (p.L_RELAX_SST && !p.L_FCORR_WITHZ && !p.L_FCORR) {   // :97-114
+        const double relax_sst = xs[XS_RELAX_SST], SST0 = xs[XS_SST0];
+        double fc = 0.0;
+        if (relax_sst > 1.e-10) {
+          if (!p.L_RELAX_CALCONLY) rhsT = rhsT + dto * relax_sst * (SST0 - To_k) * p.dm[kmixe] / c_hm[1];
+          fc = relax_sst * (SST0 - To_k) * p.dm[kmixe] * rhok * cpk;
+        }
+        csrow()[CS_FCORR] = fc;
+      }
+      if (p.L_FCORR && !p.L_RELAX_SST && !p.L_FCORR_WITHZ)     // :121-125
+        rhsT = rhsT + dto * xs[XS_FCORR_TWOD] / (rhok * cpk * c_hm[1]);
+    }
+    double tinc = 0.;                                           // :133-160
+    if (p.L_FCORR_WITHZ && !p.L_FCORR) tinc = dto * p.fcorr_withz[oin] / (rhok * cpk);
+    if (p.L_RELAX_OCNT) tinc = tinc + dto * xs[XS_RELAX_OCNT] * (p.ocnT_clim[oin] - To_k);
+    rhsT = rhsT + tinc;
+    xt = tinc;
+    const double ocnTcorr = tinc * rhok * cpk / dto;
+    // prescribed advection of salinity, rhsmod with jsclr = 2 (:179-184)
+    const int *ai = p.adv_i + (size_t)col * (p.maxmodeadv + 1);
+    const double *ad = p.adv_d + (size_t)col * (p.maxmodeadv + 1);
+    const int nmode = ai[0];
+    const int nzi = nz, km = kmixe;
+    for (int im = 0; im < nmode; ++im) {
+      const int mode = ai[1 + im];
+      if (mode <= 0) continue;
+      const double fact = dto * ad[im] * 0.033;
+      if (mode == 1) {
+        if (k == 1) rhsS = rhsS + fact / c_hm[1];
+      } else if (mode == 2) {
+        const double delta = p.hsum[km - 1];
+        if (k <= km - 1) rhsS = rhsS + fact / delta;
+      } else if (mode == 3) {
+        const double delta = p.hsum[nzi];
+        if (k <= nzi) rhsS = rhsS + fact / delta;
+      } else if (mode == 4) {
+        const int nzend = nzi - 1;
+        int n1 = 0;
+        do { n1 = n1 + 1; } while (c_zm[n1] >= -100. && n1 < nzp1);
+        double delta = 0.0;
+        for (int n = n1; n <= nzend; ++n) delta = delta + c_hm[n];
+        if (k >= n1 && k <= nzend) rhsS = rhsS + fact / delta;
+      } else if (mode == 5) {
+        if (k == nzi) rhsS = rhsS + fact / c_hm[nzi];
+      } else if (mode == 6 || mode == 7) {
+        int n1, n2 = 0;
+        double depth, dmax, delta = 0.0;
+        if (mode == 6) { n1 = 1; depth = c_hm[1]; dmax = p.dm[km] - 0.5 * (c_hm[km] + c_hm[km - 1]); }
+        else { n1 = km - 1; depth = p.dm[km] - 0.5 * c_hm[km]; dmax = 100.; }
+        for (int n = n1; n <= nzi; ++n) {
+          n2 = n;
+          delta = delta + c_hm[n];
+          depth = depth + c_hm[n + 1];
+          if (depth >= dmax) break;
+        }
+        if (k >= n1 && k <= n2) rhsS = rhsS + fact / delta;
+      }
+    }
+    double sinc = 0.;                                           // :187-213
+    if (p.L_SFCORR_WITHZ && !p.L_SFCORR) sinc = dto * p.sfcorr_withz[oin];
+    if (p.L_RELAX_SAL) sinc = sinc + dto * xs[XS_RELAX_SAL] * (p.sal_clim[oin] - So_k);
+    rhsS = rhsS + sinc;
+    if (maybe_final()) {
+      const size_t o = rowoff() + k;
+      p.tinc_fcorr[o] = tinc; p.ocnTcorr[o] = ocnTcorr; p.sinc_fcorr[o] = sinc; p.scorr[o] = sinc / dto;
+    }
   };
   auto C4 = [&]() {   // right-hand sides of U, T, S
     const double *cs = csrow();
@@ -457,9 +573,13 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
       if (k == 1) rhsS = So + dtohk * (wX0_2 * difs * ghat - wX0_2 * 1.0 + 0.0 - 0.0);
       else rhsS = So + dtohk * (wX0_2 * (difs * ghat - ds_m1 * gh_m1) + 0.0 - 0.0);
       if (k == nz && nz > 1) rhsS = rhsS + So_np * tri1_nz * difs;
+      if constexpr (EXT) ext_rhs(kbl_pass, To, So, rhsT, rhsS);
       yU[k] = rhsU; yT[k] = rhsT; yS[k] = rhsS;
     }
-    if (k == nzp1) { yU[k] = Uo; yT[k] = To; yS[k] = So; }
+    if (k == nzp1) {
+      yU[k] = Uo; yT[k] = To; yS[k] = So;
+      if constexpr (EXT) { double t = 0.0, s2 = 0.0; ext_rhs(kbl_pass, To, So, t, s2); }   // corrections of level nzp1, ocnint_mod.F90:153-160, 207-213
+    }
   };
   auto E = [&]() {   // V right-hand side with the new U
     const double Uo = ld_old(p.U), Vo = ld_old(p.V);
@@ -653,22 +773,114 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
           p.wXNT1[ro] = sc[C_WXNT0];
         }
       }
-      const size_t o = ro + (k - 1);
+    }
+    // ---- outputs of the column-step.  STEP: ocnstep_mod.F90:305-353 + check_profile
+    // (overrides.F90:42-125); the optional parts of check_profile count over all levels of the
+    // column, i.e. over the slot's waves, so they go through the slot record between barriers
+    // that every wave of the workgroup walks (EXT build only).
+    const bool fstep = fin == F_FINAL && p.mode == MCKPP_MODE_STEP;
+    double reset_out = 0.0, dampu = 0.0, dampv = 0.0, freeze = 0.0;
+    int l_ocean = 0;
+    if (fstep && k == 1) {   // level-1 references, before any override touches the profiles
+      double *cs = csrow();
+      cs[CS_UREF] = U; cs[CS_VREF] = V; cs[CS_TREF] = T;
+      cs[CS_SSURF] = p.L_SSref ? cs[CS_SSREF] : S + cs[CS_SREF];
+    }
+    if constexpr (EXT) {
+      if (fstep && p.L_DAMP_CURR) {   // ocnstep_mod.F90:317-340
+        const double rr = (double)p.dt_uvdamp * (86400. / p.dto);
+        double a = 0.99 * __builtin_fabs(U), b = (U * U) / rr;
+        const int nu = __popcll(__ballot(act && (b < a)));
+        U = U - dsign(dmin2(a, b), U);
+        a = 0.99 * __builtin_fabs(V); b = (V * V) / rr;
+        const int nv = __popcll(__ballot(act && (b < a)));
+        V = V - dsign(dmin2(a, b), V);
+        if (lane == 0) { si[I_NU + sub] = nu; si[I_NV + sub] = nv; }
+      }
+      __syncthreads();
+    }
+    if (fstep) {
+      const size_t o = rowoff() + (k - 1);
+      if constexpr (EXT) {
+        if (p.L_DAMP_CURR) {
+          const double inc = 1.0 / (double)nzp1;
+          int nu = 0, nv = 0;
+#pragma unroll
+          for (int s_ = 0; s_ < WPS; ++s_) { nu += si[I_NU + s_]; nv += si[I_NV + s_]; }
+          for (int i = 0; i < nu; ++i) dampu = dampu + inc;
+          for (int i = 0; i < nv; ++i) dampv = dampv + inc;
+        }
+      }
+      old = newi;
+      newi = 1 - old;
+      if (act) { p.Us[newi][o] = U; p.Vs[newi][o] = V; p.Ts[newi][o] = T; p.Ss[newi][o] = S; }
+      reset_out = (double)nreset;
+      if (comp_flag) {   // overrides.F90:57-78
+        if (EXT && p.clim_present && act) { T = p.ocnT_clim[o]; S = p.sal_clim[o]; }
+        if (act) { U = p.U_init[o]; V = p.V_init[o]; }
+        reset_out = 999.;
+      }
+      if constexpr (EXT) {
+        l_ocean = p.ci[(size_t)col * MCKPP_CI + CI_LOCEAN];
+        freeze = csrow()[CS_FREEZE];
+        if (l_ocean && p.L_NO_FREEZE) {   // :85-94
+          const bool cold = act && (T < -1.8);
+          if (cold) { xt = xt + (-1.8 - T); T = -1.8; }
+          const int nf = __popcll(__ballot(cold));
+          if (lane == 0) si[I_NF + sub] = nf;
+          if (act) p.tinc_fcorr[rowoff() + k] = xt;
+        }
+      }
+    }
+    if constexpr (EXT) {
+      __syncthreads();
+      const bool iso = fstep && l_ocean && p.L_NO_ISOTHERM;
+      if (fstep && l_ocean && p.L_NO_FREEZE) {
+        const double inc = 1.0 / (double)nzp1;
+        int nf = 0;
+#pragma unroll
+        for (int s_ = 0; s_ < WPS; ++s_) nf += si[I_NF + s_];
+        for (int i = 0; i < nf; ++i) freeze = freeze + inc;
+      }
+      if (iso && act) row(R_YU)[k] = T;   // :102-120
+      __syncthreads();
+      if (iso && k >= 2 && act) {
+        const double dz = c_zm[k] - c_zm[k - 1];
+        row(R_YT)[k] = __builtin_fabs((T - row(R_YU)[k - 1])) * dz;
+        row(R_YS)[k] = dz;
+      }
+      __syncthreads();
+      if (iso) {
+        const double *tD = row(R_YT), *tZ = row(R_YS);
+        double dtdz_total = 0., dz_total = 0.;
+        for (int q = 2; q <= p.iso_bot; ++q) {
+          dtdz_total = dtdz_total + tD[q];
+          dz_total = dz_total + tZ[q];
+        }
+        dtdz_total = dtdz_total / dz_total;
+        if (__builtin_fabs(dtdz_total) < p.iso_thresh) {
+          if (act) { const size_t o = rowoff() + (k - 1); T = p.ocnT_clim[o]; S = p.sal_clim[o]; }
+          reset_out = (-1.) * reset_out;
+        }
+      } else if (fstep) {
+        reset_out = 0.0;   // :121-123
+      }
+    } else {
+      reset_out = 0.0;     // :121-123 (no isotherm check in the default physics)
+    }
+    if (fin == F_FINAL) {
+      double *cs = csrow();
+      int *ci = p.ci + (size_t)col * MCKPP_CI;
+      const size_t o = rowoff() + (k - 1);
       if (p.mode == MCKPP_MODE_STEP) {
-        const double uref = U, vref = V, Tref = T, S1 = S;   // used by the lane that owns level 1
-        old = newi;
-        newi = 1 - old;
-        if (act) { p.Us[newi][o] = U; p.Vs[newi][o] = V; p.Ts[newi][o] = T; p.Ss[newi][o] = S; }
-        if (comp_flag && act) { U = p.U_init[o]; V = p.V_init[o]; }   // overrides.F90:72-78
         if (act) { p.U[o] = U; p.V[o] = V; p.T[o] = T; p.S[o] = S; }
         if (k == 1) {
           cs[CS_HMIX] = hmixn;
           cs[CS_KMIX] = (double)kmixn;
-          cs[CS_UREF] = uref; cs[CS_VREF] = vref; cs[CS_TREF] = Tref;
-          cs[CS_SSURF] = p.L_SSref ? cs[CS_SSREF] : S1 + cs[CS_SREF];
           cs[newi ? CS_HMIXD1 : CS_HMIXD0] = hmixn;
-          cs[CS_RESET] = 0.0;   // overrides.F90:121-123 (no isotherm check in the default physics)
-          cs[CS_DAMPU] = 0.0; cs[CS_DAMPV] = 0.0;
+          cs[CS_RESET] = reset_out;
+          cs[CS_DAMPU] = dampu; cs[CS_DAMPV] = dampv;
+          if constexpr (EXT) cs[CS_FREEZE] = freeze;
           ci[CI_OLD] = old; ci[CI_NEW] = newi;
           ci[CI_STATUS] = status; ci[CI_NPASS] = npass;
         }
@@ -702,38 +914,51 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
   }
 }
 
-template <int WPS, int W>
+template <int WPS, int W, bool EXT>
 size_t mw_lds_bytes()
 {
-  return (size_t)(6 * mw_na<WPS>() + W * mw_slot_stride<WPS>() + W * C_COUNT) * sizeof(double) +
+  return (size_t)(6 * mw_na<WPS>() + W * mw_slot_stride<WPS, EXT>() + W * C_COUNT) * sizeof(double) +
          (size_t)(W * I_COUNT + 2 * W) * sizeof(int);
 }
 
-template <int WPS, int W, int MINW>
+template <int WPS, int W, int MINW, bool EXT = false>
 hipError_t launch_mw(const mckpp_kparams &p, const mckpp_kparams *dp, int nblocks, hipStream_t stream)
 {
-  const size_t lds = mw_lds_bytes<WPS, W>();
+  const size_t lds = mw_lds_bytes<WPS, W, EXT>();
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_column_mw<WPS, W, MINW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_column_mw<WPS, W, MINW, EXT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_column_mw<WPS, W, MINW>), dim3((unsigned)nblocks), dim3(64 * WPS * W), lds, stream, dp,
+  hipLaunchKernelGGL((k_column_mw<WPS, W, MINW, EXT>), dim3((unsigned)nblocks), dim3(64 * WPS * W), lds, stream, dp,
                      p.ntime);
   return hipGetLastError();
 }
 
 }  // namespace
 
-// Deep columns (nzp1+2 > 64), default physics.
-// MCKPP_MW=<W>x<blocks per CU>[x<min waves per SIMD>] overrides the geometry (experiments).
+// Deep columns (nzp1+2 > 64).  MCKPP_MW=<W>x<blocks per CU>[x<min waves per SIMD>] overrides the
+// geometry of the default-physics build (experiments).
 hipError_t mckpp_launch_column_kernel_mw(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu,
                                          hipStream_t stream)
 {
   if (p.ncol <= 0) return hipSuccess;
   const int wps = (p.nzp1 + 2 + 63) / 64;
+  if (p.ext) {   // optional-physics build: two more LDS rows per slot, 4 workgroups per CU
+    const int W = (wps == 3) ? 1 : (wps == 2) ? 2 : 4;
+    int nblocks = num_cu * 4;
+    const int groups = (p.ncol + W - 1) / W;
+    if (nblocks > groups) nblocks = groups;
+    if (nblocks < 1) nblocks = 1;
+    switch (wps) {
+      case 1: return launch_mw<1, 4, 4, true>(p, dp, nblocks, stream);
+      case 2: return launch_mw<2, 2, 4, true>(p, dp, nblocks, stream);
+      case 3: return launch_mw<3, 1, 4, true>(p, dp, nblocks, stream);
+      default: return hipErrorInvalidValue;
+    }
+  }
   static int envW = -1, envB = 0, envM = 0;
   if (envW < 0) {
     envW = 0;

@@ -188,13 +188,13 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   h->ext = c->LDD || c->L_RELAX_SST || c->L_FCORR || c->L_FCORR_WITHZ || c->L_SFCORR || c->L_SFCORR_WITHZ ||
            c->L_RELAX_SAL || c->L_RELAX_OCNT || c->L_NO_FREEZE || c->L_NO_ISOTHERM || c->L_DAMP_CURR ||
            c->clim_present || c->L_ADVECT;
-  // deep columns (more than 62 levels) with the default physics run one level per lane over
+  // deep columns (more than 62 levels) run one level per lane over
   // several waves (mckpp_kernels_mw.hip); MCKPP_KERNEL=v1|wg|mw overrides (experiments, tests)
-  if (lpl > 1 && !h->ext) h->kernel_variant = 3;
+  if (lpl > 1) h->kernel_variant = 3;
   if (const char *kv = getenv("MCKPP_KERNEL")) {
     if (strcmp(kv, "v1") == 0) h->kernel_variant = 1;
     else if (strcmp(kv, "wg") == 0) h->kernel_variant = 2;
-    else if (strcmp(kv, "mw") == 0 && !h->ext) h->kernel_variant = 3;
+    else if (strcmp(kv, "mw") == 0) h->kernel_variant = 3;
   }
   if (h->ext && h->kernel_variant == 1) {
     delete h;
@@ -695,6 +695,7 @@ const char *mckpp_hip_kernel_name(mckpp_hip_handle h)
                                     {"k_column_wg<1>", "k_column_wg<2>", "k_column_wg<3>"},
                                     {"k_column_mw<1>", "k_column_mw<2>", "k_column_mw<3>"}};
   if (h->ext && h->kernel_variant == 2) return h->lpl == 1 ? "k_column_wg<1,EXT>" : h->lpl == 2 ? "k_column_wg<2,EXT>" : "k_column_wg<3,EXT>";
+  if (h->ext && h->kernel_variant == 3) return h->lpl == 1 ? "k_column_mw<1,EXT>" : h->lpl == 2 ? "k_column_mw<2,EXT>" : "k_column_mw<3,EXT>";
   return names[h->kernel_variant][h->lpl - 1];
 }
 

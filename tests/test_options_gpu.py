@@ -187,3 +187,91 @@ def test_vary_bottom_temp(mk, nz, switches):
     ctx.set_diagnostics(0)
     with pytest.raises(mk.MckppHipError):
         ctx.bottomtemp(k3.bottom_temp)
+
+
+@pytest.mark.parametrize("variant", [None, "wg"])
+@pytest.mark.parametrize("nz", [69, 150])
+def test_options_on_deep_columns(mk, monkeypatch, nz, variant):
+    """The optional physics on columns that span two or three wavefronts (k_column_mw<.,EXT>, and the
+    several-levels-per-lane form of k_column_wg as a second implementation): the level counts of
+    check_profile (damped levels, frozen levels), the isotherm sums and the double-diffusion neighbours
+    cross the 64-level wave boundary here."""
+    if variant is None:
+        monkeypatch.delenv("MCKPP_KERNEL", raising=False)
+    else:
+        monkeypatch.setenv("MCKPP_KERNEL", variant)
+    nzp1 = nz + 1
+    z = np.arange(nzp1)[None, :]
+
+    def check_kernel(k3, ob):
+        pass
+
+    # double diffusion: fingering-favourable salinity on half of the columns, all the way down
+    def prep_ldd(k3, ob):
+        S = np.asarray(k3.X[:, :, 1]).copy()
+        S[::2] = 0.4 - 0.8 * np.linspace(0, 1, nzp1)[None, :]
+        k3.X[:, :, 1] = S
+        ob.a["S"][:, 1:nzp1 + 1] = S
+    _case(mk, 40, nz, dict(LDD=1), prep_ldd, nsteps=2)
+
+    # current damping with strong deep currents (levels beyond the first wave are damped too)
+    def prep_damp(k3, ob):
+        k3.U[::2, 60:, 0] = 3.0
+        k3.U[1::4, 66:, 1] = -2.5
+        ob.a["U"][:, 1:nzp1 + 1] = k3.U[:, :, 0]
+        ob.a["V"][:, 1:nzp1 + 1] = k3.U[:, :, 1]
+    k3, ob = _case(mk, 40, nz, dict(L_DAMP_CURR=1, dt_uvdamp=360), prep_damp, nsteps=2)
+    assert np.any(k3.dampu_flag > 64.0 / nzp1) or np.any(k3.dampv_flag > 0)
+
+    # freeze clamp over the whole depth, isotherm check over 80 levels, climatology reset after a trap
+    def prep_frz(k3, ob):
+        T = np.asarray(k3.X[:, :, 0]).copy()
+        T[::3, :] = -2.2
+        T[1::3, :] = 12.0
+        k3.X[:, :, 0] = T
+        ob.a["T"][:, 1:nzp1 + 1] = T
+        _set2(k3, ob, "ocnT_clim", 8.0 + 10.0 * np.exp(-np.arange(nzp1) / 15.0)[None, :] * np.ones((k3.npts, 1)))
+        _set2(k3, ob, "sal_clim", np.asarray(k3.X[:, :, 1]) * 0.5)
+        k3.U[2::3, 0:3, 0] = 40.0
+        ob.a["U"][2::3, 1:4] = 40.0
+    sw = dict(L_NO_FREEZE=1, L_NO_ISOTHERM=1, clim_present=1, iso_bot=min(80, nz - 2), iso_thresh=0.002)
+    k3, ob = _case(mk, 42, nz, sw, prep_frz, nsteps=1)
+    assert np.any(k3.freeze_flag > 0.99) and np.any(k3.reset_flag < 0) and np.any(np.abs(k3.reset_flag) == 999)
+    _case(mk, 42, nz, sw, prep_frz, nsteps=3)
+
+    # relaxation and flux corrections with depth
+    def prep_rel(k3, ob):
+        n = k3.npts
+        _set2(k3, ob, "ocnT_clim", np.asarray(k3.X[:, :, 0]) - 0.3)
+        _set2(k3, ob, "sal_clim", np.asarray(k3.X[:, :, 1]) + 0.05)
+        r = np.full(n, 1.0 / (30 * 86400.0))
+        k3.relax_ocnT[:] = r; ob["relax_ocnT"] = r
+        k3.relax_sal[:] = 2 * r; ob["relax_sal"] = 2 * r
+        _set2(k3, ob, "fcorr_withz", 5.0 * np.exp(-z / 10.0) * np.linspace(-1, 1, n)[:, None])
+        _set2(k3, ob, "sfcorr_withz", 1e-7 * np.cos(z / 7.0) * np.ones((n, 1)))
+    k3, ob = _case(mk, 40, nz, dict(L_RELAX_OCNT=1, L_RELAX_SAL=1, L_FCORR_WITHZ=1, L_SFCORR_WITHZ=1), prep_rel)
+    assert np.any(k3.ocnTcorr[:, 64:] != 0) and np.any(k3.scorr[:, 64:] != 0)
+
+    # prescribed advection, all seven modes
+    def prep_adv(k3, ob):
+        for c in range(k3.npts):
+            k3.nmodeadv[c, 1] = 2
+            k3.modeadv[c, 0, 1] = 1 + (c % 7)
+            k3.modeadv[c, 1, 1] = 1 + ((c + 3) % 7)
+            k3.advection[c, 0, 1] = 1e-6 * (1 + c % 5)
+            k3.advection[c, 1, 1] = -5e-7
+        ob["nmodeadv"][:, 1] = k3.nmodeadv[:, 1]
+        ob["modeadv"][:, 1, :] = k3.modeadv[:, :, 1]
+        ob["advection"][:, 1, :] = k3.advection[:, :, 1]
+    _case(mk, 42, nz, dict(L_ADVECT=1), prep_adv, grid="stretched" if nz == 69 else "uniform")
+
+
+def test_optional_physics_kernel_selection(mk, monkeypatch):
+    monkeypatch.delenv("MCKPP_KERNEL", raising=False)
+    for nz, want in [(40, "k_column_wg<1,EXT>"), (69, "k_column_mw<2,EXT>"), (150, "k_column_mw<3,EXT>")]:
+        kc = mk.KppConstFields(nz)
+        kc.L_DAMP_CURR = 1
+        mk.mckpp_physics_lookup(kc)
+        ctx = mk.MckppHip(kc)
+        assert ctx.kernel_name == want, (nz, ctx.kernel_name)
+        ctx.close()

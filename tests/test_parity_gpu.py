@@ -495,7 +495,7 @@ def test_default_kernel_selection(mk, kernel_env):
     kc.LDD = True
     mk.mckpp_physics_lookup(kc)
     ctx = mk.MckppHip(kc)
-    assert ctx.kernel_name == "k_column_wg<2,EXT>"     # optional physics stays on the cooperative kernel
+    assert ctx.kernel_name == "k_column_mw<2,EXT>"     # deep columns: the one-level-per-lane kernel, optional-physics build
     ctx.close()
 
 
