@@ -710,3 +710,34 @@ def test_exact_division_helpers_against_ieee(mk):
                (np.abs(np.log2(np.abs(num3) + 1e-320) - np.log2(np.abs(den3) + 1e-320)) < 700)
     assert same(q[1][tame_den], ref3[tame_den]), "div_fast_guarded, tame denominators and any numerator"
     ctx.close()
+
+
+@pytest.mark.parametrize("nz,grid,nsteps", [(60, "uniform", 72), (69, "stretched", 48)])
+def test_three_day_diurnal_run_bitexact(mk, nz, grid, nsteps):
+    """A longer forced run: hourly steps under a diurnal short-wave cycle, so every column goes through
+    stable daytime and convective night-time boundary layers (both wscale branches, deepening and
+    shoaling hbl, pass counts from 6 up), with the state never leaving the device.  After each
+    simulated day, and at the end, everything must equal the oracle stepped the same way."""
+    from oracle import orc
+
+    ncol = 384
+    oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1, grid=grid)
+    kc, k3 = cm.make_hip_case(ncol, nz, grid=grid, land_every=11)
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    orc.init_ocean(oc, ob, 0)
+    active = np.nonzero(k3.run_physics)[0]
+    passes = []
+    for nt in range(1, nsteps + 1):
+        sf = cm.synth.forcing(ncol, "bench", t_seconds=(nt - 1) * kc.dto)
+        ob["sflux"] = sf
+        cm.set_forcing_3d(k3, sf)
+        ctx.set_forcing(k3.sflux)
+        ctx.step(nt, 1)
+        orc.physics_driver(oc, ob, nt)
+        st, nf, npass = ctx.status()
+        assert np.array_equal(st[active], ob["status"][active]) and np.array_equal(npass[active], ob["npasses"][active]), nt
+        passes.append(int(npass[active].max()))
+        if nt % 24 == 0 or nt == nsteps:
+            ctx.download(k3)
+            _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS, active), f"diurnal run nz={nz} step {nt}")
+    assert max(passes) > 6 and np.ptp(k3.hmix[active]) > 5.0     # the run was not a steady state
