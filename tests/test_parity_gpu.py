@@ -741,3 +741,45 @@ def test_three_day_diurnal_run_bitexact(mk, nz, grid, nsteps):
             ctx.download(k3)
             _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS, active), f"diurnal run nz={nz} step {nt}")
     assert max(passes) > 6 and np.ptp(k3.hmix[active]) > 5.0     # the run was not a steady state
+
+
+def test_seeded_sweep_of_shapes_and_forcings(mk, kernel_env):
+    """A seeded sweep over column depths (2 ... 189 levels, including every wave-count boundary),
+    grids, time steps, Jerlov types, land masks and randomly perturbed forcing, three steps each on
+    whatever kernel the library selects - and the same shape on the other cooperative kernel."""
+    from oracle import orc
+
+    rng = np.random.default_rng(20261003)
+    depths = [2, 3, 4, 5, 7, 12, 23, 31, 32, 33, 47, 59, 60, 61, 62, 63, 64, 65, 77, 96, 124, 125, 126, 127, 128, 160, 188, 189]
+    for i, nz in enumerate(depths):
+        grid = "stretched" if (i % 3 == 1 and nz >= 10) else "uniform"
+        dto = [3600.0, 1200.0, 900.0][i % 3]
+        ncol = int(rng.integers(3, 40))
+        for variant in (None, "wg" if nz > 61 else "mw"):
+            kernel_env(variant)
+            oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1, grid=grid, dto=dto)
+            kc, k3 = cm.make_hip_case(ncol, nz, grid=grid, dto=dto, land_every=int(rng.integers(0, 6)))
+            jer = rng.integers(1, 6, ncol).astype(np.int32)
+            k3.jerlov[:] = jer
+            ob["jerlov"] = jer
+            ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+            orc.init_ocean(oc, ob, 0)
+            active = np.nonzero(k3.run_physics)[0]
+            _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS, active), f"sweep nz={nz} {variant} init")
+            r2 = np.random.default_rng(1000 + i)        # same forcing for both kernels
+            for nt in (1, 2, 3):
+                sf = cm.synth.forcing(ncol, "bench", t_seconds=(nt - 1) * dto + 6 * 3600.0)
+                sf[:, 0] *= r2.uniform(0.0, 3.0, ncol)
+                sf[:, 1] = r2.uniform(-0.2, 0.2, ncol)
+                sf[:, 3] *= r2.uniform(0.0, 2.0, ncol)
+                sf[:, 5] += r2.uniform(-1e-4, 1e-4, ncol)
+                ob["sflux"] = sf
+                cm.set_forcing_3d(k3, sf)
+                mk.mckpp_physics_driver(k3, kc, nt)
+                orc.physics_driver(oc, ob, nt)
+                st, nf, npass = ctx.status()
+                assert np.array_equal(st[active], ob["status"][active]), (nz, variant, nt)
+                assert np.array_equal(npass[active], ob["npasses"][active]), (nz, variant, nt)
+                _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS, active), f"sweep nz={nz} {variant} step {nt}")
+            ctx.close()
+            kc._hip_ctx = None
