@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
   const bool act = k0 <= nzp1, actz = k0 <= nz;
   double U = 0, V = 0, T = 0, S = 0, talpha = 0, sbeta = 0;
   // values that cross sub-phases of one pass
-  double rho = 0, cp = 0, buoy = 0, Ritop = 0, dVsq = 0, dbloc = 0, shsq = 0, Rig = 0, zdiff = 0, zmk = 0;
+  double buoy = 0, Ritop = 0, dVsq = 0, dbloc = 0, shsq = 0, Rig = 0, zdiff = 0, zmk = 0;
   double dm_i = 0, ds_i = 0, dt_i = 0, difm = 0, difs = 0, dift = 0, ghat = 0;
   double alphaDT = 0, betaDS = 0, xt = 0;   // EXT: LDD inputs; tinc_fcorr of the latest pass (overrides.F90:87-88)
 
@@ -169,13 +169,18 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     if (k == nzp1 + 2) { Sin = p.sice; Tin = T1; Pin = -zm1; }
     double s0;
     abk80_dev(Sin, Tin, Pin, talpha, sbeta, s0);
-    rho = 1000. + s0;
-    cp = cpsw_dev(Sin, Tin, Pin);
+    const double rho = 1000. + s0;
+    const double cp = cpsw_dev(Sin, Tin, Pin);
     buoy = div_fast(-p.grav * s0, 1000., 1. / 1000.);
     if (k == 1) { sc[X_RHO0] = rho; sc[X_CP0] = cp; sc[X_TALPHA0] = talpha; sc[X_SBETA0] = sbeta; }
     if (k == nzp1 + 1) sc[X_RHOH2O] = rho;
     if (k == nzp1 + 2) sc[X_RHOB] = rho;
     if (act) { aU[k] = U; aV[k] = V; aB[k] = buoy; }
+    if (p.diag && maybe_final()) {   // what the last vmix leaves behind (types_transfer.F90:199-327)
+      size_t o = rowoff() + k;
+      if (act) { p.rho[o] = rho; p.cp[o] = cp; p.buoy[o] = buoy; p.talpha[o] = talpha; p.sbeta[o] = sbeta; }
+      if (k == 1) { p.rho[o - 1] = rho; p.cp[o - 1] = cp; p.talpha[o - 1] = talpha; p.sbeta[o - 1] = sbeta; }
+    }
     if constexpr (EXT) {
       if (act) { row(R_RHO)[k] = rho; row(R_CP)[k] = cp; }
       if (p.LDD && act) {   // neighbours for alphaDT, betaDS (T is already in aT)
@@ -251,9 +256,7 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     if (k == nzp1) aR[k] = 0.0;
     if (p.diag && maybe_final()) {
       size_t o = rowoff() + k;
-      if (act) { p.rho[o] = rho; p.cp[o] = cp; p.buoy[o] = buoy; p.talpha[o] = talpha; p.sbeta[o] = sbeta; }
       if (actz) { p.Rig[o] = Rig; p.dbloc[o] = dbloc; p.Shsq[o] = shsq; }
-      if (k == 1) { p.rho[o - 1] = rho; p.cp[o - 1] = cp; p.talpha[o - 1] = talpha; p.sbeta[o - 1] = sbeta; }
     }
   };
   auto A4 = [&]() {   // rimix + z121; interior diffusivity rows
