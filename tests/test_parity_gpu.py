@@ -783,3 +783,44 @@ def test_seeded_sweep_of_shapes_and_forcings(mk, kernel_env):
                 _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS, active), f"sweep nz={nz} {variant} step {nt}")
             ctx.close()
             kc._hip_ctx = None
+
+
+def test_full_size_soak_determinism_and_sample_parity(mk):
+    """1e5 x 60 for 60 hourly steps of diurnal forcing, twice in independent contexts: the two runs
+    must be bitwise identical (the column queue and the workgroup scheduling differ from run to run,
+    the results must not), nothing may be flagged, and every 41st column must equal the oracle."""
+    from oracle import orc
+
+    ncol, nz, nsteps = 100_000, 60, 60
+    runs = []
+    for rep in range(2):
+        kc, k3 = cm.make_hip_case(ncol, nz)
+        ctx = mk.MckppHip(kc)
+        ctx.upload(k3)
+        ctx.init_ocean(0)
+        for nt in range(1, nsteps + 1):
+            cm.set_forcing_3d(k3, cm.synth.forcing(ncol, "bench", t_seconds=(nt - 1) * 3600.0))
+            ctx.set_forcing(k3.sflux)
+            ctx.step(nt, 1)
+        ctx.download(k3)
+        st, nf, npass = ctx.status()
+        assert nf == 0
+        runs.append(k3)
+        ctx.close()
+    for n in ("U", "X", "Us", "Xs", "hmix", "kmix", "hmixd", "difm", "difs", "ghat", "wU", "wX", "rho", "Rig"):
+        assert np.array_equal(getattr(runs[0], n), getattr(runs[1], n)), n
+    k3 = runs[0]
+    assert np.all(np.isfinite(k3.X)) and np.all(np.isfinite(k3.U)) and np.ptp(k3.hmix) > 10.0
+    idx = np.arange(0, ncol, 41)
+    oc, ob = cm.make_oracle(len(idx), nz, exp_mode=1, index=idx, ntotal=ncol)
+    for nt in range(1, nsteps + 1):
+        ob["sflux"] = cm.synth.forcing(len(idx), "bench", t_seconds=(nt - 1) * 3600.0, index=idx)
+        orc.physics_driver(oc, ob, nt, nthreads=8)
+
+    class _Sub:
+        pass
+
+    sub = _Sub()
+    for n in ("U", "X", "Us", "Xs", "hmixd", "hmix", "kmix", "Tref", "uref", "vref", "Ssurf", "reset_flag"):
+        setattr(sub, n, getattr(k3, n)[idx])
+    _assert_bitexact(cm.compare(sub, ob, nz, cm.PROFILE_FIELDS + cm.SCALAR_FIELDS + ["hmixd0", "hmixd1"]), "soak sample")
