@@ -241,6 +241,12 @@ int mckpp_hip_last_kernel_ms(mckpp_hip_handle h, double *ms, int32_t *nlaunch);
  * ("k_column_wg<1>", "k_column_mw<2>", ...); static storage, never NULL. */
 const char *mckpp_hip_kernel_name(mckpp_hip_handle h);
 
+/* Residency of the most recent cooperative column-kernel launch of the process: workgroups per
+ * CU the launch asked for, how many the runtime says fit (registers, LDS), threads and dynamic
+ * LDS bytes per workgroup.  The kernels are tuned for blocks_per_cu == max_blocks_per_cu. */
+int mckpp_hip_kernel_residency(mckpp_hip_handle h, int32_t *blocks_per_cu, int32_t *max_blocks_per_cu,
+                               int32_t *threads_per_block, int64_t *lds_bytes_per_block);
+
 /* Number of device-resident (run_physics) columns. */
 int64_t mckpp_hip_ncolumns(mckpp_hip_handle h);
 

@@ -107,6 +107,7 @@ def _bind(lib):
     lib.mckpp_hip_download.argtypes = [C.c_void_p, C.POINTER(_StateC), C.c_uint32]
     lib.mckpp_hip_status.argtypes = [C.c_void_p, _ip, C.POINTER(C.c_int64), _ip]
     lib.mckpp_hip_last_kernel_ms.argtypes = [C.c_void_p, _dp, _ip]
+    lib.mckpp_hip_kernel_residency.argtypes = [C.c_void_p, _ip, _ip, _ip, C.POINTER(C.c_int64)]
     lib.mckpp_hip_kernel_name.argtypes = [C.c_void_p]
     lib.mckpp_hip_kernel_name.restype = C.c_char_p
     lib.mckpp_hip_ncolumns.argtypes = [C.c_void_p]
@@ -351,6 +352,13 @@ class MckppHip:
         nl = C.c_int32(0)
         _chk(_lib().mckpp_hip_last_kernel_ms(self._h, C.byref(ms), C.byref(nl)))
         return ms.value, nl.value
+
+    def kernel_residency(self):
+        """(blocks per CU asked for, blocks per CU that fit, threads per block, LDS bytes per block)"""
+        b, m, t = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        l = C.c_int64(0)
+        _chk(_lib().mckpp_hip_kernel_residency(self._h, C.byref(b), C.byref(m), C.byref(t), C.byref(l)))
+        return b.value, m.value, t.value, l.value
 
     @property
     def kernel_name(self):

@@ -66,6 +66,10 @@ struct mckpp_kparams {
   double *wU1, *wU2, *wX1, *wX2, *wX3, *wXNT1, *Rig, *dbloc, *Shsq;
 };
 
+// what the last cooperative-kernel launch looked like (for the residency check of the tests)
+struct mckpp_launch_info { int nblocks, threads, max_blocks_per_cu; size_t lds_bytes; };
+extern mckpp_launch_info g_mckpp_last_launch;
+
 // launchers (mckpp_kernels.hip)
 hipError_t mckpp_launch_column_kernel(const mckpp_kparams &p, hipStream_t stream);
 size_t mckpp_column_kernel_lds_bytes(int nzp1);

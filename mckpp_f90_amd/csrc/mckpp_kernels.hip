@@ -576,7 +576,7 @@ __global__ __launch_bounds__(64) void k_column(const mckpp_kparams p)
     }
     comp_flag = 1;
     double hmixe = 0, hmixn = 0;
-    int kmixe = 0, kmixn = 0;
+    int kmixn = 0;
     while (comp_flag && reset_flag <= 10.0) {                 // ocnstep_mod.F90:89
       FORJ {                                                  // :91-112
         r.U[j] = 2. * UsN[j] - UsO[j]; r.Ux[j] = r.U[j];
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(64) void k_column(const mckpp_kparams p)
         ++npass;
         ++npass_try;
         if (npass_try <= 3) {                                 // compulsory passes, :122-135
-          hmixe = h; kmixe = kb;
+          hmixe = h;
           continue;
         }
         hmixn = h; kmixn = kb;                                // :152-154 (iter == npass_try)
@@ -607,8 +607,8 @@ __global__ __launch_bounds__(64) void k_column(const mckpp_kparams p)
         if (__builtin_fabs(hmixn - hmixe) > tol) iconv = 0;   // :159-169
         else iconv = iconv + 1;
         if (iconv < 3) {                                      // :170-183
-          if (npass_try < p.itermax) { hmixe = hmixn; kmixe = kmixn; continue; }
-          else if (hmixn > hmixe) { hmixe = hmixn; kmixe = kmixn; continue; }
+          if (npass_try < p.itermax) { hmixe = hmixn; continue; }
+          else if (hmixn > hmixe) { hmixe = hmixn; continue; }
         }
         if (npass_try > (p.itermax + 1)) status |= 2;         // :184-191
         break;
@@ -971,6 +971,8 @@ size_t mckpp_column_kernel_lds_bytes(int nzp1)
   int lpl = (nzp1 + 2 + 63) / 64;
   return (size_t)A_COUNT * (64 * lpl + 8) * sizeof(double);
 }
+
+mckpp_launch_info g_mckpp_last_launch = {0, 0, 0, 0};
 
 hipError_t mckpp_launch_column_kernel(const mckpp_kparams &p, hipStream_t stream)
 {

@@ -745,7 +745,6 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     __syncthreads();
     if (fin == F_FINAL) {
       double *cs = csrow();
-      int *ci = p.ci + (size_t)col * MCKPP_CI;
       const size_t ro = rowoff();
       if (p.diag) {
         const double wX0_1 = first_lane(sc[C_WX01]), wX0_2 = first_lane(sc[C_WX02]);
@@ -935,6 +934,13 @@ hipError_t launch_mw(const mckpp_kparams &p, const mckpp_kparams *dp, int nblock
     if (e != hipSuccess) return e;
     attr_set = true;
   }
+  static int max_blocks = -1;
+  if (max_blocks < 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k_column_mw<WPS, W, MINW, EXT>), 64 * WPS * W, lds) != hipSuccess) nb = 0;
+    max_blocks = nb;
+  }
+  g_mckpp_last_launch = {nblocks, 64 * WPS * W, max_blocks, lds};
   hipLaunchKernelGGL((k_column_mw<WPS, W, MINW, EXT>), dim3((unsigned)nblocks), dim3(64 * WPS * W), lds, stream, dp,
                      p.ntime);
   return hipGetLastError();

@@ -1058,6 +1058,13 @@ hipError_t launch_wg(const mckpp_kparams &p, const mckpp_kparams *dp, int nblock
     if (e != hipSuccess) return e;
     attr_set = true;
   }
+  static int max_blocks = -1;
+  if (max_blocks < 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k_column_wg<LPL, W, MINW, EXT>), 64 * W, lds) != hipSuccess) nb = 0;
+    max_blocks = nb;
+  }
+  g_mckpp_last_launch = {nblocks, 64 * W, max_blocks, lds};
   hipLaunchKernelGGL((k_column_wg<LPL, W, MINW, EXT>), dim3((unsigned)nblocks), dim3(64 * W), lds, stream, dp,
                      p.ntime);
   return hipGetLastError();

@@ -699,6 +699,19 @@ const char *mckpp_hip_kernel_name(mckpp_hip_handle h)
   return names[h->kernel_variant][h->lpl - 1];
 }
 
+int mckpp_hip_kernel_residency(mckpp_hip_handle h, int32_t *blocks_per_cu, int32_t *max_blocks_per_cu,
+                               int32_t *threads_per_block, int64_t *lds_bytes_per_block)
+{
+  if (!h) return fail("null handle");
+  if (h->kernel_variant == 1 || g_mckpp_last_launch.threads == 0)
+    return fail("mckpp_hip_kernel_residency: no cooperative-kernel launch yet");
+  if (blocks_per_cu) *blocks_per_cu = (g_mckpp_last_launch.nblocks + h->num_cu - 1) / h->num_cu;
+  if (max_blocks_per_cu) *max_blocks_per_cu = g_mckpp_last_launch.max_blocks_per_cu;
+  if (threads_per_block) *threads_per_block = g_mckpp_last_launch.threads;
+  if (lds_bytes_per_block) *lds_bytes_per_block = (int64_t)g_mckpp_last_launch.lds_bytes;
+  return 0;
+}
+
 int mckpp_hip_last_kernel_ms(mckpp_hip_handle h, double *ms, int32_t *nlaunch)
 {
   if (!h) return fail("null handle");

@@ -824,3 +824,20 @@ def test_full_size_soak_determinism_and_sample_parity(mk):
     for n in ("U", "X", "Us", "Xs", "hmixd", "hmix", "kmix", "Tref", "uref", "vref", "Ssurf", "reset_flag"):
         setattr(sub, n, getattr(k3, n)[idx])
     _assert_bitexact(cm.compare(sub, ob, nz, cm.PROFILE_FIELDS + cm.SCALAR_FIELDS + ["hmixd0", "hmixd1"]), "soak sample")
+
+
+@pytest.mark.parametrize("nz,ncol,want", [(60, 20000, 5), (40, 20000, 5), (69, 20000, 4), (100, 20000, 4), (150, 20000, 5)])
+def test_tuned_residency_is_what_the_device_grants(mk, kernel_env, nz, ncol, want):
+    """The cooperative kernels are tuned to a number of resident workgroups per CU (5 x 4 columns at
+    up to 61 levels: <= 96 VGPRs and <= 25 LDS granules of 1,280 B each).  One more LDS row or a few
+    more registers silently drops a workgroup per CU (-10 % or worse), so ask the runtime."""
+    kernel_env(None)
+    kc, k3 = cm.make_hip_case(ncol, nz)
+    ctx = mk.MckppHip(kc)
+    ctx.upload(k3)
+    ctx.init_ocean(0)
+    ctx.step(1, 1)
+    ctx.synchronize()
+    asked, fit, threads, lds = ctx.kernel_residency()
+    assert asked == want and fit >= asked, (ctx.kernel_name, asked, fit, threads, lds)
+    ctx.close()
