@@ -368,6 +368,16 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
         if (first) { kbl = ck; hbl = first_lane(sc[X_CAND_HBL + s_]); }
       }
     }
+    hbl_pass = hbl;
+    kbl_pass = kbl;
+    if (!__any(k < kbl)) {
+      // this wave lies entirely below the boundary layer: its levels keep the interior values
+      // (kppmix_mod.F90:103-111) and need none of the boundary-layer scalars
+      const double dt_l = EXT ? dt_i : ds_i;
+      difm = dm_i; difs = ds_i; dift = dt_l; ghat = 0.;
+      if (k >= nz) { difm = 0.0001; difs = 0.00001; dift = 0.00001; ghat = 0.0; }   // verticalmixing_mod.F90:151-159
+      return;
+    }
     const wscale_u wu = wscale_prepare_uniform(ustar);
     double bfsfc = swfrac_dev_wave(-1.0, hbl, jer, lane);
     bfsfc = B0 + B0sol * (1. - bfsfc);
@@ -462,8 +472,6 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
       else { difm = dm_i; difs = ds_i; dift = dt_l; ghat = 0.; }
       if (k >= nz) { difm = 0.0001; difs = 0.00001; dift = 0.00001; ghat = 0.0; }
     }
-    hbl_pass = hbl;
-    kbl_pass = kbl;
   };
   auto C3 = [&]() {   // final diffusivities into the rows the Thomas lanes (and finalize) read
     if (act) { aDm[k] = difm; aDs[k] = difs; aDt[k] = dift; aGh[k] = ghat; }
