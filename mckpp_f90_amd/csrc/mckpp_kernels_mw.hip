@@ -25,7 +25,7 @@ using namespace mckpp_dev;
 
 enum { S_EMPTY = 0, S_ACTIVE = 1, S_DONE = 2 };
 // per-slot double record
-enum { C_B0 = 0, C_WU01, C_WU02, C_WX01, C_WX02, C_WXNT0, C_UREFNZ, C_VREFNZ, C_RHO0CP0, C_RRC,
+enum { C_B0 = 0, C_B0SOL, C_USTAR, C_WU01, C_WU02, C_WX01, C_WX02, C_WXNT0, C_UREFNZ, C_VREFNZ, C_RHO0CP0, C_RRC,
        X_RHO0, X_CP0, X_TALPHA0, X_SBETA0, X_RHOH2O, X_RHOB,
        X_CAND_HBL,            // + sub (WPS entries)
        C_COUNT = X_CAND_HBL + 4 };
@@ -190,27 +190,31 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
   };
   double B0 = 0, B0sol = 0, ustar = 0;   // wave-uniform, recomputed identically by every wave of the slot
   auto A3 = [&]() {   // surface fluxes, reference-level loop, Ri pieces
-    const double *cs = csrow();
-    const double rho0 = first_lane(sc[X_RHO0]), cp0 = first_lane(sc[X_CP0]);
-    const double talpha0 = first_lane(sc[X_TALPHA0]), sbeta0 = first_lane(sc[X_SBETA0]);
-    const double rhoh2o = first_lane(sc[X_RHOH2O]), rhob = first_lane(sc[X_RHOB]);
-    const double sflux1 = cs[CS_SFLUX1], sflux2 = cs[CS_SFLUX2], sflux3 = cs[CS_SFLUX3],
-                 sflux4 = cs[CS_SFLUX4], sflux5 = cs[CS_SFLUX5], sflux6 = cs[CS_SFLUX6];
-    const double Ssurf = cs[CS_SSURF];
-    const double r_rho0 = rcp_refine(rho0), rho0cp0 = rho0 * cp0, r_rc = rcp_refine(rho0cp0);
-    const double wU0_1 = first_lane(div_fast(-sflux1, rho0, r_rho0));
-    const double wU0_2 = first_lane(div_fast(-sflux2, rho0, r_rho0));
-    const double tau = __builtin_sqrt(sflux1 * sflux1 + sflux2 * sflux2) + 1.e-16;
-    ustar = first_lane(__builtin_sqrt(div_fast(tau, rho0, r_rho0)));
-    const double wX0_1 = first_lane(div_fast(div_fast(-sflux4, rho0, r_rho0), cp0, rcp_refine(cp0)));
-    const double wX0_2 = first_lane(div_fast(Ssurf * sflux6, rhoh2o, rcp_refine(rhoh2o)) +
-                                    div_fast((Ssurf - p.sice) * sflux5, rhob, rcp_refine(rhob)));
-    B0 = first_lane(-p.grav * (talpha0 * wX0_1 - sbeta0 * wX0_2));
-    B0sol = first_lane(div_fast(p.grav * talpha0 * sflux3, rho0cp0, r_rc));
-    if (lead && lane == 0) {
-      sc[C_B0] = B0; sc[C_WU01] = wU0_1; sc[C_WU02] = wU0_2;
-      sc[C_WX01] = wX0_1; sc[C_WX02] = wX0_2; sc[C_RHO0CP0] = rho0cp0; sc[C_RRC] = r_rc;
-      if (ntime >= 1) sc[C_WXNT0] = div_fast(-sflux3 * p.swdk_tab[jer * p.ldc], rho0cp0, r_rc);
+    // the surface fluxes are slot-uniform: the lead wave computes and publishes them, the other
+    // waves of the slot pick B0, B0sol and ustar up from the record in A5 (two barriers later)
+    if (lead) {
+      const double *cs = csrow();
+      const double rho0 = first_lane(sc[X_RHO0]), cp0 = first_lane(sc[X_CP0]);
+      const double talpha0 = first_lane(sc[X_TALPHA0]), sbeta0 = first_lane(sc[X_SBETA0]);
+      const double rhoh2o = first_lane(sc[X_RHOH2O]), rhob = first_lane(sc[X_RHOB]);
+      const double sflux1 = cs[CS_SFLUX1], sflux2 = cs[CS_SFLUX2], sflux3 = cs[CS_SFLUX3],
+                   sflux4 = cs[CS_SFLUX4], sflux5 = cs[CS_SFLUX5], sflux6 = cs[CS_SFLUX6];
+      const double Ssurf = cs[CS_SSURF];
+      const double r_rho0 = rcp_refine(rho0), rho0cp0 = rho0 * cp0, r_rc = rcp_refine(rho0cp0);
+      const double wU0_1 = first_lane(div_fast(-sflux1, rho0, r_rho0));
+      const double wU0_2 = first_lane(div_fast(-sflux2, rho0, r_rho0));
+      const double tau = __builtin_sqrt(sflux1 * sflux1 + sflux2 * sflux2) + 1.e-16;
+      ustar = first_lane(__builtin_sqrt(div_fast(tau, rho0, r_rho0)));
+      const double wX0_1 = first_lane(div_fast(div_fast(-sflux4, rho0, r_rho0), cp0, rcp_refine(cp0)));
+      const double wX0_2 = first_lane(div_fast(Ssurf * sflux6, rhoh2o, rcp_refine(rhoh2o)) +
+                                      div_fast((Ssurf - p.sice) * sflux5, rhob, rcp_refine(rhob)));
+      B0 = first_lane(-p.grav * (talpha0 * wX0_1 - sbeta0 * wX0_2));
+      B0sol = first_lane(div_fast(p.grav * talpha0 * sflux3, rho0cp0, r_rc));
+      if (lane == 0) {
+        sc[C_B0] = B0; sc[C_B0SOL] = B0sol; sc[C_USTAR] = ustar; sc[C_WU01] = wU0_1; sc[C_WU02] = wU0_2;
+        sc[C_WX01] = wX0_1; sc[C_WX02] = wX0_2; sc[C_RHO0CP0] = rho0cp0; sc[C_RRC] = r_rc;
+        if (ntime >= 1) sc[C_WXNT0] = div_fast(-sflux3 * p.swdk_tab[jer * p.ldc], rho0cp0, r_rc);
+      }
     }
     const double zm1 = first_lane(c_zm[1]);
     const double U1 = first_lane(aU[1]), V1 = first_lane(aV[1]), Bu1 = first_lane(aB[1]);
@@ -301,6 +305,7 @@ __global__ __launch_bounds__(64 * WPS * W, MINW) void k_column_mw(const mckpp_kp
     if (k == 1) { aDm[0] = 0.0; aDs[0] = 0.0; aDt[0] = 0.0; }
   };
   auto A5 = [&]() {   // bldepth, level-parallel part
+    if (!lead) { B0 = first_lane(sc[C_B0]); B0sol = first_lane(sc[C_B0SOL]); ustar = first_lane(sc[C_USTAR]); }
     const wscale_u wu = wscale_prepare_uniform(ustar);
     const double zm_kmp1 = first_lane(c_zm[nzp1]);
     double swf = p.swfrac_tab[jer * p.ldc + k];
