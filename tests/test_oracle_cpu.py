@@ -53,8 +53,20 @@ def test_z121_golden_bitexact():
         assert np.array_equal(w, wout[: km + 2])
 
 
-@pytest.mark.skipif(not os.path.exists(orc.REFLIB), reason="compiled reference (oracle/_ref) not built")
-def test_eos_vs_compiled_reference_1e6():
+def _need_ref():
+    """oracle/_ref is built by __graft_entry__.build() where /root/reference is mounted; only a box
+    without the reference (the GPU box) may skip."""
+    if not os.path.exists(orc.REFLIB):
+        if os.path.isdir("/root/reference/src"):
+            import __graft_entry__ as g
+            g.build()
+        else:
+            pytest.skip("compiled reference (oracle/_ref) not available: /root/reference is not mounted here")
+    assert os.path.exists(orc.REFLIB)
+
+
+def test_eos_vs_compiled_reference_1e6(built):
+    _need_ref()
     L, R = orc.lib(), orc.ref()
     rng = np.random.default_rng(7)
     n = 1_000_000
@@ -69,9 +81,9 @@ def test_eos_vs_compiled_reference_1e6():
     assert np.array_equal(o[8].view(np.int64), o[9].view(np.int64))
 
 
-@pytest.mark.skipif(not os.path.exists(orc.REFLIB), reason="compiled reference (oracle/_ref) not built")
-def test_abk80_flag_paths_vs_compiled_reference():
+def test_abk80_flag_paths_vs_compiled_reference(built):
     """P = 0 short-cuts and the kappa-only / alpha-only entry paths of mckpp_abk80."""
+    _need_ref()
     L, R = orc.lib(), orc.ref()
     for S, T, P in ((35.0, 10.0, 0.0), (0.0, 4.0, 0.0), (35.0, 10.0, 500.0), (20.0, -5.0, 50.0)):
         for a0, b0, k0 in ((1, 1, 1), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (0, 0, 0)):
