@@ -214,9 +214,22 @@ int mckpp_hip_download(mckpp_hip_handle h, mckpp_state_ptrs_c *s, uint32_t field
  * write list, :436-465 read path, cadence src/mckpp_xios_control.F90:61-83):
  * U,V,T,S,CP,rho,hmix,kmix,Sref,SSref,Ssurf,Tref,old,new,Us,Vs,Ts,Ss,hmixd (and
  * the column map) straight between HBM and a flat binary file.  load needs a
- * context created with the same vertical grid; it replaces any resident state. */
+ * context created with the same vertical grid; it replaces any resident state
+ * (only after the whole file has been read and checked: a bad file leaves the
+ * resident state as it was). */
 int mckpp_hip_save_restart(mckpp_hip_handle h, const char *path);
 int mckpp_hip_load_restart(mckpp_hip_handle h, const char *path);
+
+/* What the reference's time loop rewrites on the host between steps when the
+ * optional physics is on (mckpp_boundary_update, src/mckpp_ocean_model_3D.F90:51-55;
+ * the ndtupd* cadences of src/mckpp_boundary_update.F90): relax_sst, SST0,
+ * fcorr_twod, relax_sal, relax_ocnT, fcorr_withz, sfcorr_withz, ocnT_clim,
+ * sal_clim, nmodeadv/modeadv/advection.  Only those members of `s` are read;
+ * the prognostic state stays as it is on the device.  Also what an
+ * optional-physics context needs after mckpp_hip_load_restart (the restart set
+ * does not carry these inputs; stepping is refused until they are resident).
+ * No-op on a default-physics context. */
+int mckpp_hip_update_ancillaries(mckpp_hip_handle h, const mckpp_state_ptrs_c *s);
 
 /* Output-window reductions on the device (replace the XIOS temporal operations
  * "average" / "minimum" / "maximum" of run/iodef.xml:91-116 on the fields sent

@@ -96,6 +96,7 @@ def _bind(lib):
     lib.mckpp_hip_window_fetch.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
     lib.mckpp_hip_save_restart.argtypes = [C.c_void_p, C.c_char_p]
     lib.mckpp_hip_load_restart.argtypes = [C.c_void_p, C.c_char_p]
+    lib.mckpp_hip_update_ancillaries.argtypes = [C.c_void_p, C.POINTER(_StateC)]
     lib.mckpp_hip_fluxes.argtypes = [C.c_void_p, C.c_int] + [_dp] * 8 + [C.c_int, C.c_double, C.c_double]
     lib.mckpp_hip_bottomtemp.argtypes = [C.c_void_p, _dp]
     lib.mckpp_hip_set_flux_series.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
@@ -305,6 +306,11 @@ class MckppHip:
     def load_restart(self, path, npts):
         _chk(_lib().mckpp_hip_load_restart(self._h, str(path).encode()))
         self._npts_cache = npts
+
+    def update_ancillaries(self, kpp_3d_fields):
+        """Re-upload what mckpp_boundary_update rewrites between steps (optional-physics inputs only)."""
+        sc = kpp_3d_fields.as_c()
+        _chk(_lib().mckpp_hip_update_ancillaries(self._h, C.byref(sc)))
 
     def window_reset(self):
         _chk(_lib().mckpp_hip_window_reset(self._h))

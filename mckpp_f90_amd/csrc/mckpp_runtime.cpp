@@ -92,6 +92,9 @@ struct mckpp_hip_ctx {
   double *d_stage = nullptr;
   size_t stage_elems = 0;
   int diag = 1;
+  // optional-physics contexts: the relaxation / correction / advection inputs come with upload (or
+  // update_ancillaries); load_restart does not carry them, so stepping is refused until they are there
+  bool ext_inputs_resident = false;
 };
 
 extern "C" {
@@ -345,6 +348,84 @@ static int down_rows(mckpp_hip_ctx *h, const double *src, int src_off, int nlev,
   return 0;
 }
 
+
+// Device buffers of the column state for `ncol` resident columns out of `npts` grid points (every
+// row zeroed).  Used by upload and by load_restart, so a context with the optional physics gets
+// its input/output rows and per-column records from either.
+static int alloc_state(mckpp_hip_ctx *h, int64_t npts, int64_t ncol)
+{
+  free_state(h);
+  h->npts = npts;
+  h->ncol = ncol;
+  h->ext_inputs_resident = false;
+  if (ncol <= 0) return 0;
+  const size_t rowbytes = (size_t)ncol * h->ld * sizeof(double);
+  for (auto &p : h->d_prof) { HIPCHK(hipMalloc(&p, rowbytes)); HIPCHK(hipMemsetAsync(p, 0, rowbytes, h->stream)); }
+  for (auto &p : h->d_diag) { HIPCHK(hipMalloc(&p, rowbytes)); HIPCHK(hipMemsetAsync(p, 0, rowbytes, h->stream)); }
+  HIPCHK(hipMalloc(&h->d_cs, (size_t)ncol * MCKPP_CS * sizeof(double)));
+  HIPCHK(hipMalloc(&h->d_ci, (size_t)ncol * MCKPP_CI * sizeof(int)));
+  HIPCHK(hipMalloc(&h->d_ipt, (size_t)ncol * sizeof(int)));
+  if (h->ext) {
+    for (auto &p : h->d_ext_in) { HIPCHK(hipMalloc(&p, rowbytes)); HIPCHK(hipMemsetAsync(p, 0, rowbytes, h->stream)); }
+    for (auto &p : h->d_ext_out) { HIPCHK(hipMalloc(&p, rowbytes)); HIPCHK(hipMemsetAsync(p, 0, rowbytes, h->stream)); }
+    const size_t nadv = (size_t)ncol * (h->c.maxmodeadv + 1);
+    HIPCHK(hipMalloc(&h->d_xs, (size_t)ncol * MCKPP_XS * sizeof(double)));
+    HIPCHK(hipMemsetAsync(h->d_xs, 0, (size_t)ncol * MCKPP_XS * sizeof(double), h->stream));
+    HIPCHK(hipMalloc(&h->d_adv_d, nadv * sizeof(double)));
+    HIPCHK(hipMemsetAsync(h->d_adv_d, 0, nadv * sizeof(double), h->stream));
+    HIPCHK(hipMalloc(&h->d_adv_i, nadv * sizeof(int)));
+    HIPCHK(hipMemsetAsync(h->d_adv_i, 0, nadv * sizeof(int), h->stream));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// Inputs of the optional physics: what mckpp_boundary_update and the ancillary readers
+// rewrite on the host between steps (src/mckpp_ocean_model_3D.F90:51-55) - relaxation times and targets,
+// flux corrections, climatologies, prescribed advection.  Rows go through the staging buffer; the
+// per-column scalars are compacted on the host.
+static int upload_ancillaries(mckpp_hip_ctx *h, const mckpp_state_ptrs_c *s, const char *who = "mckpp_hip_upload")
+{
+  const mckpp_const_c &k = h->c;
+  const int64_t npts = h->npts, ncol = h->ncol;
+  const int nzp1 = h->nzp1;
+  const std::vector<int> &ipt = h->ipt;
+  if ((k.L_FCORR_WITHZ && !s->fcorr_withz) || (k.L_SFCORR_WITHZ && !s->sfcorr_withz) ||
+      ((k.L_RELAX_OCNT || k.clim_present || k.L_NO_ISOTHERM) && !s->ocnT_clim) ||
+      ((k.L_RELAX_SAL || k.clim_present || k.L_NO_ISOTHERM) && !s->sal_clim) ||
+      (k.L_RELAX_SST && (!s->relax_sst || !s->SST0)) || (k.L_FCORR && !s->fcorr_twod) ||
+      (k.L_RELAX_SAL && !s->relax_sal) || (k.L_RELAX_OCNT && !s->relax_ocnT))
+    return fail("%s: a switch is on but the field it reads is a NULL pointer", who);
+  if (s->fcorr_withz && up_rows(h, s->fcorr_withz, nzp1, h->d_ext_in[E_FCORR_WITHZ], 0)) return -1;
+  if (s->sfcorr_withz && up_rows(h, s->sfcorr_withz, nzp1, h->d_ext_in[E_SFCORR_WITHZ], 0)) return -1;
+  if (s->ocnT_clim && up_rows(h, s->ocnT_clim, nzp1, h->d_ext_in[E_OCNT_CLIM], 0)) return -1;
+  if (s->sal_clim && up_rows(h, s->sal_clim, nzp1, h->d_ext_in[E_SAL_CLIM], 0)) return -1;
+  const int mm = k.maxmodeadv;
+  std::vector<double> xs((size_t)ncol * MCKPP_XS, 0.0), ad((size_t)ncol * (mm + 1), 0.0);
+  std::vector<int> ai((size_t)ncol * (mm + 1), 0);
+  for (int64_t c = 0; c < ncol; ++c) {
+    const int64_t i = ipt[c];
+    double *x = &xs[(size_t)c * MCKPP_XS];
+    x[XS_RELAX_SST] = s->relax_sst ? s->relax_sst[i] : 0.0;
+    x[XS_SST0] = s->SST0 ? s->SST0[i] : 0.0;
+    x[XS_FCORR_TWOD] = s->fcorr_twod ? s->fcorr_twod[i] : 0.0;
+    x[XS_RELAX_SAL] = s->relax_sal ? s->relax_sal[i] : 0.0;
+    x[XS_RELAX_OCNT] = s->relax_ocnT ? s->relax_ocnT[i] : 0.0;
+    int nm = (k.L_ADVECT && s->nmodeadv) ? s->nmodeadv[i + npts * 1] : 0;   // nmodeadv(ipt,2)
+    if (nm < 0 || nm > mm) return fail("%s: nmodeadv(%lld,2)=%d outside 0..%d", who, (long long)i + 1, nm, mm);
+    ai[(size_t)c * (mm + 1)] = nm;
+    for (int j = 0; j < mm; ++j) {
+      ai[(size_t)c * (mm + 1) + 1 + j] = s->modeadv ? s->modeadv[i + npts * (j + (int64_t)mm * 1)] : 0;
+      ad[(size_t)c * (mm + 1) + j] = s->advection ? s->advection[i + npts * (j + (int64_t)mm * 1)] : 0.0;
+    }
+  }
+  HIPCHK(hipMemcpy(h->d_xs, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->d_adv_d, ad.data(), ad.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->d_adv_i, ai.data(), ai.size() * sizeof(int), hipMemcpyHostToDevice));
+  h->ext_inputs_resident = true;
+  return 0;
+}
+
 static void fill_params(mckpp_hip_ctx *h, mckpp_kparams &p, int ntime, int mode);
 
 int mckpp_hip_upload(mckpp_hip_handle h, const mckpp_state_ptrs_c *s)
@@ -361,24 +442,7 @@ int mckpp_hip_upload(mckpp_hip_handle h, const mckpp_state_ptrs_c *s)
     if (!s->run_physics || s->run_physics[i]) ipt.push_back((int)i);
   const int64_t ncol = (int64_t)ipt.size();
   if (ncol != h->ncol || npts != h->npts) {
-    free_state(h);
-    h->npts = npts;
-    h->ncol = ncol;
-    if (ncol > 0) {
-      const size_t rowbytes = (size_t)ncol * h->ld * sizeof(double);
-      for (auto &p : h->d_prof) { HIPCHK(hipMalloc(&p, rowbytes)); HIPCHK(hipMemsetAsync(p, 0, rowbytes, h->stream)); }
-      for (auto &p : h->d_diag) { HIPCHK(hipMalloc(&p, rowbytes)); HIPCHK(hipMemsetAsync(p, 0, rowbytes, h->stream)); }
-      HIPCHK(hipMalloc(&h->d_cs, (size_t)ncol * MCKPP_CS * sizeof(double)));
-      HIPCHK(hipMalloc(&h->d_ci, (size_t)ncol * MCKPP_CI * sizeof(int)));
-      HIPCHK(hipMalloc(&h->d_ipt, (size_t)ncol * sizeof(int)));
-      if (h->ext) {
-        for (auto &p : h->d_ext_in) { HIPCHK(hipMalloc(&p, rowbytes)); HIPCHK(hipMemsetAsync(p, 0, rowbytes, h->stream)); }
-        for (auto &p : h->d_ext_out) { HIPCHK(hipMalloc(&p, rowbytes)); HIPCHK(hipMemsetAsync(p, 0, rowbytes, h->stream)); }
-        HIPCHK(hipMalloc(&h->d_xs, (size_t)ncol * MCKPP_XS * sizeof(double)));
-        HIPCHK(hipMalloc(&h->d_adv_d, (size_t)ncol * (h->c.maxmodeadv + 1) * sizeof(double)));
-        HIPCHK(hipMalloc(&h->d_adv_i, (size_t)ncol * (h->c.maxmodeadv + 1) * sizeof(int)));
-      }
-    }
+    if (alloc_state(h, npts, ncol)) return -1;
   }
   if (ipt != h->ipt && h->d_series) {   // resident flux records were compacted with the previous land mask
     hipFree(h->d_series);
@@ -409,41 +473,7 @@ int mckpp_hip_upload(mckpp_hip_handle h, const mckpp_state_ptrs_c *s)
     if (up_rows(h, s->U_init, nzp1, h->d_prof[P_UINIT], 0)) return -1;
     if (up_rows(h, s->U_init + slab, nzp1, h->d_prof[P_VINIT], 0)) return -1;
   }
-  if (h->ext) {
-    const mckpp_const_c &k = h->c;
-    if ((k.L_FCORR_WITHZ && !s->fcorr_withz) || (k.L_SFCORR_WITHZ && !s->sfcorr_withz) ||
-        ((k.L_RELAX_OCNT || k.clim_present || k.L_NO_ISOTHERM) && !s->ocnT_clim) ||
-        ((k.L_RELAX_SAL || k.clim_present || k.L_NO_ISOTHERM) && !s->sal_clim) ||
-        (k.L_RELAX_SST && (!s->relax_sst || !s->SST0)) || (k.L_FCORR && !s->fcorr_twod) ||
-        (k.L_RELAX_SAL && !s->relax_sal) || (k.L_RELAX_OCNT && !s->relax_ocnT))
-      return fail("mckpp_hip_upload: a switch is on but the field it reads is a NULL pointer");
-    if (s->fcorr_withz && up_rows(h, s->fcorr_withz, nzp1, h->d_ext_in[E_FCORR_WITHZ], 0)) return -1;
-    if (s->sfcorr_withz && up_rows(h, s->sfcorr_withz, nzp1, h->d_ext_in[E_SFCORR_WITHZ], 0)) return -1;
-    if (s->ocnT_clim && up_rows(h, s->ocnT_clim, nzp1, h->d_ext_in[E_OCNT_CLIM], 0)) return -1;
-    if (s->sal_clim && up_rows(h, s->sal_clim, nzp1, h->d_ext_in[E_SAL_CLIM], 0)) return -1;
-    const int mm = k.maxmodeadv;
-    std::vector<double> xs((size_t)ncol * MCKPP_XS, 0.0), ad((size_t)ncol * (mm + 1), 0.0);
-    std::vector<int> ai((size_t)ncol * (mm + 1), 0);
-    for (int64_t c = 0; c < ncol; ++c) {
-      const int64_t i = ipt[c];
-      double *x = &xs[(size_t)c * MCKPP_XS];
-      x[XS_RELAX_SST] = s->relax_sst ? s->relax_sst[i] : 0.0;
-      x[XS_SST0] = s->SST0 ? s->SST0[i] : 0.0;
-      x[XS_FCORR_TWOD] = s->fcorr_twod ? s->fcorr_twod[i] : 0.0;
-      x[XS_RELAX_SAL] = s->relax_sal ? s->relax_sal[i] : 0.0;
-      x[XS_RELAX_OCNT] = s->relax_ocnT ? s->relax_ocnT[i] : 0.0;
-      int nm = (k.L_ADVECT && s->nmodeadv) ? s->nmodeadv[i + npts * 1] : 0;   // nmodeadv(ipt,2)
-      if (nm < 0 || nm > mm) return fail("mckpp_hip_upload: nmodeadv(%lld,2)=%d outside 0..%d", (long long)i + 1, nm, mm);
-      ai[(size_t)c * (mm + 1)] = nm;
-      for (int j = 0; j < mm; ++j) {
-        ai[(size_t)c * (mm + 1) + 1 + j] = s->modeadv ? s->modeadv[i + npts * (j + (int64_t)mm * 1)] : 0;
-        ad[(size_t)c * (mm + 1) + j] = s->advection ? s->advection[i + npts * (j + (int64_t)mm * 1)] : 0.0;
-      }
-    }
-    HIPCHK(hipMemcpy(h->d_xs, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_adv_d, ad.data(), ad.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_adv_i, ai.data(), ai.size() * sizeof(int), hipMemcpyHostToDevice));
-  }
+  if (h->ext && upload_ancillaries(h, s)) return -1;
   std::vector<double> cs((size_t)ncol * MCKPP_CS, 0.0);
   std::vector<int> ci((size_t)ncol * MCKPP_CI, 0);
   const int64_t fl_i = npts;                                        // stride of the flux index
@@ -591,6 +621,9 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode, const forced_r
 {
   if (!h) return fail("null handle");
   if (h->ncol == 0) { h->nlaunch = 0; h->timed = false; return 0; }
+  if (h->ext && !h->ext_inputs_resident)
+    return fail("optional-physics context: the relaxation / correction / advection inputs are not resident "
+                "(after mckpp_hip_load_restart call mckpp_hip_update_ancillaries before stepping)");
   HIPCHK(hipSetDevice(h->device));
   if (h->kernel_variant != 1) {   // parameter block (identical for every launch of this call but ntime)
     mckpp_kparams p0;
@@ -886,55 +919,67 @@ int mckpp_hip_load_restart(mckpp_hip_handle h, const char *path)
 {
   if (!h || !path) return fail("mckpp_hip_load_restart: null argument");
   HIPCHK(hipSetDevice(h->device));
-  FILE *f = fopen(path, "rb");
+  // The whole file is read and checked on the host first; the resident state is replaced only
+  // once everything is known to be there and consistent.
+  struct closer { FILE *f; ~closer() { if (f) fclose(f); } } fc{fopen(path, "rb")};
+  FILE *f = fc.f;
   if (!f) return fail("mckpp_hip_load_restart: cannot open %s", path);
   restart_header hd{};
-  if (fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, kRestartMagic, 8) != 0 || hd.version != 1) {
-    fclose(f);
+  if (fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, kRestartMagic, 8) != 0 || hd.version != 1)
     return fail("mckpp_hip_load_restart: %s is not a restart file of this library", path);
-  }
   if (hd.nz != h->nz || hd.ld != h->ld || hd.cs != MCKPP_CS || hd.ci != MCKPP_CI || hd.nprof != P_COUNT + 2 ||
-      hd.ncol <= 0 || hd.ncol > hd.npts) {
-    fclose(f);
+      hd.ncol <= 0 || hd.ncol > hd.npts)
     return fail("mckpp_hip_load_restart: %s was written for nz=%d (context has nz=%d) or another layout", path,
                 hd.nz, h->nz);
-  }
-  std::vector<int> ipt((size_t)hd.ncol);
+  const size_t ncol = (size_t)hd.ncol, rowelems = ncol * h->ld;
+  std::vector<int> ipt(ncol), ci(ncol * MCKPP_CI);
+  std::vector<double> rows((size_t)(P_COUNT + 2) * rowelems), cs(ncol * MCKPP_CS);
   bool ok = fread(ipt.data(), sizeof(int), ipt.size(), f) == ipt.size();
-  if (ok && (hd.ncol != h->ncol || hd.npts != h->npts)) {
-    free_state(h);
-    h->npts = hd.npts;
-    h->ncol = hd.ncol;
-    const size_t rowbytes = (size_t)h->ncol * h->ld * sizeof(double);
-    for (auto &p : h->d_prof) { HIPCHK(hipMalloc(&p, rowbytes)); }
-    for (auto &p : h->d_diag) { HIPCHK(hipMalloc(&p, rowbytes)); HIPCHK(hipMemset(p, 0, rowbytes)); }
-    HIPCHK(hipMalloc(&h->d_cs, (size_t)h->ncol * MCKPP_CS * sizeof(double)));
-    HIPCHK(hipMalloc(&h->d_ci, (size_t)h->ncol * MCKPP_CI * sizeof(int)));
-    HIPCHK(hipMalloc(&h->d_ipt, (size_t)h->ncol * sizeof(int)));
+  ok = ok && fread(rows.data(), sizeof(double), rows.size(), f) == rows.size();
+  ok = ok && fread(cs.data(), sizeof(double), cs.size(), f) == cs.size();
+  ok = ok && fread(ci.data(), sizeof(int), ci.size(), f) == ci.size();
+  if (!ok) return fail("mckpp_hip_load_restart: %s is truncated or unreadable", path);
+  for (size_t c = 0; c < ncol; ++c) {   // the column map scatters into (npts) arrays at download
+    if (ipt[c] < 0 || ipt[c] >= hd.npts || (c > 0 && ipt[c] <= ipt[c - 1]))
+      return fail("mckpp_hip_load_restart: %s has a corrupt column map (entry %zu = %d, npts = %lld)", path, c,
+                  ipt[c], (long long)hd.npts);
+    const int jw = ci[c * MCKPP_CI + CI_JERLOV];
+    if (jw < 1 || jw > 5) return fail("mckpp_hip_load_restart: %s: jerlov=%d in column %zu", path, jw, c);
   }
-  if (ipt != h->ipt && h->d_series) {   // resident flux records were compacted with the previous land mask
-    hipFree(h->d_series);
-    h->d_series = nullptr;
-    h->series_nrec = 0;
+  const bool same_shape = hd.ncol == h->ncol && hd.npts == h->npts;
+  if (!same_shape) {
+    if (alloc_state(h, hd.npts, hd.ncol)) return -1;
+  } else if (ipt != h->ipt) {
+    if (h->d_series) {   // resident flux records were compacted with the previous land mask
+      hipFree(h->d_series);
+      h->d_series = nullptr;
+      h->series_nrec = 0;
+    }
+    h->ext_inputs_resident = false;   // and so were the optional-physics inputs
   }
   h->ipt = ipt;
-  const size_t rowelems = (size_t)h->ncol * h->ld;
-  std::vector<double> buf(rowelems);
-  auto slurp = [&](double *d, size_t n) -> int {
-    if (n > buf.size()) buf.resize(n);
-    if (fread(buf.data(), sizeof(double), n, f) != n) return -1;
-    return hipMemcpy(d, buf.data(), n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
-  };
-  ok = ok && hipMemcpy(h->d_ipt, ipt.data(), ipt.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
-  for (int i = 0; i < P_COUNT && ok; ++i) ok = slurp(h->d_prof[i], rowelems) == 0;
-  ok = ok && slurp(h->d_diag[D_CP], rowelems) == 0 && slurp(h->d_diag[D_RHO], rowelems) == 0;
-  ok = ok && slurp(h->d_cs, (size_t)h->ncol * MCKPP_CS) == 0;
-  std::vector<int> ci((size_t)h->ncol * MCKPP_CI);
-  ok = ok && fread(ci.data(), sizeof(int), ci.size(), f) == ci.size();
-  ok = ok && hipMemcpy(h->d_ci, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
-  fclose(f);
-  if (!ok) return fail("mckpp_hip_load_restart: %s is truncated or unreadable", path);
+  HIPCHK(hipMemcpy(h->d_ipt, ipt.data(), ipt.size() * sizeof(int), hipMemcpyHostToDevice));
+  for (int i = 0; i < P_COUNT; ++i)
+    HIPCHK(hipMemcpy(h->d_prof[i], rows.data() + (size_t)i * rowelems, rowelems * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->d_diag[D_CP], rows.data() + (size_t)P_COUNT * rowelems, rowelems * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->d_diag[D_RHO], rows.data() + (size_t)(P_COUNT + 1) * rowelems, rowelems * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->d_cs, cs.data(), cs.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->d_ci, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice));
   return 0;
+}
+
+// Re-upload of what the host rewrites between steps for the optional physics
+// (mckpp_boundary_update, src/mckpp_ocean_model_3D.F90:51-55): SST0 / relaxation times, flux
+// corrections, climatologies, prescribed advection.  Prognostic state is not touched.
+int mckpp_hip_update_ancillaries(mckpp_hip_handle h, const mckpp_state_ptrs_c *s)
+{
+  if (!h || !s) return fail("mckpp_hip_update_ancillaries: null argument");
+  if (h->npts <= 0) return fail("mckpp_hip_update_ancillaries: no resident state (upload or load_restart first)");
+  if (s->npts != h->npts) return fail("mckpp_hip_update_ancillaries: npts=%lld but %lld are resident", (long long)s->npts, (long long)h->npts);
+  if (!h->ext || h->ncol == 0) return 0;   // the default physics reads none of them
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return upload_ancillaries(h, s, "mckpp_hip_update_ancillaries");
 }
 
 // ---------------------------------------------------------------------------

@@ -76,6 +76,12 @@ module mckpp_hip_binding
       type(mckpp_state_ptrs_c), intent(in) :: s
       integer(c_int) :: rc
     end function
+    function mckpp_hip_update_ancillaries(handle, s) bind(C, name="mckpp_hip_update_ancillaries") result(rc)
+      import :: c_int, c_ptr, mckpp_state_ptrs_c
+      type(c_ptr), value :: handle
+      type(mckpp_state_ptrs_c), intent(in) :: s
+      integer(c_int) :: rc
+    end function
     function mckpp_hip_set_forcing(handle, sflux) bind(C, name="mckpp_hip_set_forcing") result(rc)
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: handle

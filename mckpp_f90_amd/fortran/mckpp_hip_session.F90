@@ -12,12 +12,19 @@ module mckpp_hip_session
   private
   public :: mckpp_hip_attach, mckpp_hip_push_state, mckpp_hip_pull_state, mckpp_hip_detach
   public :: mckpp_hip_handle, mckpp_hip_check, mckpp_hip_output_mask, mckpp_hip_device
+  public :: mckpp_hip_push_ancillaries, mckpp_hip_ancillaries_every_step
   public :: mckpp_hip_const_view, mckpp_hip_state_view, l2i
 
   type(c_ptr), save :: mckpp_hip_handle = c_null_ptr
   integer(c_int), save :: mckpp_hip_output_mask = MCKPP_F_ALL   !< fields copied back after each driver call
   integer(c_int), save :: mckpp_hip_device = 0
   logical, save :: resident = .false.
+  !> The reference's time loop lets mckpp_boundary_update rewrite SST0, the climatologies and the flux
+  !! corrections on the host between steps (src/mckpp_ocean_model_3D.F90:51-55).  With this flag on
+  !! (default) mckpp_physics_driver re-sends those inputs before every step when an optional switch
+  !! reads them, so the device can never run on stale ancillaries; set it .false. and call
+  !! mckpp_hip_push_ancillaries at the ndtupd* cadences to save the per-step upload.
+  logical, save :: mckpp_hip_ancillaries_every_step = .true.
 
 contains
 
@@ -109,15 +116,30 @@ contains
     call mckpp_hip_check(mckpp_hip_init(c, mckpp_hip_device, mckpp_hip_handle), 'mckpp_hip_init')
   end subroutine mckpp_hip_attach
 
-  !> kpp_3d_fields -> HBM (once; afterwards the state lives on the device).
+  !> Optional-physics inputs only (relaxation, corrections, climatologies, advection): host -> HBM.
+  subroutine mckpp_hip_push_ancillaries()
+    type(mckpp_state_ptrs_c) :: s
+    if (.not. resident) return   ! the full upload that is still to come carries them
+    call mckpp_hip_state_view(kpp_3d_fields, npts, s)
+    call mckpp_hip_check(mckpp_hip_update_ancillaries(mckpp_hip_handle, s), 'mckpp_hip_update_ancillaries')
+  end subroutine mckpp_hip_push_ancillaries
+
+  !> kpp_3d_fields -> HBM (once; afterwards the state lives on the device).  A forced re-upload
+  !! first brings back every field group the per-step download left on the device, so host copies
+  !! that are older than the device state cannot overwrite it.
   subroutine mckpp_hip_push_state(force)
     logical, intent(in), optional :: force
     type(mckpp_state_ptrs_c) :: s
     logical :: doit
+    integer(c_int) :: missing
     doit = .not. resident
     if (present(force)) doit = doit .or. force
     if (.not. doit) return
     call mckpp_hip_attach()
+    if (resident) then
+      missing = iand(MCKPP_F_ALL, not(mckpp_hip_output_mask))
+      if (missing /= 0) call mckpp_hip_pull_state(missing)
+    end if
     call mckpp_hip_state_view(kpp_3d_fields, npts, s)
     call mckpp_hip_check(mckpp_hip_upload(mckpp_hip_handle, s), 'mckpp_hip_upload')
     resident = .true.

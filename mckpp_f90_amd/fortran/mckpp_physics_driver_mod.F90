@@ -14,6 +14,8 @@ module mckpp_physics_driver_mod
 contains
   subroutine mckpp_physics_driver()
     call mckpp_hip_push_state()
+    ! what mckpp_boundary_update may have rewritten since the last step (src/mckpp_ocean_model_3D.F90:51-55)
+    if (mckpp_hip_ancillaries_every_step) call mckpp_hip_push_ancillaries()
     ! forcing written by mckpp_fluxes into sflux(:,1:6,5,0) (src/mckpp_fluxes_mod.F90:62-69)
     call mckpp_hip_check(mckpp_hip_set_forcing(mckpp_hip_handle, kpp_3d_fields%sflux), 'mckpp_hip_set_forcing')
     call mckpp_hip_check(mckpp_hip_step(mckpp_hip_handle, int(ntime, c_int), 1_c_int), 'mckpp_hip_step')

@@ -275,3 +275,85 @@ def test_optional_physics_kernel_selection(mk, monkeypatch):
         ctx = mk.MckppHip(kc)
         assert ctx.kernel_name == want, (nz, ctx.kernel_name)
         ctx.close()
+
+
+def test_restart_and_ancillary_update_on_optional_physics_context(mk, tmp_path):
+    """A restart file loaded into a fresh optional-physics context: stepping is refused until the
+    relaxation inputs are resident (mckpp_hip_update_ancillaries), then continues bit-identically;
+    a changed ancillary (SST0 / climatology, what mckpp_boundary_update rewrites between steps,
+    src/mckpp_ocean_model_3D.F90:51-55) reaches the device without touching the prognostic state."""
+    from oracle import orc
+
+    ncol, nz = 96, 40
+    sw = dict(L_RELAX_SST=1, L_RELAX_OCNT=1)
+
+    def fill(k3, ob, dT):
+        n = k3.npts
+        r = np.full(n, 1.0 / (5 * 86400.0))
+        k3.relax_sst[:] = r
+        k3.relax_ocnT[:] = r / 6
+        k3.SST0[:] = T0[:, 0] + dT
+        k3.ocnT_clim[:, :] = T0 - 0.3 + dT
+        if ob is not None:
+            ob["relax_sst"] = r; ob["relax_ocnT"] = r / 6; ob["SST0"] = T0[:, 0] + dT
+            ob.a["ocnT_clim"][:, 1:nz + 2] = T0 - 0.3 + dT
+
+    oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1, **sw)
+    kc, k3 = cm.make_hip_case(ncol, nz, land_every=7)
+    for k, v in sw.items():
+        setattr(kc, k, v)
+    T0 = np.asarray(k3.X[:, :, 0]).copy()
+    fill(k3, ob, 1.5)
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    orc.init_ocean(oc, ob, 0)
+    sf = cm.synth.forcing(ncol, "bench")
+    ob["sflux"] = sf
+    cm.set_forcing_3d(k3, sf)
+    ctx.set_forcing(k3.sflux)
+    ctx.step(1, 2)
+    for nt in (1, 2):
+        orc.physics_driver(oc, ob, nt)
+    rst = tmp_path / "ext.restart"
+    ctx.save_restart(rst)
+
+    # (a) ancillaries change on the host between steps: only they are re-uploaded
+    fill(k3, ob, 0.4)
+    ctx.update_ancillaries(k3)
+    ctx.step(3, 1)
+    orc.physics_driver(oc, ob, 3)
+    ctx.download(k3)
+    ocean = np.flatnonzero(k3.run_physics)
+    res = cm.compare(k3, ob, nz, cm.PROFILE_FIELDS + cm.SCALAR_FIELDS + ["fcorr", "tinc_fcorr", "ocnTcorr"], active=ocean)
+    assert not {k: v for k, v in res.items() if v[2] != 0}, res
+
+    # (b) fresh optional-physics context + restart file
+    kc2, k3b = cm.make_hip_case(ncol, nz, land_every=7)
+    for k, v in sw.items():
+        setattr(kc2, k, v)
+    ctx2 = mk.MckppHip(kc2)
+    ctx2.load_restart(rst, ncol)
+    with pytest.raises(mk.MckppHipError, match="update_ancillaries"):
+        ctx2.step(3, 1)
+    fill(k3b, None, 0.4)
+    ctx2.update_ancillaries(k3b)
+    cm.set_forcing_3d(k3b, sf)
+    ctx2.step(3, 1)
+    ctx2.download(k3b)
+    for n in ("U", "X", "Us", "Xs", "hmix", "kmix", "Tref", "fcorr", "tinc_fcorr", "ocnTcorr"):
+        assert np.array_equal(getattr(k3, n)[ocean], getattr(k3b, n)[ocean]), n
+
+    # (c) a file with a corrupt column map or a truncated tail is refused and the resident state survives
+    raw = bytearray(rst.read_bytes())
+    hdr = 8 + 6 * 4 + 2 * 8
+    bad = bytearray(raw)
+    bad[hdr:hdr + 4] = (10 ** 6).to_bytes(4, "little")          # ipt[0] far outside npts
+    (tmp_path / "badmap").write_bytes(bad)
+    with pytest.raises(mk.MckppHipError, match="column map"):
+        ctx2.load_restart(tmp_path / "badmap", ncol)
+    (tmp_path / "short").write_bytes(raw[:len(raw) // 2])
+    with pytest.raises(mk.MckppHipError, match="truncated"):
+        ctx2.load_restart(tmp_path / "short", ncol)
+    k3c = cm.make_hip_case(ncol, nz, land_every=7)[1]
+    ctx2.download(k3c)
+    assert np.array_equal(k3c.X[ocean], k3b.X[ocean]) and np.array_equal(k3c.hmix[ocean], k3b.hmix[ocean])
+    ctx2.close()
