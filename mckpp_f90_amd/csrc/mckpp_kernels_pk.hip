@@ -1,0 +1,1072 @@
+// mckpp_kernels_pk.hip - packed-lane cooperative column kernel (any depth up to 190 levels).
+//
+// Lane map.  A water column needs L = nzp1 + 2 lanes (one per grid level plus the two
+// fresh-water / brine evaluations of the equation of state, verticalmixing_mod.F90:52-55).
+// The workgroup's 64*NW lanes are dealt to W = floor(64*NW / L) columns ("slots") back to
+// back: thread t works on slot t / L, level t % L + 1, so a 70-level column costs 72 lanes,
+// not two wavefronts, and a wavefront may carry the tail of one column and the head of the
+// next.  Nothing about a column is therefore wave-uniform: what the one-wave-per-column
+// kernels keep in scalar registers lives in a per-slot record in LDS, and
+//   * level-parallel phases ("L") run on every lane with a per-lane slot pointer;
+//   * everything that is one value per column - queue/refill, surface fluxes, the choice of
+//     hbl/kbl and the boundary-layer scalars of blmix, the ocnstep convergence control, the
+//     instability trap - runs in "manager" phases ("M") on wave 0 with a lane per slot, and
+//     the serial recurrences (bulk-Ri running maximum, Thomas sweeps) with a lane per
+//     (slot, system) as in the other cooperative kernels (mckpp_sweeps.h).  The slot-uniform
+//     work is thus paid once per workgroup instead of once per wave.
+// Phases are separated by workgroup barriers (11 per pass); slots are independent otherwise:
+// each carries its own iteration state and pulls its next column from the global queue.
+//
+// Arithmetic is identical, operation for operation, to k_column_wg / k_column_mw; the tests
+// require bit-identical results from all of them and from the CPU oracle.
+#include "mckpp_sweeps.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace {
+
+using namespace mckpp_dev;
+
+enum { PS_EMPTY = 0, PS_ACTIVE = 1, PS_DONE = 2 };
+enum { F_NONE = 0, F_TRAP = 1, F_FINAL = 2 };
+
+// per-slot double record
+enum {
+  C_B0 = 0, C_B0SOL, C_USTAR, C_UFRAC, C_UCUBE, C_HEK, C_WU01, C_WU02, C_WX01, C_WX02, C_WXNT0, C_UREFNZ, C_VREFNZ,
+  C_RHO0CP0, C_RRC, X_RHO0, X_CP0, X_TALPHA0, X_SBETA0, X_RHOH2O, X_RHOB,
+  C_F, C_HMIXE, C_HMIXN, C_HBL, C_RHBL, C_STABLE, C_BFSFC, C_CASEA,
+  C_GAT1, C_DAT1 = C_GAT1 + 3, C_DKM1 = C_DAT1 + 3,
+  C_SREF = C_DKM1 + 3, C_SSURF, C_OCDEPTH, C_SFLUX1, C_SFLUX2, C_SFLUX3, C_SFLUX4, C_SFLUX5, C_SFLUX6,
+  C_COUNT
+};
+// per-slot int record
+enum {
+  I_STATE = 0, I_ACT, I_COL, I_OLD, I_NEW, I_JER, I_INITFLAG, I_STATUS, I_NPASS, I_NPASS_TRY, I_ICONV, I_COMP, I_KMIXN,
+  I_KBL, I_NRESET, I_FIN, I_MAYBE, I_LOAD /* 1: new column, 2: restart the iteration (trap retry) */, I_JU,
+  I_KBLC, I_NVIOL, I_NU, I_NV, I_NF, I_BAD, I_LOCEAN, I_COUNT
+};
+enum { R_RHO = R_COUNT, R_CP, R_COUNT_EXT };   // rho, cp rows of the optional-physics build
+// Row aliases of this kernel.  The two EOS lanes of a column read the previous temperature solution yT(1)
+// in the phase in which the level lanes publish U, V, buoyancy: nothing may be written to R_YT there, so V
+// goes to R_YV (its own relaxation memory, consumed by the same lane just before).
+enum { R_PV = R_YV, R_RAW = R_RB /* bulk Ri, free until the Thomas sweep */, R_H = R_YV /* hmin candidates */,
+       R_LA = R_DM /* LDD: talpha of the level below */ };
+
+// host and device agree on the LDS layout through these
+__host__ __device__ inline int pk_rows(bool ext) { return ext ? (int)R_COUNT_EXT : (int)R_COUNT; }
+__host__ __device__ inline int pk_na(int L) { return (L + 2) | 1; }   // indices 0..L+1, odd
+__host__ __device__ inline int pk_ss(int L, bool ext)
+{
+  // lane (slot s, system m) of the serial sweeps touches slot*SS + m*NA + i: with NA odd and
+  // SS = 3*NA (mod 32 doubles) up to ten slots x three systems fall on distinct banks
+  const int na = pk_na(L);
+  int s = pk_rows(ext) * na;
+  while ((s & 31) != ((3 * na) & 31)) ++s;
+  return s;
+}
+__host__ __device__ inline size_t pk_lds_bytes(int L, int W, bool ext)
+{
+  return (size_t)(6 * pk_na(L) + 2 + W * pk_ss(L, ext) + W * C_COUNT) * sizeof(double) +
+         (size_t)(W * I_COUNT + 4) * sizeof(int);
+}
+
+template <bool EXT>
+__global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__restrict__ pp, const int ntime, const int L,
+                                                     const int W)
+{
+  const mckpp_kparams &p = *pp;
+  extern __shared__ double lds[];
+  const int NA = pk_na(L), SS = pk_ss(L, EXT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nz = p.nz, nzp1 = p.nzp1;
+  double *c_zm = lds, *c_hm = lds + NA, *c_t0 = lds + 2 * NA, *c_t1 = lds + 3 * NA;
+  double *c_rdz = lds + 4 * NA, *c_dtohk = lds + 5 * NA, *c_misc = lds + 6 * NA;
+  double *slots = lds + 6 * NA + 2;
+  double *screc = slots + W * SS;
+  int *sirec = reinterpret_cast<int *>(screc + W * C_COUNT);
+  int *s_flags = sirec + W * I_COUNT;   // [0] some slot active, [1] some slot finishing
+
+  for (int i = tid; i < NA; i += blockDim.x) {
+    c_zm[i] = p.zm[i];
+    c_hm[i] = p.hm[i];
+    c_t0[i] = p.tri0[i];
+    c_t1[i] = p.tri1[i];
+    c_rdz[i] = rcp_refine(p.zm[i] - p.zm[i + 1]);
+    c_dtohk[i] = p.dto / p.hm[i];
+  }
+  if (tid == 0) { c_misc[0] = rcp_refine(p.hm[1]); c_misc[1] = rcp_refine(p.vonk); }
+  for (int i = tid; i < W * I_COUNT; i += blockDim.x) sirec[i] = 0;   // every slot PS_EMPTY
+  if (tid < 4) s_flags[tid] = 0;
+
+  // ---- lane -> (slot, level) ------------------------------------------------
+  int slot = tid / L;
+  int k0 = tid - slot * L + 1;
+  const bool alive = slot < W;
+  if (!alive) { slot = 0; k0 = 1; }   // spare lanes of the last wave: compute on slot 0, store nothing
+  const bool act = alive && k0 <= nzp1, actz = alive && k0 <= nz;
+  const bool virt1 = alive && k0 == nzp1 + 1, virt2 = alive && k0 == nzp1 + 2;
+  const bool actT = alive;                 // the two EOS lanes carry the level-1 temperature
+  const bool is1 = alive && k0 == 1, isnz = alive && k0 == nz, isnzp1 = alive && k0 == nzp1;
+  const int kr = act ? k0 : 1;             // level whose temperature this lane holds
+  double *my = slots + slot * SS;
+  double *sc = screc + slot * C_COUNT;
+  int *si = sirec + slot * I_COUNT;
+  auto row = [&](int a) -> double * { return my + a * NA; };
+  double *aDm = row(R_DM), *aDs = row(R_DS), *aDt = row(R_DT), *aGh = row(R_GH);
+  double *aU = row(R_U), *aV = row(R_PV), *aB = row(R_B), *aR = row(R_R), *aDb = row(R_DB), *aDmo = row(R_DMO),
+         *aT = row(R_T), *aRaw = row(R_RAW), *aH = row(R_H);
+  __syncthreads();
+
+  int k = k0;
+  double U = 0, V = 0, T = 0, S = 0, talpha = 0, sbeta = 0;
+  double buoy = 0, Ritop = 0, dVsq = 0, dbloc = 0, Rig = 0, zdiff = 0, zmk = 0;
+  double dm_i = 0, ds_i = 0, dt_i = 0, difm = 0, difs = 0, dift = 0, ghat = 0;
+  double alphaDT = 0, betaDS = 0, xt = 0;
+  int col = 0;
+  const double lambda = 0.5;
+  const double epsln16 = 1.e-16, Ricr = 0.30, eps01 = 0.1, cekman = 0.7, cmonob = 1.0, epsln20 = 1.e-20;
+  const bool do_ocnint = p.mode != MCKPP_MODE_INIT;
+
+  auto rowoff = [&]() -> size_t { return (size_t)col * p.ld; };
+  auto ld_old = [&](const double *src) -> double { return act ? src[(size_t)col * p.ld + (k - 1)] : 0.0; };
+
+  // =========================== manager phases (wave 0) ===========================
+  // M0: slots whose column has finished pull the next one from the queue (refill of k_column_wg)
+  auto M0 = [&]() {
+    bool a = false;
+    if (lane < W) {
+      int *msi = sirec + lane * I_COUNT;
+      double *msc = screc + lane * C_COUNT;
+      int st = msi[I_STATE];
+      if (st == PS_ACTIVE && msi[I_FIN] == F_FINAL) st = PS_EMPTY;   // its outputs are stored (barrier before M0)
+      if (st == PS_EMPTY) {
+        const int c = atomicAdd(p.qhead, 1);
+        msi[I_FIN] = F_NONE;
+        if (c >= p.ncol) {
+          st = PS_DONE;
+          msi[I_ACT] = 0;
+        } else {
+          st = PS_ACTIVE;
+          const int *ci = p.ci + (size_t)c * MCKPP_CI;
+          const double *cs = p.cs + (size_t)c * MCKPP_CS;
+          int old = ci[CI_OLD], newi = ci[CI_NEW], status = 0;
+          if (old < 0 || old > 1) { old = newi; status |= 16; }
+          if (newi < 0 || newi > 1) { newi = old; status |= 16; }
+          msi[I_ACT] = 1; msi[I_COL] = c; msi[I_OLD] = old; msi[I_NEW] = newi; msi[I_JER] = ci[CI_JERLOV];
+          msi[I_INITFLAG] = (p.mode == MCKPP_MODE_INIT) ? 1 : ci[CI_INITFLAG];   // initialize_ocean.F90:59
+          msi[I_LOCEAN] = ci[CI_LOCEAN];
+          msi[I_STATUS] = status; msi[I_NPASS] = 0; msi[I_NPASS_TRY] = 0; msi[I_ICONV] = 0; msi[I_COMP] = 1;
+          msi[I_NRESET] = 0; msi[I_KMIXN] = 0; msi[I_KBL] = 0; msi[I_LOAD] = 1; msi[I_BAD] = 0;
+          msi[I_MAYBE] = (p.mode != MCKPP_MODE_STEP) ? 1 : 0;
+          msi[I_KBLC] = 0x7fffffff; msi[I_NVIOL] = 0; msi[I_NU] = 0; msi[I_NV] = 0; msi[I_NF] = 0;
+          msc[C_F] = cs[CS_F]; msc[C_WXNT0] = 0.0; msc[C_HMIXE] = 0.0; msc[C_HMIXN] = 0.0;
+          msc[C_SREF] = cs[CS_SREF]; msc[C_SSURF] = cs[CS_SSURF]; msc[C_OCDEPTH] = cs[CS_OCDEPTH];
+          msc[C_SFLUX1] = cs[CS_SFLUX1]; msc[C_SFLUX2] = cs[CS_SFLUX2]; msc[C_SFLUX3] = cs[CS_SFLUX3];
+          msc[C_SFLUX4] = cs[CS_SFLUX4]; msc[C_SFLUX5] = cs[CS_SFLUX5]; msc[C_SFLUX6] = cs[CS_SFLUX6];
+        }
+        msi[I_STATE] = st;
+      }
+      a = st == PS_ACTIVE;
+    }
+    const unsigned long long m = __ballot(a);
+    if (lane == 0) { s_flags[0] = m != 0ull ? 1 : 0; s_flags[1] = 0; }
+  };
+
+  // M1: surface fluxes and friction velocity (verticalmixing_mod.F90:81-100), wXNT(0) (fluxes_mod.F90:110-116)
+  auto M1 = [&]() {
+    if (lane < W) {
+      int *msi = sirec + lane * I_COUNT;
+      double *msc = screc + lane * C_COUNT;
+      if (msi[I_ACT]) {
+        msi[I_LOAD] = 0;
+        const double rho0 = msc[X_RHO0], cp0 = msc[X_CP0], talpha0 = msc[X_TALPHA0], sbeta0 = msc[X_SBETA0];
+        const double rhoh2o = msc[X_RHOH2O], rhob = msc[X_RHOB];
+        const double sflux1 = msc[C_SFLUX1], sflux2 = msc[C_SFLUX2], sflux3 = msc[C_SFLUX3], sflux4 = msc[C_SFLUX4],
+                     sflux5 = msc[C_SFLUX5], sflux6 = msc[C_SFLUX6];
+        const double Ssurf = msc[C_SSURF];
+        const double r_rho0 = rcp_refine(rho0), rho0cp0 = rho0 * cp0, r_rc = rcp_refine(rho0cp0);
+        const double wU0_1 = div_fast(-sflux1, rho0, r_rho0);
+        const double wU0_2 = div_fast(-sflux2, rho0, r_rho0);
+        const double tau = __builtin_sqrt(sflux1 * sflux1 + sflux2 * sflux2) + 1.e-16;
+        const double ustar = __builtin_sqrt(div_fast(tau, rho0, r_rho0));
+        const double wX0_1 = div_fast(div_fast(-sflux4, rho0, r_rho0), cp0, rcp_refine(cp0));
+        const double wX0_2 = div_fast(Ssurf * sflux6, rhoh2o, rcp_refine(rhoh2o)) +
+                             div_fast((Ssurf - p.sice) * sflux5, rhob, rcp_refine(rhob));
+        const double B0 = -p.grav * (talpha0 * wX0_1 - sbeta0 * wX0_2);
+        const double B0sol = div_fast(p.grav * talpha0 * sflux3, rho0cp0, r_rc);
+        const wscale_u wu = wscale_prepare(ustar);
+        const double fa = __builtin_fabs(msc[C_F]) + epsln16;
+        msc[C_B0] = B0; msc[C_B0SOL] = B0sol; msc[C_USTAR] = ustar; msc[C_UFRAC] = wu.ufrac; msc[C_UCUBE] = wu.ucube;
+        msi[I_JU] = wu.ju;
+        msc[C_HEK] = div_fast(cekman * ustar, fa, rcp_refine(fa));   // Ekman depth scale, bldepth_mod.F90:158
+        msc[C_WU01] = wU0_1; msc[C_WU02] = wU0_2; msc[C_WX01] = wX0_1; msc[C_WX02] = wX0_2;
+        msc[C_RHO0CP0] = rho0cp0; msc[C_RRC] = r_rc;
+        if (ntime >= 1) msc[C_WXNT0] = div_fast(-sflux3 * p.swdk_tab[msi[I_JER] * p.ldc], rho0cp0, r_rc);
+      }
+    }
+  };
+
+  // M3: boundary-layer depth from the first level with hmin < -zm(k) (bldepth_mod.F90:161-201) and the
+  //     slot-uniform part of blmix (blmix_mod.F90:62-100, 136-149)
+  auto M3 = [&]() {
+    if (lane < W) {
+      int *msi = sirec + lane * I_COUNT;
+      double *msc = screc + lane * C_COUNT;
+      if (msi[I_ACT]) {
+        const double *mrow = slots + lane * SS;
+        const int kc = msi[I_KBLC];
+        msi[I_KBLC] = 0x7fffffff;
+        int kbl = nz;
+        double hbl = -c_zm[nz];
+        if (kc <= nz) { kbl = kc; hbl = mrow[R_H * NA + kc]; }
+        msi[I_KBL] = kbl;
+        msc[C_HBL] = hbl;
+        const int jer = msi[I_JER];
+        const double B0 = msc[C_B0], B0sol = msc[C_B0SOL], ustar = msc[C_USTAR];
+        wscale_u wu;
+        wu.ju = msi[I_JU]; wu.ufrac = msc[C_UFRAC]; wu.ustar = ustar; wu.ucube = msc[C_UCUBE];
+        double bfsfc = swfrac_dev(-1.0, hbl, jer);
+        bfsfc = B0 + B0sol * (1. - bfsfc);
+        const double stable = 0.5 + dsign(0.5, bfsfc);
+        bfsfc = bfsfc + stable * epsln16;
+        const double caseA = 0.5 + dsign(0.5, -c_zm[kbl] - 0.5 * c_hm[kbl] - hbl);
+        double gat1[3], dat1[3];
+        const double r_hbl = rcp_refine(hbl);
+        {
+          double wm, ws;
+          double sigma = stable * 1.0 + (1. - stable) * eps01;
+          wscale_dev(p, wu, sigma, hbl, bfsfc, wm, ws);
+          int ifx = (int)(caseA + epsln20);
+          int kn = ifx * (kbl - 1) + (1 - ifx) * kbl;
+          double hmkn = c_hm[kn], hmkn1 = c_hm[kn + 1];
+          const double r_hmkn = rcp_refine(hmkn), r_hmkn1 = rcp_refine(hmkn1);
+          double delhat = 0.5 * hmkn - c_zm[kn] - hbl;
+          double R = 1.0 - div_fast(delhat, hmkn, r_hmkn);
+          const double *dd[3] = {mrow + R_DM * NA, mrow + R_DS * NA, mrow + R_DT * NA};
+          double dp[3], dh[3];
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            double dvdzup = div_fast(dd[m][kn - 1] - dd[m][kn], hmkn, r_hmkn);
+            double dvdzdn = div_fast(dd[m][kn] - dd[m][kn + 1], hmkn1, r_hmkn1);
+            dp[m] = 0.5 * ((1. - R) * (dvdzup + __builtin_fabs(dvdzup)) + R * (dvdzdn + __builtin_fabs(dvdzdn)));
+            dh[m] = dd[m][kn] + dp[m] * delhat;
+          }
+          double u4 = ((ustar * ustar) * ustar) * ustar;
+          const double u4e = u4 + epsln20, wme = wm + epsln20, wse = ws + epsln20;
+          const double r_wme = rcp_refine(wme), r_wse = rcp_refine(wse);
+          double f1 = div_fast(stable * 5.0 * bfsfc, u4e, rcp_refine(u4e));
+          gat1[0] = div_fast(div_fast(dh[0], hbl, r_hbl), wme, r_wme);
+          dat1[0] = div_fast(-dp[0], wme, r_wme) + f1 * dh[0];
+          dat1[0] = dmin2(dat1[0], 0.);
+          gat1[1] = div_fast(div_fast(dh[1], hbl, r_hbl), wse, r_wse);
+          dat1[1] = div_fast(-dp[1], wse, r_wse) + f1 * dh[1];
+          dat1[1] = dmin2(dat1[1], 0.);
+          gat1[2] = div_fast(div_fast(dh[2], hbl, r_hbl), wse, r_wse);
+          dat1[2] = div_fast(-dp[2], wse, r_wse) + f1 * dh[2];
+          dat1[2] = dmin2(dat1[2], 0.);
+        }
+        {
+          double wm, ws;
+          double sig = div_fast(-c_zm[kbl - 1], hbl, r_hbl);
+          double sigma = stable * sig + (1. - stable) * dmin2(sig, eps01);
+          wscale_dev(p, wu, sigma, hbl, bfsfc, wm, ws);
+          double a1 = sig - 2.;
+          double a2 = 3. - 2. * sig;
+          double a3 = sig - 1.;
+          double Gm = a1 + a2 * gat1[0] + a3 * dat1[0];
+          double Gs = a1 + a2 * gat1[1] + a3 * dat1[1];
+          double Gt = a1 + a2 * gat1[2] + a3 * dat1[2];
+          msc[C_DKM1 + 0] = hbl * wm * sig * (1. + sig * Gm);
+          msc[C_DKM1 + 1] = hbl * ws * sig * (1. + sig * Gs);
+          msc[C_DKM1 + 2] = hbl * ws * sig * (1. + sig * Gt);
+        }
+        msc[C_RHBL] = r_hbl; msc[C_STABLE] = stable; msc[C_BFSFC] = bfsfc; msc[C_CASEA] = caseA;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { msc[C_GAT1 + m] = gat1[m]; msc[C_DAT1 + m] = dat1[m]; }
+      }
+    }
+  };
+
+  // G: ocnstep control after a pass (ocnstep_mod.F90:122-192), one lane per slot
+  auto G = [&]() {
+    bool f_any = false;
+    if (lane < W) {
+      int *msi = sirec + lane * I_COUNT;
+      double *msc = screc + lane * C_COUNT;
+      if (msi[I_ACT]) {
+        int fin = F_NONE;
+        int status = msi[I_STATUS], npass_try = msi[I_NPASS_TRY], iconv = msi[I_ICONV];
+        if (p.mode != MCKPP_MODE_INIT && msi[I_BAD]) status |= 1;
+        msi[I_BAD] = 0;
+        msi[I_NPASS] = msi[I_NPASS] + 1;
+        if (p.mode != MCKPP_MODE_STEP) {
+          fin = F_FINAL;
+        } else {
+          ++npass_try;
+          const double hbl = msc[C_HBL];
+          if (npass_try <= 3) {   // compulsory passes
+            msc[C_HMIXE] = hbl;
+          } else {
+            const double hmixn = hbl, hmixe = msc[C_HMIXE];
+            const int kmixn = msi[I_KBL];
+            msc[C_HMIXN] = hmixn;
+            msi[I_KMIXN] = kmixn;
+            double tol = p.hmixtolfrac * c_hm[kmixn];
+            if (kmixn == nzp1) tol = p.hmixtolfrac * c_hm[nz];
+            if (__builtin_fabs(hmixn - hmixe) > tol) iconv = 0;
+            else iconv = iconv + 1;
+            bool go_on = false;
+            if (iconv < 3) {
+              if (npass_try < p.itermax) { msc[C_HMIXE] = hmixn; go_on = true; }
+              else if (hmixn > hmixe) { msc[C_HMIXE] = hmixn; go_on = true; }
+            }
+            if (!go_on) {
+              if (npass_try > (p.itermax + 1)) status |= 2;
+              fin = F_TRAP;
+              msi[I_NVIOL] = 0;
+            }
+          }
+          msi[I_MAYBE] = (npass_try >= 3 && (iconv >= 2 || npass_try + 1 >= p.itermax)) ? 1 : 0;
+        }
+        msi[I_STATUS] = status; msi[I_NPASS_TRY] = npass_try; msi[I_ICONV] = iconv;
+        msi[I_FIN] = fin;
+        f_any = fin != F_NONE;
+      }
+    }
+    const unsigned long long m = __ballot(f_any);
+    if (lane == 0) s_flags[1] = m != 0ull ? 1 : 0;
+  };
+
+  // ---- optional terms of the T and S right-hand sides (ocnint_mod.F90:97-215), level k of this lane:
+  // relaxation / flux corrections / prescribed advection (rhsmod, solvers.F90:176-335, salinity only)
+  auto ext_rhs = [&](int kmixe, double To_k, double So_k, double &rhsT, double &rhsS) {
+    const double dto = p.dto;
+    const double *xs = p.xs + (size_t)col * MCKPP_XS;
+    const double *aRho = row(R_RHO), *aCp = row(R_CP);
+    const double rhok = aRho[k], cpk = aCp[k];
+    const size_t oin = rowoff() + (k - 1);
+    if (k == 1) {
+      if (p.L_RELAX_SST && !p.L_FCORR_WITHZ && !p.L_FCORR) {   // :97-114
+        const double relax_sst = xs[XS_RELAX_SST], SST0 = xs[XS_SST0];
+        double fc = 0.0;
+        if (relax_sst > 1.e-10) {
+          if (!p.L_RELAX_CALCONLY) rhsT = rhsT + dto * relax_sst * (SST0 - To_k) * p.dm[kmixe] / c_hm[1];
+          fc = relax_sst * (SST0 - To_k) * p.dm[kmixe] * rhok * cpk;
+        }
+        p.cs[(size_t)col * MCKPP_CS + CS_FCORR] = fc;
+      }
+      if (p.L_FCORR && !p.L_RELAX_SST && !p.L_FCORR_WITHZ)     // :121-125
+        rhsT = rhsT + dto * xs[XS_FCORR_TWOD] / (rhok * cpk * c_hm[1]);
+    }
+    double tinc = 0.;                                           // :133-160
+    if (p.L_FCORR_WITHZ && !p.L_FCORR) tinc = dto * p.fcorr_withz[oin] / (rhok * cpk);
+    if (p.L_RELAX_OCNT) tinc = tinc + dto * xs[XS_RELAX_OCNT] * (p.ocnT_clim[oin] - To_k);
+    rhsT = rhsT + tinc;
+    xt = tinc;
+    const double ocnTcorr = tinc * rhok * cpk / dto;
+    // prescribed advection of salinity, rhsmod with jsclr = 2 (:179-184)
+    const int *ai = p.adv_i + (size_t)col * (p.maxmodeadv + 1);
+    const double *ad = p.adv_d + (size_t)col * (p.maxmodeadv + 1);
+    const int nmode = ai[0];
+    const int nzi = nz, km = kmixe;
+    for (int im = 0; im < nmode; ++im) {
+      const int mode = ai[1 + im];
+      if (mode <= 0) continue;
+      const double fact = dto * ad[im] * 0.033;
+      if (mode == 1) {
+        if (k == 1) rhsS = rhsS + fact / c_hm[1];
+      } else if (mode == 2) {
+        const double delta = p.hsum[km - 1];
+        if (k <= km - 1) rhsS = rhsS + fact / delta;
+      } else if (mode == 3) {
+        const double delta = p.hsum[nzi];
+        if (k <= nzi) rhsS = rhsS + fact / delta;
+      } else if (mode == 4) {
+        const int nzend = nzi - 1;
+        int n1 = 0;
+        do { n1 = n1 + 1; } while (c_zm[n1] >= -100. && n1 < nzp1);
+        double delta = 0.0;
+        for (int n = n1; n <= nzend; ++n) delta = delta + c_hm[n];
+        if (k >= n1 && k <= nzend) rhsS = rhsS + fact / delta;
+      } else if (mode == 5) {
+        if (k == nzi) rhsS = rhsS + fact / c_hm[nzi];
+      } else if (mode == 6 || mode == 7) {
+        int n1, n2 = 0;
+        double depth, dmax, delta = 0.0;
+        if (mode == 6) { n1 = 1; depth = c_hm[1]; dmax = p.dm[km] - 0.5 * (c_hm[km] + c_hm[km - 1]); }
+        else { n1 = km - 1; depth = p.dm[km] - 0.5 * c_hm[km]; dmax = 100.; }
+        for (int n = n1; n <= nzi; ++n) {
+          n2 = n;
+          delta = delta + c_hm[n];
+          depth = depth + c_hm[n + 1];
+          if (depth >= dmax) break;
+        }
+        if (k >= n1 && k <= n2) rhsS = rhsS + fact / delta;
+      }
+    }
+    double sinc = 0.;                                           // :187-213
+    if (p.L_SFCORR_WITHZ && !p.L_SFCORR) sinc = dto * p.sfcorr_withz[oin];
+    if (p.L_RELAX_SAL) sinc = sinc + dto * xs[XS_RELAX_SAL] * (p.sal_clim[oin] - So_k);
+    rhsS = rhsS + sinc;
+    if (si[I_MAYBE]) {
+      const size_t o = rowoff() + k;
+      p.tinc_fcorr[o] = tinc; p.ocnTcorr[o] = ocnTcorr; p.sinc_fcorr[o] = sinc; p.scorr[o] = sinc / dto;
+    }
+  };
+
+  // =========================== persistent pass loop ===========================
+  if (wv == 0) M0();
+  __syncthreads();
+  for (;;) {
+    if (!s_flags[0]) break;
+    k = k0;
+    asm volatile("" : "+v"(k));   // keeps the k-indexed grid-constant LDS reads inside the loop
+    const bool active = si[I_ACT] != 0;
+
+    // ---- L1: (new column: load, ocnstep_mod.F90:91-112 extrapolation) under-relaxation, equation of state
+    if (active) {
+      col = si[I_COL];
+      const int ldf = si[I_LOAD];
+      if (ldf == 1) {
+        const size_t o = rowoff() + (kr - 1);
+        U = act ? p.U[o] : 0.0; V = act ? p.V[o] : 0.0; T = actT ? p.T[o] : 0.0; S = act ? p.S[o] : 0.0;
+      }
+      if (ldf != 0 && p.mode == MCKPP_MODE_STEP) {   // also seeds the solution rows (see k_column_wg)
+        const int old = si[I_OLD], newi = si[I_NEW];
+        const size_t o = rowoff() + (kr - 1);
+        const double uo = act ? p.Us[old][o] : 0.0, un = act ? p.Us[newi][o] : 0.0;
+        const double vo = act ? p.Vs[old][o] : 0.0, vn = act ? p.Vs[newi][o] : 0.0;
+        const double to = actT ? p.Ts[old][o] : 0.0, tn = actT ? p.Ts[newi][o] : 0.0;
+        const double so = act ? p.Ss[old][o] : 0.0, sn = act ? p.Ss[newi][o] : 0.0;
+        U = 2. * un - uo;
+        V = 2. * vn - vo;
+        T = 2. * tn - to;
+        S = 2. * sn - so;
+        if (act) { row(R_YU)[k] = U; row(R_YV)[k] = V; row(R_YT)[k] = T; row(R_YS)[k] = S; }
+      }
+      if (p.mode == MCKPP_MODE_STEP) {   // under-relaxation, ocnstep_mod.F90:123-132 / :142-151
+        if (act) {
+          U = lambda * U + (1 - lambda) * row(R_YU)[k];
+          V = lambda * V + (1 - lambda) * row(R_YV)[k];
+          S = lambda * S + (1 - lambda) * row(R_YS)[k];
+        }
+        // an EOS lane follows level 1; right after an extrapolation level 1's row entry is being
+        // written by another lane in this very phase and equals this lane's own T
+        const double yt = (!act && ldf != 0) ? T : row(R_YT)[kr];
+        if (actT) T = lambda * T + (1 - lambda) * yt;
+      }
+      const double Sref = sc[C_SREF];
+      const double zm1 = c_zm[1];
+      zmk = c_zm[k];
+      double Sin = S + Sref, Pin = -zmk;
+      const double Tin = T;
+      if (virt1) { Sin = 0.0; Pin = -zm1; }
+      if (virt2) { Sin = p.sice; Pin = -zm1; }
+      double s0;
+      abk80_dev(Sin, Tin, Pin, talpha, sbeta, s0);
+      const double rho = 1000. + s0;
+      const double cp = cpsw_dev(Sin, Tin, Pin);
+      buoy = div_fast(-p.grav * s0, 1000., 1. / 1000.);
+      if (is1) { sc[X_RHO0] = rho; sc[X_CP0] = cp; sc[X_TALPHA0] = talpha; sc[X_SBETA0] = sbeta; }
+      if (virt1) sc[X_RHOH2O] = rho;
+      if (virt2) sc[X_RHOB] = rho;
+      if (act) { aU[k] = U; aV[k] = V; aB[k] = buoy; }
+      if (p.diag && si[I_MAYBE]) {   // what the last vmix leaves behind (types_transfer.F90:199-327)
+        const size_t o = rowoff() + k;
+        if (act) { p.rho[o] = rho; p.cp[o] = cp; p.buoy[o] = buoy; p.talpha[o] = talpha; p.sbeta[o] = sbeta; }
+        if (is1) { p.rho[o - 1] = rho; p.cp[o - 1] = cp; p.talpha[o - 1] = talpha; p.sbeta[o - 1] = sbeta; }
+      }
+      if constexpr (EXT) {
+        if (act) { row(R_RHO)[k] = rho; row(R_CP)[k] = cp; }
+        if (p.LDD && act) {   // neighbours for alphaDT, betaDS
+          row(R_LA)[k] = talpha; row(R_RB)[k] = sbeta; row(R_GH)[k] = S; aT[k] = T;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- M1 | L2: surface fluxes (wave 0) | reference-level loop, Ri pieces (verticalmixing_mod.F90:111-137)
+    if (wv == 0) M1();
+    if (active) {
+      const double zm1 = c_zm[1];
+      const double U1 = aU[1], V1 = aV[1], Bu1 = aB[1];
+      const double zref = eps01 * zmk, rzref = rcp_refine(zref);
+      double wz = dmax2(zm1, zref);
+      double ur = div_fast_guarded(U1 * wz, zref, rzref), vr = div_fast_guarded(V1 * wz, zref, rzref),
+             br = div_fast(Bu1 * wz, zref, rzref);
+      bool live = actz;
+      double zk = zm1, Uk = U1, Vk = V1, Bk = Bu1;
+      for (int kl = 1; kl <= nz; ++kl) {
+        live = live && !(zref >= zk);
+        if (!__any(live)) break;
+        const double zk1 = c_zm[kl + 1], Uk1 = aU[kl + 1], Vk1 = aV[kl + 1], Bk1 = aB[kl + 1];
+        if (live) {
+          const double dzk = zk - zk1, rdzk = c_rdz[kl];
+          double wz2 = dmin2(zk - zk1, zk - zref);
+          double del = div_fast(0.5 * wz2, dzk, rdzk);
+          ur = ur - div_fast_guarded(wz2 * (Uk + del * (Uk1 - Uk)), zref, rzref);
+          vr = vr - div_fast_guarded(wz2 * (Vk + del * (Vk1 - Vk)), zref, rzref);
+          br = br - div_fast(wz2 * (Bk + del * (Bk1 - Bk)), zref, rzref);
+        }
+        zk = zk1; Uk = Uk1; Vk = Vk1; Bk = Bk1;
+      }
+      if constexpr (EXT) {
+        alphaDT = 0.0; betaDS = 0.0;
+        if (p.LDD) {   // verticalmixing_mod.F90:103-108
+          alphaDT = 0.5 * (talpha + row(R_LA)[k + 1]) * (T - aT[k + 1]);
+          betaDS = 0.5 * (sbeta + row(R_RB)[k + 1]) * (S - row(R_GH)[k + 1]);
+        }
+      }
+      const double bk1 = aB[k + 1], uk1 = aU[k + 1], vk1 = aV[k + 1];
+      Ritop = (zref - zmk) * (br - buoy);
+      dbloc = buoy - bk1;
+      dVsq = (ur - U) * (ur - U) + (vr - V) * (vr - V);
+      const double shsq = (U - uk1) * (U - uk1) + (V - vk1) * (V - vk1);
+      if (p.mode != MCKPP_MODE_STEP && isnz) { sc[C_UREFNZ] = ur; sc[C_VREFNZ] = vr; }
+      zdiff = zmk - c_zm[k + 1];
+      const double shs = shsq + 1.e-16;
+      Rig = div_fast(dbloc * zdiff, shs, rcp_refine(shs));
+      if (actz) { aR[k] = Rig; aDb[k] = dbloc; }
+      if (is1) aR[0] = 0.0;
+      if (isnzp1) aR[k] = 0.0;
+      if (p.diag && si[I_MAYBE]) {
+        const size_t o = rowoff() + k;
+        if (actz) { p.Rig[o] = Rig; p.dbloc[o] = dbloc; p.Shsq[o] = shsq; }
+      }
+    }
+    __syncthreads();
+
+    // ---- L3: rimix + z121 (rimix_mod.F90:13-106, z121_mod.F90:7-45), ddmix, interior diffusivity rows;
+    //          bldepth, level-parallel part (bldepth_mod.F90:105-147)
+    if (active) {
+      const double Riinfty = 0.8;
+      double vm1 = aR[k - 1], vp1 = aR[k + 1];
+      double wm1 = (k - 1 >= 1 && !((vm1 < 0.0) || (vm1 > Riinfty))) ? 1.0 : 0.0;
+      double wp1 = (k + 1 <= nz && !((vp1 < 0.0) || (vp1 > Riinfty))) ? 1.0 : 0.0;
+      double sm = wm1 * vm1 + 2. * Rig + wp1 * vp1;
+      double wait = wm1 + 2.0 + wp1;
+      sm = div_fast(sm, wait, wait == 3.0 ? 1. / 3. : (wait == 2.0 ? 0.5 : 0.25));
+      double Rigg = dmax2(sm, 0.0);
+      double ratio = dmin2(div_fast(Rigg, Riinfty, 1. / Riinfty), 1.0);
+      double fri = (1.0 - ratio * ratio);
+      fri = fri * fri * fri;
+      dm_i = (0.0001 + fri * 0.005);
+      ds_i = (0.00001 + fri * 0.005);
+      if constexpr (EXT) {
+        dt_i = ds_i;   // dift = difs, rimix_mod.F90:95-97
+        if (p.LDD) {   // ddmix_mod.F90:12-52
+          const double Rrho0 = 1.9, dsfmax = 1.0e-4;
+          const double aDT = alphaDT, bDS = betaDS;
+          if ((aDT > bDS) && (bDS > 0.)) {
+            double Rrho = dmin2(aDT / bDS, Rrho0);
+            double rr = ((Rrho - 1) / (Rrho0 - 1));
+            double diffdd = 1.0 - rr * rr;
+            diffdd = dsfmax * diffdd * diffdd * diffdd;
+            dt_i = dt_i + diffdd * 0.8 / Rrho;
+            ds_i = ds_i + diffdd;
+          } else if ((aDT < 0.0) && (bDS < 0.0) && (aDT < bDS)) {
+            double Rrho = aDT / bDS;
+            double diffdd = 1.5e-6 * 9.0 * 0.101 * mckpp_exp(4.6 * mckpp_exp(-0.54 * (1 / Rrho - 1)));
+            double prandtl = 0.15 * Rrho;
+            if (Rrho > 0.5) prandtl = (1.85 - 0.85 / Rrho) * Rrho;
+            dt_i = dt_i + diffdd;
+            ds_i = ds_i + prandtl * diffdd;
+          }
+        }
+      }
+      const double dt_l = EXT ? dt_i : ds_i;
+      if (actz) { aDm[k] = dm_i; aDs[k] = ds_i; aDt[k] = dt_l; }
+      if (isnz) { aDm[k + 1] = dm_i; aDs[k + 1] = ds_i; aDt[k + 1] = dt_l; }   // kppmix_mod.F90:82-84
+      if (is1) { aDm[0] = 0.0; aDs[0] = 0.0; aDt[0] = 0.0; }
+
+      const double B0 = sc[C_B0], B0sol = sc[C_B0SOL], ustar = sc[C_USTAR];
+      wscale_u wu;
+      wu.ju = si[I_JU]; wu.ufrac = sc[C_UFRAC]; wu.ustar = ustar; wu.ucube = sc[C_UCUBE];
+      const double zm_kmp1 = c_zm[nzp1];
+      double swf = p.swfrac_tab[si[I_JER] * p.ldc + k];
+      double bf = B0 + B0sol * (1. - swf);
+      double st = 0.5 + dsign(0.5, bf + epsln16);
+      double sg = st * 1. + (1. - st) * eps01;
+      double wm, ws;
+      wscale_dev(p, wu, sg, -zmk, bf, wm, ws);
+      double dbm1 = aDb[k - 1];
+      double bvsq = 0.5 * (div_fast(dbm1, c_zm[k - 1] - zmk, c_rdz[k - 1]) + div_fast(dbloc, zdiff, c_rdz[k]));
+      double Vtsq = -zmk * ws * __builtin_sqrt(__builtin_fabs(bvsq)) * p.Vtc;
+      const double rawden = dVsq + Vtsq + epsln16, bfa = __builtin_fabs(bf) + epsln16;
+      double raw = div_fast(Ritop, rawden, rcp_refine(rawden));
+      double dmo = div_fast(div_fast(cmonob * ustar * ustar * ustar, p.vonk, c_misc[1]), bfa, rcp_refine(bfa));
+      dmo = st * dmo - (1. - st) * zm_kmp1;
+      if (k >= 2 && actz) { aRaw[k] = raw; aDmo[k] = dmo; }
+      if (is1) { aRaw[1] = 0.0; aDmo[1] = -zm_kmp1; }
+    }
+    __syncthreads();
+
+    // ---- M2: Rib(ku) = MAX(Rib(ku), Rib(ka)+epsln), bldepth_mod.F90:137
+    if (wv == 0) serial_scan_rib_n(W, R_RAW, slots, SS, NA, nz, sirec + I_ACT, I_COUNT, lane);
+    __syncthreads();
+
+    // ---- L4: first level with hmin < -zm(k) (bldepth_mod.F90:139-180): every hit level posts its hmin,
+    //          the shallowest one wins through an LDS minimum
+    if (active) {
+      const double ocdepth = sc[C_OCDEPTH];
+      const double zm_kmp1 = c_zm[nzp1];
+      const double hek = sc[C_HEK];
+      const double B0 = sc[C_B0], B0sol = sc[C_B0SOL];
+      double swf = p.swfrac_tab[si[I_JER] * p.ldc + k];
+      double bf = B0 + B0sol * (1. - swf);
+      double stab = 0.5 + dsign(0.5, bf + epsln16);
+      double Rka = aRaw[k - 1], Rku = aRaw[k], dmoa = aDmo[k - 1], dmou = aDmo[k];
+      double zkm1 = c_zm[k - 1];
+      double hri = -zkm1 + (zkm1 - zmk) * (Ricr - Rka) / (Rku - Rka);
+      double hmonob;
+      if (dmou <= (-zmk)) {
+        hmonob = (dmou - dmoa) / (zkm1 - zmk);
+        hmonob = (dmou + hmonob * zmk) / (1. - hmonob);
+      } else {
+        hmonob = -zm_kmp1;
+      }
+      double hekman = stab * hek - (1. - stab) * zm_kmp1;
+      double hmin = dmin2(dmin2(dmin2(hri, hmonob), hekman), -ocdepth);
+      bool hit = (k >= 2) && actz && (hmin < -zmk);
+      if (hit && !si[I_INITFLAG] && (hmin < -zkm1)) {
+        double hmin2 = dmin2(dmin2(hri, hmonob), -ocdepth);
+        if (hmin2 < -zmk) hmin = hmin2;
+      }
+      if (hit) aH[k] = hmin;
+      // only a hit whose shallower neighbour (same wave, same column since k >= 2) did not hit can be the first
+      const unsigned long long m = __ballot(hit);
+      const bool prev = lane > 0 && ((m >> (lane - 1)) & 1ull);
+      if (hit && !prev) atomicMin(&si[I_KBLC], k);
+    }
+    __syncthreads();
+
+    // ---- M3: hbl, kbl, slot-uniform part of blmix
+    if (wv == 0) M3();
+    __syncthreads();
+
+    // ---- L5: blmix shape functions, enhance, combine (blmix_mod.F90:110-133, enhance_mod.F90:10-51,
+    //          kppmix_mod.F90:103-111, verticalmixing_mod.F90:151-159) -> final diffusivity rows
+    if (active) {
+      const int kbl = si[I_KBL];
+      const double dt_l = EXT ? dt_i : ds_i;
+      difm = dm_i; difs = ds_i; dift = dt_l; ghat = 0.;
+      if (k < kbl) {
+        const double hbl = sc[C_HBL], r_hbl = sc[C_RHBL], stable = sc[C_STABLE], bfsfc = sc[C_BFSFC];
+        wscale_u wu;
+        wu.ju = si[I_JU]; wu.ufrac = sc[C_UFRAC]; wu.ustar = sc[C_USTAR]; wu.ucube = sc[C_UCUBE];
+        const double hk = c_hm[k];
+        double wm, ws;
+        double sig = div_fast(-zmk + 0.5 * hk, hbl, r_hbl);
+        double sigma = stable * sig + (1. - stable) * dmin2(sig, eps01);
+        wscale_dev(p, wu, sigma, hbl, bfsfc, wm, ws);
+        double a1 = sig - 2.;
+        double a2 = 3. - 2. * sig;
+        double a3 = sig - 1.;
+        double Gm = a1 + a2 * sc[C_GAT1 + 0] + a3 * sc[C_DAT1 + 0];
+        double Gs = a1 + a2 * sc[C_GAT1 + 1] + a3 * sc[C_DAT1 + 1];
+        double Gt = a1 + a2 * sc[C_GAT1 + 2] + a3 * sc[C_DAT1 + 2];
+        double b0 = hbl * wm * sig * (1. + sig * Gm);
+        double b1 = hbl * ws * sig * (1. + sig * Gs);
+        double b2 = hbl * ws * sig * (1. + sig * Gt);
+        const double ghd = ws * hbl + epsln20;
+        double gh = div_fast((1. - stable) * p.cg, ghd, rcp_refine(ghd));
+        if (k == kbl - 1 && k <= nz - 1) {
+          const double caseA = sc[C_CASEA];
+          double delta = div_fast(hbl + zmk, zmk - c_zm[k + 1], c_rdz[k]);
+          double omd = 1. - delta;
+          double dkmp5 = caseA * dm_i + (1. - caseA) * b0;
+          double dstar = (omd * omd) * sc[C_DKM1 + 0] + (delta * delta) * dkmp5;
+          b0 = omd * dm_i + delta * dstar;
+          dkmp5 = caseA * ds_i + (1. - caseA) * b1;
+          dstar = (omd * omd) * sc[C_DKM1 + 1] + (delta * delta) * dkmp5;
+          b1 = omd * ds_i + delta * dstar;
+          dkmp5 = caseA * dt_l + (1. - caseA) * b2;
+          dstar = (omd * omd) * sc[C_DKM1 + 2] + (delta * delta) * dkmp5;
+          b2 = omd * dt_l + delta * dstar;
+          gh = (1. - caseA) * gh;
+        }
+        difm = b0; difs = b1; dift = b2; ghat = gh;
+      }
+      if (k >= nz) { difm = 0.0001; difs = 0.00001; dift = 0.00001; ghat = 0.0; }
+      if (act) { aDm[k] = difm; aDs[k] = difs; aDt[k] = dift; aGh[k] = ghat; }
+    }
+    __syncthreads();
+
+    // ---- L6: right-hand sides of U, T, S (ocnint_mod.F90:51-58, tridrhs solvers.F90:53-107)
+    if (active && do_ocnint) {
+      const double f = sc[C_F];
+      const double Uo = ld_old(p.U), Vo = ld_old(p.V), To = ld_old(p.T), So = ld_old(p.S);
+      const double dto = p.dto, tri1_nz = c_t1[nz];
+      const double wX0_1 = sc[C_WX01], wX0_2 = sc[C_WX02];
+      double *yU = row(R_YU), *yT = row(R_YT), *yS = row(R_YS);
+      if (actz) {
+        const int jer = si[I_JER];
+        const double rho0cp0 = sc[C_RHO0CP0], r_rc = sc[C_RRC], sflux3 = sc[C_SFLUX3];
+        const double dt_m1 = aDt[k - 1], ds_m1 = aDs[k - 1];
+        const double gh_m1 = (k >= 2) ? aGh[k - 1] : 0.0;
+        double wxnt = 0.0, wxnt_m1 = 0.0;   // wXNT(k,1), wXNT(k-1,1), fluxes_mod.F90:110-116
+        if (ntime >= 1) {
+          wxnt = div_fast(-sflux3 * p.swdk_tab[jer * p.ldc + k], rho0cp0, r_rc);
+          wxnt_m1 = div_fast(-sflux3 * p.swdk_tab[jer * p.ldc + k - 1], rho0cp0, r_rc);
+        }
+        double rhsU;
+        if (k == 1) rhsU = Uo + dto * (f * .5 * (Vo + V) - div_fast(sc[C_WU01], c_hm[1], c_misc[0]));
+        else rhsU = Uo + dto * f * .5 * (Vo + V);
+        if (k == nz) rhsU = rhsU + tri1_nz * difm * p.U[rowoff() + (nzp1 - 1)];
+        double rhsT;
+        const double dtohk = c_dtohk[k];
+        if (k == 1) rhsT = To + dtohk * (wX0_1 * dift * ghat - wX0_1 * 1.0 + wxnt - sc[C_WXNT0]);
+        else rhsT = To + dtohk * (wX0_1 * (dift * ghat - dt_m1 * gh_m1) + wxnt - wxnt_m1);
+        if (k == nz && nz > 1) rhsT = rhsT + p.T[rowoff() + (nzp1 - 1)] * tri1_nz * dift;
+        double rhsS;
+        if (k == 1) rhsS = So + dtohk * (wX0_2 * difs * ghat - wX0_2 * 1.0 + 0.0 - 0.0);
+        else rhsS = So + dtohk * (wX0_2 * (difs * ghat - ds_m1 * gh_m1) + 0.0 - 0.0);
+        if (k == nz && nz > 1) rhsS = rhsS + p.S[rowoff() + (nzp1 - 1)] * tri1_nz * difs;
+        if constexpr (EXT) ext_rhs(si[I_KBL], To, So, rhsT, rhsS);
+        yU[k] = rhsU; yT[k] = rhsT; yS[k] = rhsS;
+      }
+      if (isnzp1) {
+        yU[k] = Uo; yT[k] = To; yS[k] = So;   // solvers.F90:159
+        if constexpr (EXT) { double t = 0.0, s2 = 0.0; ext_rhs(si[I_KBL], To, So, t, s2); }   // ocnint_mod.F90:153-160, 207-213
+      }
+    }
+    __syncthreads();
+
+    // ---- M4: Thomas factorise + sweep for U, T, S (solvers.F90:14-44, 112-161)
+    if (wv == 0 && do_ocnint)
+      serial_thomas_uts_n(W, slots, SS, NA, nz, c_t0, c_t1, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+    __syncthreads();
+
+    // ---- L7: V right-hand side with the new U (ocnint_mod.F90:62-69)
+    if (active && do_ocnint) {
+      const double Uo = ld_old(p.U), Vo = ld_old(p.V);
+      const double dto = p.dto, f = sc[C_F];
+      const double *yU = row(R_YU);
+      double *yV = row(R_YV);
+      if (actz) {
+        const double un = yU[k];
+        double rhsV;
+        if (k == 1) rhsV = Vo - dto * (f * .5 * (Uo + un) + div_fast(sc[C_WU02], c_hm[1], c_misc[0]));
+        else rhsV = Vo - dto * f * .5 * (Uo + un);
+        if (k == nz) rhsV = rhsV + c_t1[nz] * aDm[k] * p.V[rowoff() + (nzp1 - 1)];
+        yV[k] = rhsV;
+      } else if (act) {
+        yV[k] = Vo;
+      }
+    }
+    __syncthreads();
+
+    // ---- M5: Thomas sweep for V on the stored momentum factorisation; ocnstep control
+    if (wv == 0) {
+      if (do_ocnint) serial_thomas_v_n(W, slots, SS, NA, nz, c_t0, sirec + I_ACT, I_COUNT, lane);
+      G();
+    }
+    __syncthreads();
+    if (!s_flags[1]) continue;
+
+    // =========================== finish round ===========================
+    // instability trap (ocnstep_mod.F90:200-236), then retry or outputs + check_profile.  All lanes of
+    // the workgroup walk the same barriers; only the flagged slots work.
+    int fin = active ? si[I_FIN] : F_NONE;
+    if (fin != F_NONE && do_ocnint) {   // U,V,T,S <- what the last ocnint returned
+      if (act) { U = row(R_YU)[k]; V = row(R_YV)[k]; S = row(R_YS)[k]; }
+      if (actT) T = row(R_YT)[kr];
+    }
+    if (fin == F_TRAP && act) aT[k] = T;
+    __syncthreads();
+    if (fin == F_TRAP) {   // :200-207
+      const double tk1 = aT[k + 1];
+      const bool v = actz && (__builtin_fabs(U) >= 10 || __builtin_fabs(V) >= 10 || __builtin_fabs(T - tk1) >= 10);
+      if (v) atomicAdd(&si[I_NVIOL], 1);
+    }
+    __syncthreads();
+    if (fin == F_TRAP && si[I_NVIOL] == 0 && act) {   // :208-219
+      const double Uo = ld_old(p.U), Vo = ld_old(p.V), To = ld_old(p.T), So = ld_old(p.S);
+      const double hk = c_hm[k];
+      row(R_YU)[k] = (U - Uo) * (U - Uo) * hk / p.dm_nz;
+      row(R_YT)[k] = (V - Vo) * (V - Vo) * hk / p.dm_nz;
+      row(R_YS)[k] = (T - To) * (T - To) * hk / p.dm_nz;
+      row(R_GM)[k] = (S - So) * (S - So) * hk / p.dm_nz;
+    }
+    __syncthreads();
+    if (wv == 0) {   // trap decision, one lane per (slot, profile) for the rmsd sums, then one per slot
+      bool over = false;
+      if (lane < 4 * W) {
+        const int ms = lane >> 2;
+        const int *msi = sirec + ms * I_COUNT;
+        if (msi[I_ACT] && msi[I_FIN] == F_TRAP && msi[I_NVIOL] == 0) {
+          const double *t = slots + ms * SS + (R_YU + (lane & 3)) * NA;
+          double sum = 0.;
+          for (int q = 1; q <= nzp1; ++q) sum = sum + t[q];
+          sum = __builtin_sqrt(sum);
+          over = sum >= 1.0;
+        }
+      }
+      const unsigned long long mo = __ballot(over);
+      bool f_any = false;
+      if (lane < W) {
+        int *msi = sirec + lane * I_COUNT;
+        double *msc = screc + lane * C_COUNT;
+        if (msi[I_ACT] && msi[I_FIN] == F_TRAP) {
+          int comp_flag = 0, status = msi[I_STATUS], nreset = msi[I_NRESET];
+          double f = msc[C_F];
+          const int nviol = msi[I_NVIOL];
+          if (nviol > 0) {
+            comp_flag = 1;
+            for (int i = 0; i < nviol; ++i) f = f * 1.01;
+          } else {
+            const int nover = __popcll((mo >> (4 * lane)) & 0xFull);
+            if (nover > 0) {
+              comp_flag = 1;
+              for (int i = 0; i < nover; ++i) f = f * 1.01;
+            }
+          }
+          if (comp_flag) { status |= 4; msc[C_F] = f; }
+          nreset = nreset + 1;
+          if (nreset > 10) status |= 8;
+          msi[I_COMP] = comp_flag; msi[I_STATUS] = status; msi[I_NRESET] = nreset;
+          if (comp_flag && nreset <= 10) {   // retry, ocnstep_mod.F90:89
+            msi[I_FIN] = F_NONE; msi[I_LOAD] = 2; msi[I_NPASS_TRY] = 0; msi[I_ICONV] = 0; msi[I_MAYBE] = 0;
+          } else {
+            msi[I_FIN] = F_FINAL;
+            msi[I_NU] = 0; msi[I_NV] = 0; msi[I_NF] = 0;
+          }
+        }
+        f_any = msi[I_ACT] && msi[I_FIN] == F_FINAL;
+      }
+      (void)f_any;
+    }
+    __syncthreads();
+    fin = active ? si[I_FIN] : F_NONE;
+    // the diagnostic fluxes need the k+1 neighbours of the final profiles
+    if (fin == F_FINAL && p.diag && p.mode != MCKPP_MODE_PASS && act) {
+      row(R_YU)[k] = U; row(R_YT)[k] = V; row(R_YS)[k] = T; row(R_GM)[k] = S;
+    }
+    __syncthreads();
+    const bool fstep = fin == F_FINAL && p.mode == MCKPP_MODE_STEP;
+    if (fin == F_FINAL && p.diag) {   // ocnstep_mod.F90:242-256 / initialize_ocean.F90:66-81
+      const size_t ro = rowoff();
+      const double wX0_1 = sc[C_WX01], wX0_2 = sc[C_WX02];
+      const double *tU = row(R_YU), *tV = row(R_YT), *tT = row(R_YS), *tS = row(R_GM);
+      const double rho0cp0 = sc[C_RHO0CP0], sflux3 = sc[C_SFLUX3];
+      const size_t o = ro + k;
+      const double dfm = aDm[k], dfs = aDs[k], dft = aDt[k], gh = aGh[k];
+      if (act) { p.difm[o] = dfm; p.difs[o] = dfs; p.dift[o] = dft; }
+      if (actz) {
+        p.ghat[o] = gh;
+        p.wXNT1[o] = (ntime >= 1) ? -sflux3 * p.swdk_tab[si[I_JER] * p.ldc + k] / rho0cp0 : 0.0;
+        if (p.mode != MCKPP_MODE_PASS) {
+          double deltaz = 0.5 * (c_hm[k] + c_hm[k + 1]);
+          double uk1 = tU[k + 1], vk1 = tV[k + 1], tk1 = tT[k + 1], sk1 = tS[k + 1];
+          double wX1 = -dfs * ((T - tk1) / deltaz - gh * wX0_1);
+          double wX2 = -dfs * ((S - sk1) / deltaz - gh * wX0_2);
+          if (p.LDD) wX1 = -dft * ((T - tk1) / deltaz - gh * wX0_1);
+          p.wX1[o] = wX1; p.wX2[o] = wX2;
+          p.wX3[o] = p.grav * (talpha * wX1 - sbeta * wX2);
+          p.wU1[o] = -dfm * (U - uk1) / deltaz;
+          p.wU2[o] = -dfm * (V - vk1) / deltaz;
+        }
+      }
+      if (is1) {   // index-0 entries
+        p.difm[ro] = 0.0; p.difs[ro] = 0.0; p.dift[ro] = 0.0;
+        p.wU1[ro] = sc[C_WU01]; p.wU2[ro] = sc[C_WU02];
+        p.wX1[ro] = wX0_1; p.wX2[ro] = wX0_2; p.wX3[ro] = -sc[C_B0];
+        p.wXNT1[ro] = sc[C_WXNT0];
+      }
+    }
+    // ---- outputs of the column-step.  STEP: ocnstep_mod.F90:305-353 + check_profile
+    // (overrides.F90:42-125); the optional parts of check_profile count over all levels of the
+    // column, i.e. over lanes of several waves: LDS counters between workgroup barriers (EXT build).
+    double reset_out = 0.0, dampu = 0.0, dampv = 0.0, freeze = 0.0;
+    int l_ocean = 0, old = 0, newi = 1;
+    if (fstep && is1) {   // level-1 references, before any override touches the profiles
+      double *cs = p.cs + (size_t)col * MCKPP_CS;
+      cs[CS_UREF] = U; cs[CS_VREF] = V; cs[CS_TREF] = T;
+      cs[CS_SSURF] = p.L_SSref ? cs[CS_SSREF] : S + sc[C_SREF];
+    }
+    if constexpr (EXT) {
+      if (fstep && p.L_DAMP_CURR) {   // ocnstep_mod.F90:317-340
+        const double rr = (double)p.dt_uvdamp * (86400. / p.dto);
+        double a = 0.99 * __builtin_fabs(U), b = (U * U) / rr;
+        if (act && (b < a)) atomicAdd(&si[I_NU], 1);
+        U = U - dsign(dmin2(a, b), U);
+        a = 0.99 * __builtin_fabs(V); b = (V * V) / rr;
+        if (act && (b < a)) atomicAdd(&si[I_NV], 1);
+        V = V - dsign(dmin2(a, b), V);
+      }
+      __syncthreads();
+    }
+    if (fstep) {
+      const size_t o = rowoff() + (k - 1);
+      if constexpr (EXT) {
+        if (p.L_DAMP_CURR) {
+          const double inc = 1.0 / (double)nzp1;
+          const int nu = si[I_NU], nv = si[I_NV];
+          for (int i = 0; i < nu; ++i) dampu = dampu + inc;
+          for (int i = 0; i < nv; ++i) dampv = dampv + inc;
+        }
+      }
+      old = si[I_NEW];
+      newi = 1 - old;
+      if (act) { p.Us[newi][o] = U; p.Vs[newi][o] = V; p.Ts[newi][o] = T; p.Ss[newi][o] = S; }
+      reset_out = (double)si[I_NRESET];
+      if (si[I_COMP]) {   // overrides.F90:57-78
+        if (EXT && p.clim_present && act) { T = p.ocnT_clim[o]; S = p.sal_clim[o]; }
+        if (act) { U = p.U_init[o]; V = p.V_init[o]; }
+        reset_out = 999.;
+      }
+      if constexpr (EXT) {
+        l_ocean = si[I_LOCEAN];
+        freeze = p.cs[(size_t)col * MCKPP_CS + CS_FREEZE];
+        if (l_ocean && p.L_NO_FREEZE) {   // :85-94
+          const bool cold = act && (T < -1.8);
+          if (cold) { xt = xt + (-1.8 - T); T = -1.8; atomicAdd(&si[I_NF], 1); }
+          if (act) p.tinc_fcorr[rowoff() + k] = xt;
+        }
+      }
+    }
+    if constexpr (EXT) {
+      __syncthreads();
+      const bool iso = fstep && l_ocean && p.L_NO_ISOTHERM;
+      if (fstep && l_ocean && p.L_NO_FREEZE) {
+        const double inc = 1.0 / (double)nzp1;
+        const int nf = si[I_NF];
+        for (int i = 0; i < nf; ++i) freeze = freeze + inc;
+      }
+      if (iso && act) row(R_YU)[k] = T;   // :102-120
+      __syncthreads();
+      if (iso && k >= 2 && act) {
+        const double dz = c_zm[k] - c_zm[k - 1];
+        row(R_YT)[k] = __builtin_fabs((T - row(R_YU)[k - 1])) * dz;
+        row(R_YS)[k] = dz;
+      }
+      __syncthreads();
+      if (iso) {
+        const double *tD = row(R_YT), *tZ = row(R_YS);
+        double dtdz_total = 0., dz_total = 0.;
+        for (int q = 2; q <= p.iso_bot; ++q) {
+          dtdz_total = dtdz_total + tD[q];
+          dz_total = dz_total + tZ[q];
+        }
+        dtdz_total = dtdz_total / dz_total;
+        if (__builtin_fabs(dtdz_total) < p.iso_thresh) {
+          if (act) { const size_t o = rowoff() + (k - 1); T = p.ocnT_clim[o]; S = p.sal_clim[o]; }
+          reset_out = (-1.) * reset_out;
+        }
+      } else if (fstep) {
+        reset_out = 0.0;   // :121-123
+      }
+    } else {
+      reset_out = 0.0;     // :121-123 (no isotherm check in the default physics)
+    }
+    if (fin == F_FINAL) {
+      double *cs = p.cs + (size_t)col * MCKPP_CS;
+      int *ci = p.ci + (size_t)col * MCKPP_CI;
+      const size_t o = rowoff() + (k - 1);
+      if (p.mode == MCKPP_MODE_STEP) {
+        if (act) { p.U[o] = U; p.V[o] = V; p.T[o] = T; p.S[o] = S; }
+        if (is1) {
+          const double hmixn = sc[C_HMIXN];
+          cs[CS_HMIX] = hmixn;
+          cs[CS_KMIX] = (double)si[I_KMIXN];
+          cs[newi ? CS_HMIXD1 : CS_HMIXD0] = hmixn;
+          cs[CS_RESET] = reset_out;
+          cs[CS_DAMPU] = dampu; cs[CS_DAMPV] = dampv;
+          if constexpr (EXT) cs[CS_FREEZE] = freeze;
+          ci[CI_OLD] = old; ci[CI_NEW] = newi;
+          ci[CI_STATUS] = si[I_STATUS]; ci[CI_NPASS] = si[I_NPASS];
+        }
+      } else if (p.mode == MCKPP_MODE_INIT) {
+        if (act) {
+          p.Us[0][o] = U; p.Us[1][o] = U; p.Vs[0][o] = V; p.Vs[1][o] = V;
+          p.Ts[0][o] = T; p.Ts[1][o] = T; p.Ss[0][o] = S; p.Ss[1][o] = S;
+        }
+        if (is1) {
+          const double hbl = sc[C_HBL];
+          cs[CS_HMIX] = hbl;
+          cs[CS_KMIX] = (double)si[I_KBL];
+          cs[CS_TREF] = T;
+          cs[CS_UREF] = sc[C_UREFNZ]; cs[CS_VREF] = sc[C_VREFNZ];
+          cs[CS_HMIXD0] = hbl; cs[CS_HMIXD1] = hbl;
+          ci[CI_OLD] = 0; ci[CI_NEW] = 1; ci[CI_INITFLAG] = 0;
+          ci[CI_STATUS] = si[I_STATUS]; ci[CI_NPASS] = si[I_NPASS];
+        }
+      } else {
+        if (act) { p.U[o] = U; p.V[o] = V; p.T[o] = T; p.S[o] = S; }
+        if (is1) {
+          cs[CS_HMIX] = sc[C_HBL];
+          cs[CS_KMIX] = (double)si[I_KBL];
+          cs[CS_UREF] = sc[C_UREFNZ]; cs[CS_VREF] = sc[C_VREFNZ];
+          ci[CI_STATUS] = si[I_STATUS]; ci[CI_NPASS] = si[I_NPASS];
+        }
+      }
+    }
+    __syncthreads();   // every read of the finished slots' records is done: hand them to the queue
+    if (wv == 0) M0();
+    __syncthreads();
+  }
+}
+
+struct pk_geom { int nw, w, per_cu; };
+
+// Waves per workgroup / columns per workgroup / workgroups per CU for a column of L lanes.
+// 128 VGPRs -> 16 waves per CU; the serial sweeps want W <= 10 (bank-conflict-free lanes) and the
+// fewer lanes are left over at the end of the last wave the better.
+pk_geom pk_choose(int L, bool ext, int num_cu_lds_bytes)
+{
+  pk_geom best{4, 1, 1};
+  double best_score = -1.0;
+  for (int nw = 4; nw <= 8; ++nw) {
+    const int w = (64 * nw) / L;
+    if (w < 1 || w > 10) continue;
+    int per_cu = 16 / nw;
+    const size_t lds = pk_lds_bytes(L, w, ext);
+    while (per_cu > 0 && (size_t)per_cu * ((lds + 1279) / 1280 * 1280) > (size_t)num_cu_lds_bytes) --per_cu;
+    if (per_cu < 1) continue;
+    const double util = (double)(w * L) / (64.0 * nw);
+    const double occ = (double)(per_cu * nw) / 16.0;
+    const double score = util * (0.5 + 0.5 * occ) * (nw == 5 || nw == 7 ? 0.97 : 1.0);
+    if (score > best_score) { best_score = score; best = {nw, w, per_cu}; }
+  }
+  return best;
+}
+
+}  // namespace
+
+// MCKPP_PK=<waves per workgroup>x<workgroups per CU> overrides the geometry (experiments).
+hipError_t mckpp_launch_column_kernel_pk(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu, hipStream_t stream,
+                                         mckpp_launch_info *info)
+{
+  if (p.ncol <= 0) return hipSuccess;
+  const int L = p.nzp1 + 2;
+  if (L > 512) return hipErrorInvalidValue;
+  const bool ext = p.ext != 0;
+  pk_geom g = pk_choose(L, ext, 160 * 1024);
+  if (const char *e = getenv("MCKPP_PK")) {
+    int nw = 0, b = 0;
+    if (sscanf(e, "%dx%d", &nw, &b) >= 1 && nw >= 1 && nw <= 8 && (64 * nw) / L >= 1) {
+      g.nw = nw;
+      g.w = (64 * nw) / L;
+      if (g.w > 16) g.w = 16;
+      if (b > 0) g.per_cu = b;
+    }
+  }
+  const size_t lds = pk_lds_bytes(L, g.w, ext);
+  const void *fn = ext ? reinterpret_cast<const void *>(k_column_pk<true>) : reinterpret_cast<const void *>(k_column_pk<false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  int nblocks = num_cu * g.per_cu;
+  const int groups = (p.ncol + g.w - 1) / g.w;
+  if (nblocks > groups) nblocks = groups;
+  if (nblocks < 1) nblocks = 1;
+  if (info) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * g.nw, lds) != hipSuccess) nb = 0;
+    *info = {nblocks, 64 * g.nw, nb, lds};
+  }
+  if (ext) hipLaunchKernelGGL(k_column_pk<true>, dim3((unsigned)nblocks), dim3(64 * g.nw), lds, stream, dp, p.ntime, L, g.w);
+  else hipLaunchKernelGGL(k_column_pk<false>, dim3((unsigned)nblocks), dim3(64 * g.nw), lds, stream, dp, p.ntime, L, g.w);
+  return hipGetLastError();
+}

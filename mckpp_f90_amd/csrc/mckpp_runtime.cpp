@@ -88,7 +88,8 @@ struct mckpp_hip_ctx {
   int num_cu = 256;
   double *d_series = nullptr;   // [nrec][8][ncol] forcing records (mckpp_hip_set_flux_series)
   int series_rec0 = 0, series_nrec = 0;
-  int kernel_variant = 2;   // 2: cooperative workgroup kernel, 1: one wave per column (MCKPP_KERNEL=v1)
+  int kernel_variant = 2;   // 1: one wave per column (v1), 2: k_column_wg, 3: k_column_mw, 4: k_column_pk (packed lanes)
+  mckpp_launch_info last_launch{};   // geometry of this context's most recent cooperative launch
   double *d_stage = nullptr;
   size_t stage_elems = 0;
   int diag = 1;
@@ -198,6 +199,7 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
     if (strcmp(kv, "v1") == 0) h->kernel_variant = 1;
     else if (strcmp(kv, "wg") == 0) h->kernel_variant = 2;
     else if (strcmp(kv, "mw") == 0) h->kernel_variant = 3;
+    else if (strcmp(kv, "pk") == 0) h->kernel_variant = 4;
   }
   if (h->ext && h->kernel_variant == 1) {
     delete h;
@@ -644,8 +646,13 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode, const forced_r
       HIPCHK(mckpp_launch_column_kernel(p, h->stream));
     } else {
       HIPCHK(hipMemsetAsync(h->d_qhead, 0, sizeof(int), h->stream));
-      if (h->kernel_variant == 3) HIPCHK(mckpp_launch_column_kernel_mw(p, h->d_params, h->num_cu, h->stream));
-      else HIPCHK(mckpp_launch_column_kernel_wg(p, h->d_params, h->num_cu, h->stream));
+      if (h->kernel_variant == 4) {
+        HIPCHK(mckpp_launch_column_kernel_pk(p, h->d_params, h->num_cu, h->stream, &h->last_launch));
+      } else {
+        if (h->kernel_variant == 3) HIPCHK(mckpp_launch_column_kernel_mw(p, h->d_params, h->num_cu, h->stream));
+        else HIPCHK(mckpp_launch_column_kernel_wg(p, h->d_params, h->num_cu, h->stream));
+        h->last_launch = g_mckpp_last_launch;
+      }
     }
   }
   HIPCHK(hipEventRecord(h->ev1, h->stream));
@@ -729,6 +736,7 @@ const char *mckpp_hip_kernel_name(mckpp_hip_handle h)
                                     {"k_column_mw<1>", "k_column_mw<2>", "k_column_mw<3>"}};
   if (h->ext && h->kernel_variant == 2) return h->lpl == 1 ? "k_column_wg<1,EXT>" : h->lpl == 2 ? "k_column_wg<2,EXT>" : "k_column_wg<3,EXT>";
   if (h->ext && h->kernel_variant == 3) return h->lpl == 1 ? "k_column_mw<1,EXT>" : h->lpl == 2 ? "k_column_mw<2,EXT>" : "k_column_mw<3,EXT>";
+  if (h->kernel_variant == 4) return h->ext ? "k_column_pk<EXT>" : "k_column_pk";
   return names[h->kernel_variant][h->lpl - 1];
 }
 
@@ -736,12 +744,12 @@ int mckpp_hip_kernel_residency(mckpp_hip_handle h, int32_t *blocks_per_cu, int32
                                int32_t *threads_per_block, int64_t *lds_bytes_per_block)
 {
   if (!h) return fail("null handle");
-  if (h->kernel_variant == 1 || g_mckpp_last_launch.threads == 0)
+  if (h->kernel_variant == 1 || h->last_launch.threads == 0)
     return fail("mckpp_hip_kernel_residency: no cooperative-kernel launch yet");
-  if (blocks_per_cu) *blocks_per_cu = (g_mckpp_last_launch.nblocks + h->num_cu - 1) / h->num_cu;
-  if (max_blocks_per_cu) *max_blocks_per_cu = g_mckpp_last_launch.max_blocks_per_cu;
-  if (threads_per_block) *threads_per_block = g_mckpp_last_launch.threads;
-  if (lds_bytes_per_block) *lds_bytes_per_block = (int64_t)g_mckpp_last_launch.lds_bytes;
+  if (blocks_per_cu) *blocks_per_cu = (h->last_launch.nblocks + h->num_cu - 1) / h->num_cu;
+  if (max_blocks_per_cu) *max_blocks_per_cu = h->last_launch.max_blocks_per_cu;
+  if (threads_per_block) *threads_per_block = h->last_launch.threads;
+  if (lds_bytes_per_block) *lds_bytes_per_block = (int64_t)h->last_launch.lds_bytes;
   return 0;
 }
 

@@ -19,12 +19,13 @@ enum { R_DM = 0, R_DT, R_DS, R_GH, R_YU, R_YT, R_YS, R_GM, R_GT, R_GS, R_BETM, R
 enum { R_U = R_YU, R_V = R_YT, R_B = R_YS, R_R = R_GM, R_DB = R_GT, R_DMO = R_GS, R_T = R_BETM };
 
 // Rib(ku) = MAX(Rib(ku), Rib(ka)+epsln), bldepth_mod.F90:137; W lanes
-template <int W>
-__device__ __forceinline__ void serial_scan_rib(double *slots, int SS, int NA, int nz, const int *sact, int lane)
+// (the _n forms take the number of slots and the row to scan at run time: packed-lane kernel)
+__device__ __forceinline__ void serial_scan_rib_n(int W, int R_SCAN, double *slots, int SS, int NA, int nz,
+                                                  const int *sact, int sact_stride, int lane)
 {
   const double epsln16 = 1.e-16;
-  if (lane < W && sact[lane]) {
-    double *r = slots + lane * SS + R_R * NA;
+  if (lane < W && sact[lane * sact_stride]) {
+    double *r = slots + lane * SS + R_SCAN * NA;
     double rb = 0.0;
     int k = 2;
     for (; k + 3 <= nz; k += 4) {
@@ -42,15 +43,21 @@ __device__ __forceinline__ void serial_scan_rib(double *slots, int SS, int NA, i
   }
 }
 
+template <int W>
+__device__ __forceinline__ void serial_scan_rib(double *slots, int SS, int NA, int nz, const int *sact, int lane)
+{
+  serial_scan_rib_n(W, R_R, slots, SS, NA, nz, sact, 1, lane);
+}
+
 // tridcof + tridmat (solvers.F90:14-44, 112-161), skewed by one level: iteration i forms
 // gam(i) = cl(i-1)/bet(i-1) and y(i-1) = num(i-1)/bet(i-1) over the same denominator.  3W lanes
-template <int W>
-__device__ __forceinline__ void serial_thomas_uts(double *slots, int SS, int NA, int nz, const double *c_t0,
-                                                  const double *c_t1, const int *sact, int *sbad, int lane)
+__device__ __forceinline__ void serial_thomas_uts_n(int W, double *slots, int SS, int NA, int nz, const double *c_t0,
+                                                    const double *c_t1, const int *sact, int sact_stride, int *sbad,
+                                                    int sbad_stride, int lane)
 {
   if (lane < 3 * W) {
     const int sl = lane / 3, sys = lane - 3 * sl;
-    if (sact[sl]) {
+    if (sact[sl * sact_stride]) {
       double *base = slots + sl * SS;
       const double *d = base + (R_DM + sys) * NA;
       double *y = base + (R_YU + sys) * NA, *gm = base + (R_GM + sys) * NA;
@@ -117,17 +124,22 @@ __device__ __forceinline__ void serial_thomas_uts(double *slots, int SS, int NA,
         yy = y[i] - gm[i + 1] * yy;
         y[i] = yy;
       }
-      if (bad) sbad[sl] = 1;
+      if (bad) sbad[sl * sbad_stride] = 1;
     }
   }
 }
+template <int W>
+__device__ __forceinline__ void serial_thomas_uts(double *slots, int SS, int NA, int nz, const double *c_t0,
+                                                  const double *c_t1, const int *sact, int *sbad, int lane)
+{
+  serial_thomas_uts_n(W, slots, SS, NA, nz, c_t0, c_t1, sact, 1, sbad, 1, lane);
+}
 
 // V on the stored momentum factorisation (bet, refined 1/bet, gam); W lanes
-template <int W>
-__device__ __forceinline__ void serial_thomas_v(double *slots, int SS, int NA, int nz, const double *c_t0,
-                                                const int *sact, int lane)
+__device__ __forceinline__ void serial_thomas_v_n(int W, double *slots, int SS, int NA, int nz, const double *c_t0,
+                                                  const int *sact, int sact_stride, int lane)
 {
-  if (lane < W && sact[lane]) {
+  if (lane < W && sact[lane * sact_stride]) {
     double *base = slots + lane * SS;
     const double *d = base + R_DM * NA, *gm = base + R_GM * NA, *betm = base + R_BETM * NA,
                  *rbm = base + R_RB * NA;
@@ -181,6 +193,13 @@ __device__ __forceinline__ void serial_thomas_v(double *slots, int SS, int NA, i
       y[i] = yy;
     }
   }
+}
+
+template <int W>
+__device__ __forceinline__ void serial_thomas_v(double *slots, int SS, int NA, int nz, const double *c_t0,
+                                                const int *sact, int lane)
+{
+  serial_thomas_v_n(W, slots, SS, NA, nz, c_t0, sact, 1, lane);
 }
 
 }  // namespace mckpp_dev

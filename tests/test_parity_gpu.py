@@ -499,7 +499,7 @@ def test_default_kernel_selection(mk, kernel_env):
     ctx.close()
 
 
-@pytest.mark.parametrize("variant", ["v1", "wg", "mw"])
+@pytest.mark.parametrize("variant", ["v1", "wg", "mw", "pk"])
 @pytest.mark.parametrize("nz,ncol,nsteps,grid", [(40, 70, 2, "uniform"), (61, 67, 2, "uniform"), (62, 67, 2, "uniform"),
                                                  (69, 131, 2, "stretched"), (125, 35, 2, "uniform"),
                                                  (126, 35, 2, "uniform"), (150, 41, 2, "uniform")])
@@ -508,13 +508,13 @@ def test_every_kernel_variant_bitexact(mk, kernel_env, variant, nz, ncol, nsteps
     column stops fitting one (two) wave(s) with its two virtual equation-of-state slots."""
     kernel_env(variant)
     out, k3, ob, kc, oc = _run_both(mk, ncol, nz, nsteps, grid=grid, land_every=5, jerlov_mix=True)
-    want = {"v1": "k_column<", "wg": "k_column_wg<", "mw": "k_column_mw<"}[variant]
+    want = {"v1": "k_column<", "wg": "k_column_wg<", "mw": "k_column_mw<", "pk": "k_column_pk"}[variant]
     assert kc._hip_ctx.kernel_name.startswith(want), kc._hip_ctx.kernel_name
     for tag, res in out:
         _assert_bitexact(res, f"{variant} nz={nz} {tag}")
 
 
-@pytest.mark.parametrize("variant,nz", [("mw", 40), ("mw", 69), ("mw", 150), ("wg", 69)])
+@pytest.mark.parametrize("variant,nz", [("mw", 40), ("mw", 69), ("mw", 150), ("wg", 69), ("pk", 40), ("pk", 69), ("pk", 100), ("pk", 150)])
 def test_instability_trap_every_variant(mk, kernel_env, variant, nz):
     """The retry round of the deep-column kernel (cross-wave violation counts and rmsd sums)."""
     from oracle import orc
@@ -555,7 +555,7 @@ def test_config2_pass_every_variant(mk, kernel_env):
 
     fields = ["U", "V", "T", "S", "hmix", "kmix", "uref", "vref", "rho", "cp", "buoy", "difm", "difs", "dift",
               "ghat", "Rig", "dbloc", "Shsq", "wXNT1"]
-    for variant, nz in [("mw", 60), ("mw", 100), ("mw", 150)]:
+    for variant, nz in [("mw", 60), ("mw", 100), ("mw", 150), ("pk", 40), ("pk", 69), ("pk", 100), ("pk", 150)]:
         kernel_env(variant)
         ncol = 300
         oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1)
@@ -564,7 +564,7 @@ def test_config2_pass_every_variant(mk, kernel_env):
         ob["sflux"] = sf
         cm.set_forcing_3d(k3, sf)
         ctx = mk.MckppHip(kc)
-        assert ctx.kernel_name.startswith("k_column_mw<")
+        assert ctx.kernel_name.startswith("k_column_mw<" if variant == "mw" else "k_column_pk")
         ctx.upload(k3)
         ctx.vmix_pass(1)
         ctx.download(k3)
@@ -573,7 +573,7 @@ def test_config2_pass_every_variant(mk, kernel_env):
         ctx.close()
 
 
-@pytest.mark.parametrize("variant,nz", [("v1", 40), ("wg", 40), ("wg", 60), ("mw", 40), ("mw", 69), ("wg", 69)])
+@pytest.mark.parametrize("variant,nz", [("v1", 40), ("wg", 40), ("wg", 60), ("mw", 40), ("mw", 69), ("wg", 69), ("pk", 40), ("pk", 60), ("pk", 69), ("pk", 100)])
 def test_tiny_and_denormal_velocities_take_the_ieee_paths(mk, kernel_env, variant, nz):
     """The kernels drop the v_div_scale rescaling where operand ranges are known and guard the
     quotients whose numerators can be tiny non-zero numbers (velocities diffused down a deep column):
