@@ -53,23 +53,33 @@ enum { R_RHO = R_COUNT, R_CP, R_COUNT_EXT };   // rho, cp rows of the optional-p
 enum { R_PV = R_YV, R_RAW = R_RB /* bulk Ri, free until the Thomas sweep */, R_H = R_YV /* hmin candidates */,
        R_LA = R_DM /* LDD: talpha of the level below */ };
 
-// host and device agree on the LDS layout through these
+// LDS layout.  A slot's rows are interleaved per level: element (row a, level i) sits at i*ROWS + a
+// doubles, so a level lane reaches all its rows and the rows of its neighbours through ONE base register
+// plus immediate offsets (the column depth, hence any row-major row length, is a run-time value).  ROWS is
+// odd (13 / 15): 32 consecutive levels fall on 32 distinct banks.  The grid constants are interleaved the
+// same way with a stride of 7.  Host and device agree on the sizes through these:
+enum { K_ZM = 0, K_HM, K_T0, K_T1, K_RDZ, K_DTOHK, K_STRIDE = 7 };
 __host__ __device__ inline int pk_rows(bool ext) { return ext ? (int)R_COUNT_EXT : (int)R_COUNT; }
-__host__ __device__ inline int pk_na(int L) { return (L + 2) | 1; }   // indices 0..L+1, odd
+__host__ __device__ inline int pk_nl(int L) { return L + 2; }   // level indices 0..L+1
 __host__ __device__ inline int pk_ss(int L, bool ext)
 {
-  // lane (slot s, system m) of the serial sweeps touches slot*SS + m*NA + i: with NA odd and
-  // SS = 3*NA (mod 32 doubles) up to ten slots x three systems fall on distinct banks
-  const int na = pk_na(L);
-  int s = pk_rows(ext) * na;
-  while ((s & 31) != ((3 * na) & 31)) ++s;
+  // lane (slot s, system m) of the serial sweeps touches s*SS + i*ROWS + m: with SS = 3 (mod 32 doubles)
+  // up to ten slots x three systems fall on distinct banks
+  int s = pk_rows(ext) * pk_nl(L);
+  while ((s & 31) != 3) ++s;
   return s;
 }
 __host__ __device__ inline size_t pk_lds_bytes(int L, int W, bool ext)
 {
-  return (size_t)(6 * pk_na(L) + 2 + W * pk_ss(L, ext) + W * C_COUNT) * sizeof(double) +
+  return (size_t)(K_STRIDE * pk_nl(L) + 2 + W * pk_ss(L, ext) + W * C_COUNT) * sizeof(double) +
          (size_t)(W * I_COUNT + 4) * sizeof(int);
 }
+
+template <int KS>
+struct strided {   // x[i] of a level-interleaved row
+  double *b;
+  __device__ __forceinline__ double &operator[](int i) const { return b[i * KS]; }
+};
 
 template <bool EXT>
 __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__restrict__ pp, const int ntime, const int L,
@@ -77,18 +87,21 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
 {
   const mckpp_kparams &p = *pp;
   extern __shared__ double lds[];
-  const int NA = pk_na(L), SS = pk_ss(L, EXT);
+  constexpr int ROWS = EXT ? (int)R_COUNT_EXT : (int)R_COUNT;
+  const int NL = pk_nl(L), SS = pk_ss(L, EXT);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nz = p.nz, nzp1 = p.nzp1;
-  double *c_zm = lds, *c_hm = lds + NA, *c_t0 = lds + 2 * NA, *c_t1 = lds + 3 * NA;
-  double *c_rdz = lds + 4 * NA, *c_dtohk = lds + 5 * NA, *c_misc = lds + 6 * NA;
-  double *slots = lds + 6 * NA + 2;
+  double *cst = lds;
+  const strided<K_STRIDE> c_zm{cst + K_ZM}, c_hm{cst + K_HM}, c_t0{cst + K_T0}, c_t1{cst + K_T1}, c_rdz{cst + K_RDZ},
+      c_dtohk{cst + K_DTOHK};
+  double *c_misc = lds + K_STRIDE * NL;
+  double *slots = c_misc + 2;
   double *screc = slots + W * SS;
   int *sirec = reinterpret_cast<int *>(screc + W * C_COUNT);
   int *s_flags = sirec + W * I_COUNT;   // [0] some slot active, [1] some slot finishing
 
-  for (int i = tid; i < NA; i += blockDim.x) {
+  for (int i = tid; i < NL; i += blockDim.x) {
     c_zm[i] = p.zm[i];
     c_hm[i] = p.hm[i];
     c_t0[i] = p.tri0[i];
@@ -113,10 +126,10 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
   double *my = slots + slot * SS;
   double *sc = screc + slot * C_COUNT;
   int *si = sirec + slot * I_COUNT;
-  auto row = [&](int a) -> double * { return my + a * NA; };
-  double *aDm = row(R_DM), *aDs = row(R_DS), *aDt = row(R_DT), *aGh = row(R_GH);
-  double *aU = row(R_U), *aV = row(R_PV), *aB = row(R_B), *aR = row(R_R), *aDb = row(R_DB), *aDmo = row(R_DMO),
-         *aT = row(R_T), *aRaw = row(R_RAW), *aH = row(R_H);
+  auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };
+  const strided<ROWS> aDm = row(R_DM), aDs = row(R_DS), aDt = row(R_DT), aGh = row(R_GH);
+  const strided<ROWS> aU = row(R_U), aV = row(R_PV), aB = row(R_B), aR = row(R_R), aDb = row(R_DB), aDmo = row(R_DMO),
+                      aT = row(R_T), aRaw = row(R_RAW), aH = row(R_H);
   __syncthreads();
 
   int k = k0;
@@ -215,12 +228,12 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
       int *msi = sirec + lane * I_COUNT;
       double *msc = screc + lane * C_COUNT;
       if (msi[I_ACT]) {
-        const double *mrow = slots + lane * SS;
+        double *mrow = slots + lane * SS;
         const int kc = msi[I_KBLC];
         msi[I_KBLC] = 0x7fffffff;
         int kbl = nz;
         double hbl = -c_zm[nz];
-        if (kc <= nz) { kbl = kc; hbl = mrow[R_H * NA + kc]; }
+        if (kc <= nz) { kbl = kc; hbl = mrow[kc * ROWS + R_H]; }
         msi[I_KBL] = kbl;
         msc[C_HBL] = hbl;
         const int jer = msi[I_JER];
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
           const double r_hmkn = rcp_refine(hmkn), r_hmkn1 = rcp_refine(hmkn1);
           double delhat = 0.5 * hmkn - c_zm[kn] - hbl;
           double R = 1.0 - div_fast(delhat, hmkn, r_hmkn);
-          const double *dd[3] = {mrow + R_DM * NA, mrow + R_DS * NA, mrow + R_DT * NA};
+          const strided<ROWS> dd[3] = {{mrow + R_DM}, {mrow + R_DS}, {mrow + R_DT}};
           double dp[3], dh[3];
 #pragma unroll
           for (int m = 0; m < 3; ++m) {
@@ -344,7 +357,7 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
   auto ext_rhs = [&](int kmixe, double To_k, double So_k, double &rhsT, double &rhsS) {
     const double dto = p.dto;
     const double *xs = p.xs + (size_t)col * MCKPP_XS;
-    const double *aRho = row(R_RHO), *aCp = row(R_CP);
+    const strided<ROWS> aRho = row(R_RHO), aCp = row(R_CP);
     const double rhok = aRho[k], cpk = aCp[k];
     const size_t oin = rowoff() + (k - 1);
     if (k == 1) {
@@ -604,7 +617,7 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
     __syncthreads();
 
     // ---- M2: Rib(ku) = MAX(Rib(ku), Rib(ka)+epsln), bldepth_mod.F90:137
-    if (wv == 0) serial_scan_rib_n(W, R_RAW, slots, SS, NA, nz, sirec + I_ACT, I_COUNT, lane);
+    if (wv == 0) serial_scan_rib_n(W, R_RAW, slots, SS, 1, ROWS, nz, sirec + I_ACT, I_COUNT, lane);
     __syncthreads();
 
     // ---- L4: first level with hmin < -zm(k) (bldepth_mod.F90:139-180): every hit level posts its hmin,
@@ -700,7 +713,7 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
       const double Uo = ld_old(p.U), Vo = ld_old(p.V), To = ld_old(p.T), So = ld_old(p.S);
       const double dto = p.dto, tri1_nz = c_t1[nz];
       const double wX0_1 = sc[C_WX01], wX0_2 = sc[C_WX02];
-      double *yU = row(R_YU), *yT = row(R_YT), *yS = row(R_YS);
+      const strided<ROWS> yU = row(R_YU), yT = row(R_YT), yS = row(R_YS);
       if (actz) {
         const int jer = si[I_JER];
         const double rho0cp0 = sc[C_RHO0CP0], r_rc = sc[C_RRC], sflux3 = sc[C_SFLUX3];
@@ -736,15 +749,15 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
 
     // ---- M4: Thomas factorise + sweep for U, T, S (solvers.F90:14-44, 112-161)
     if (wv == 0 && do_ocnint)
-      serial_thomas_uts_n(W, slots, SS, NA, nz, c_t0, c_t1, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+      serial_thomas_uts_n(W, slots, SS, 1, ROWS, K_STRIDE, nz, cst + K_T0, cst + K_T1, sirec + I_ACT, I_COUNT,
+                          sirec + I_BAD, I_COUNT, lane);
     __syncthreads();
 
     // ---- L7: V right-hand side with the new U (ocnint_mod.F90:62-69)
     if (active && do_ocnint) {
       const double Uo = ld_old(p.U), Vo = ld_old(p.V);
       const double dto = p.dto, f = sc[C_F];
-      const double *yU = row(R_YU);
-      double *yV = row(R_YV);
+      const strided<ROWS> yU = row(R_YU), yV = row(R_YV);
       if (actz) {
         const double un = yU[k];
         double rhsV;
@@ -760,7 +773,7 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
 
     // ---- M5: Thomas sweep for V on the stored momentum factorisation; ocnstep control
     if (wv == 0) {
-      if (do_ocnint) serial_thomas_v_n(W, slots, SS, NA, nz, c_t0, sirec + I_ACT, I_COUNT, lane);
+      if (do_ocnint) serial_thomas_v_n(W, slots, SS, 1, ROWS, K_STRIDE, nz, cst + K_T0, sirec + I_ACT, I_COUNT, lane);
       G();
     }
     __syncthreads();
@@ -797,7 +810,7 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
         const int ms = lane >> 2;
         const int *msi = sirec + ms * I_COUNT;
         if (msi[I_ACT] && msi[I_FIN] == F_TRAP && msi[I_NVIOL] == 0) {
-          const double *t = slots + ms * SS + (R_YU + (lane & 3)) * NA;
+          const strided<ROWS> t{slots + ms * SS + (R_YU + (lane & 3))};
           double sum = 0.;
           for (int q = 1; q <= nzp1; ++q) sum = sum + t[q];
           sum = __builtin_sqrt(sum);
@@ -849,7 +862,7 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
     if (fin == F_FINAL && p.diag) {   // ocnstep_mod.F90:242-256 / initialize_ocean.F90:66-81
       const size_t ro = rowoff();
       const double wX0_1 = sc[C_WX01], wX0_2 = sc[C_WX02];
-      const double *tU = row(R_YU), *tV = row(R_YT), *tT = row(R_YS), *tS = row(R_GM);
+      const strided<ROWS> tU = row(R_YU), tV = row(R_YT), tT = row(R_YS), tS = row(R_GM);
       const double rho0cp0 = sc[C_RHO0CP0], sflux3 = sc[C_SFLUX3];
       const size_t o = ro + k;
       const double dfm = aDm[k], dfs = aDs[k], dft = aDt[k], gh = aGh[k];
@@ -944,7 +957,7 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
       }
       __syncthreads();
       if (iso) {
-        const double *tD = row(R_YT), *tZ = row(R_YS);
+        const strided<ROWS> tD = row(R_YT), tZ = row(R_YS);
         double dtdz_total = 0., dz_total = 0.;
         for (int q = 2; q <= p.iso_bot; ++q) {
           dtdz_total = dtdz_total + tD[q];

@@ -1,0 +1,16 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r02pk
+B="python bench.py --no-cpu-baseline --steps 10 --warmup 3"
+MCKPP_KERNEL=pk timeout -k 10 600 python -m pytest tests/test_parity_gpu.py -x -q -m gpu -k "pk" 2>&1 | tail -1
+for cfg in ${CFGS:-"60 4x4" "60 8x2" "69 4x4" "69 6x2" "69 8x2" "100 4x4" "100 6x2" "100 7x2" "100 8x2" "40 4x4" "40 7x2" "40 6x2" "150 8x2" "150 6x2"}; do
+  set -- $cfg
+  nz=$1; g=$2
+  extra=""
+  if [ $nz = 150 ]; then extra="--ncol 50000"; fi
+  MCKPP_KERNEL=pk MCKPP_PK=$g timeout -k 10 200 $B --nz $nz $extra > gpurun_out/r02pk/b_${nz}_$g.json 2>/dev/null
+  python - <<PY
+import json
+d=json.load(open("gpurun_out/r02pk/b_${nz}_$g.json"))
+print("nz=$nz pk=$g", "%.3e"%d['value'], "%.3f ms"%d['ms_per_step'], d['roofline']['kernel'], d['config']['mean_passes_per_column_step_last_step'])
+PY
+done
