@@ -70,15 +70,11 @@ struct mckpp_kparams {
 struct mckpp_launch_info { int nblocks, threads, max_blocks_per_cu; size_t lds_bytes; };
 extern mckpp_launch_info g_mckpp_last_launch;
 
-// launchers (mckpp_kernels.hip)
-hipError_t mckpp_launch_column_kernel(const mckpp_kparams &p, hipStream_t stream);
-size_t mckpp_column_kernel_lds_bytes(int nzp1);
-// cooperative kernel (mckpp_kernels_wg.hip): W columns per workgroup, persistent grid
-// `dp` is a device copy of `p` (every field but ntime is read from it; ntime is passed by value)
+// launchers
+// cooperative kernel, one wavefront per column (mckpp_kernels_wg.hip): 4 columns per workgroup, persistent
+// grid; columns of up to 61 levels.  `dp` is a device copy of `p` (every field but ntime is read from it;
+// ntime is passed by value)
 hipError_t mckpp_launch_column_kernel_wg(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu,
-                                         hipStream_t stream);
-// deep-column kernel (mckpp_kernels_mw.hip): WPS waves per column, one level per lane
-hipError_t mckpp_launch_column_kernel_mw(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu,
                                          hipStream_t stream);
 // packed-lane kernel (mckpp_kernels_pk.hip): columns dealt back to back over the workgroup's lanes
 hipError_t mckpp_launch_column_kernel_pk(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu,

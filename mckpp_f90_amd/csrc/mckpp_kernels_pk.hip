@@ -72,14 +72,27 @@ __host__ __device__ inline int pk_ss(int L, bool ext)
 __host__ __device__ inline size_t pk_lds_bytes(int L, int W, bool ext)
 {
   return (size_t)(K_STRIDE * pk_nl(L) + 2 + W * pk_ss(L, ext) + W * C_COUNT) * sizeof(double) +
-         (size_t)(W * I_COUNT + 4) * sizeof(int);
+         (size_t)(W * I_COUNT + 4 + 8) * sizeof(int);
 }
+
+#ifndef MCKPP_PK_MGR_SIMD
+#define MCKPP_PK_MGR_SIMD -1
+#endif
 
 template <int KS>
 struct strided {   // x[i] of a level-interleaved row
   double *b;
   __device__ __forceinline__ double &operator[](int i) const { return b[i * KS]; }
 };
+
+// the manager wave's serial phases are what the other waves of the workgroup wait for
+#ifndef MCKPP_PK_PRIO   // measured: raising the manager wave's priority costs 3 % (its phases are latency-, not issue-bound)
+#define PRIO_HI()
+#define PRIO_LO()
+#else
+#define PRIO_HI() __builtin_amdgcn_s_setprio(3)
+#define PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#endif
 
 template <bool EXT>
 __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__restrict__ pp, const int ntime, const int L,
@@ -112,6 +125,24 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
   if (tid == 0) { c_misc[0] = rcp_refine(p.hm[1]); c_misc[1] = rcp_refine(p.vonk); }
   for (int i = tid; i < W * I_COUNT; i += blockDim.x) sirec[i] = 0;   // every slot PS_EMPTY
   if (tid < 4) s_flags[tid] = 0;
+  // The manager is wave 0.  (Experiment kept behind MCKPP_PK_MGR_SIMD >= 0: electing the wave that sits on a
+  // given SIMD, so that the serial chains of all workgroups of a CU share one SIMD - measured 0.8-0.9x; one
+  // SIMD per workgroup chosen from blockIdx - 0.97x.  Raising the manager's s_setprio: 0.97x.)
+  int mgr = 0;
+#if MCKPP_PK_MGR_SIMD >= 0
+  {
+    int *s_simd = s_flags + 4;   // [8] SIMD id per wave
+    const int simd = (__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4) & 3);   // HW_REG_HW_ID bits 5:4
+    if (lane == 0) s_simd[wv] = simd;
+    __syncthreads();
+    const int nwv = blockDim.x >> 6;
+    mgr = -1;
+    for (int w = 0; w < nwv; ++w)
+      if (mgr < 0 && s_simd[w] == MCKPP_PK_MGR_SIMD) mgr = w;
+    if (mgr < 0) mgr = 0;
+    mgr = __builtin_amdgcn_readfirstlane(mgr);
+  }
+#endif
 
   // ---- lane -> (slot, level) ------------------------------------------------
   int slot = tid / L;
@@ -430,10 +461,22 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
   };
 
   // =========================== persistent pass loop ===========================
-  if (wv == 0) M0();
+  // p.dbg != nullptr (MCKPP_STAMP=1): wave 0 of every workgroup accumulates shader cycles per segment
+  unsigned long long tlast = p.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+#define STAMP(i)                                                       \
+  do {                                                                 \
+    if (p.dbg && wv == mgr) {                                            \
+      unsigned long long t_ = __builtin_amdgcn_s_memtime();            \
+      if (lane == 0) atomicAdd(p.dbg + (i), t_ - tlast);               \
+      tlast = t_;                                                      \
+    }                                                                  \
+  } while (0)
+  if (wv == mgr) M0();
   __syncthreads();
   for (;;) {
     if (!s_flags[0]) break;
+    STAMP(22);
+    if (p.dbg && wv == mgr && lane == 0) atomicAdd(p.dbg + 31, 1ull);
     k = k0;
     asm volatile("" : "+v"(k));   // keeps the k-indexed grid-constant LDS reads inside the loop
     const bool active = si[I_ACT] != 0;
@@ -498,10 +541,12 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
         }
       }
     }
+    STAMP(0);
     __syncthreads();
+    STAMP(1);
 
     // ---- M1 | L2: surface fluxes (wave 0) | reference-level loop, Ri pieces (verticalmixing_mod.F90:111-137)
-    if (wv == 0) M1();
+    if (wv == mgr) M1();
     if (active) {
       const double zm1 = c_zm[1];
       const double U1 = aU[1], V1 = aV[1], Bu1 = aB[1];
@@ -549,7 +594,9 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
         if (actz) { p.Rig[o] = Rig; p.dbloc[o] = dbloc; p.Shsq[o] = shsq; }
       }
     }
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
 
     // ---- L3: rimix + z121 (rimix_mod.F90:13-106, z121_mod.F90:7-45), ddmix, interior diffusivity rows;
     //          bldepth, level-parallel part (bldepth_mod.F90:105-147)
@@ -614,11 +661,15 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
       if (k >= 2 && actz) { aRaw[k] = raw; aDmo[k] = dmo; }
       if (is1) { aRaw[1] = 0.0; aDmo[1] = -zm_kmp1; }
     }
+    STAMP(4);
     __syncthreads();
+    STAMP(5);
 
     // ---- M2: Rib(ku) = MAX(Rib(ku), Rib(ka)+epsln), bldepth_mod.F90:137
-    if (wv == 0) serial_scan_rib_n(W, R_RAW, slots, SS, 1, ROWS, nz, sirec + I_ACT, I_COUNT, lane);
+    if (wv == mgr) { PRIO_HI(); serial_scan_rib_n(W, R_RAW, slots, SS, 1, ROWS, nz, sirec + I_ACT, I_COUNT, lane); PRIO_LO(); }
+    STAMP(6);
     __syncthreads();
+    STAMP(7);
 
     // ---- L4: first level with hmin < -zm(k) (bldepth_mod.F90:139-180): every hit level posts its hmin,
     //          the shallowest one wins through an LDS minimum
@@ -653,11 +704,15 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
       const bool prev = lane > 0 && ((m >> (lane - 1)) & 1ull);
       if (hit && !prev) atomicMin(&si[I_KBLC], k);
     }
+    STAMP(8);
     __syncthreads();
+    STAMP(9);
 
     // ---- M3: hbl, kbl, slot-uniform part of blmix
-    if (wv == 0) M3();
+    if (wv == mgr) { PRIO_HI(); M3(); PRIO_LO(); }
+    STAMP(10);
     __syncthreads();
+    STAMP(11);
 
     // ---- L5: blmix shape functions, enhance, combine (blmix_mod.F90:110-133, enhance_mod.F90:10-51,
     //          kppmix_mod.F90:103-111, verticalmixing_mod.F90:151-159) -> final diffusivity rows
@@ -705,7 +760,9 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
       if (k >= nz) { difm = 0.0001; difs = 0.00001; dift = 0.00001; ghat = 0.0; }
       if (act) { aDm[k] = difm; aDs[k] = difs; aDt[k] = dift; aGh[k] = ghat; }
     }
+    STAMP(12);
     __syncthreads();
+    STAMP(13);
 
     // ---- L6: right-hand sides of U, T, S (ocnint_mod.F90:51-58, tridrhs solvers.F90:53-107)
     if (active && do_ocnint) {
@@ -745,13 +802,20 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
         if constexpr (EXT) { double t = 0.0, s2 = 0.0; ext_rhs(si[I_KBL], To, So, t, s2); }   // ocnint_mod.F90:153-160, 207-213
       }
     }
+    STAMP(14);
     __syncthreads();
+    STAMP(15);
 
     // ---- M4: Thomas factorise + sweep for U, T, S (solvers.F90:14-44, 112-161)
-    if (wv == 0 && do_ocnint)
+    if (wv == mgr && do_ocnint) {
+      PRIO_HI();
       serial_thomas_uts_n(W, slots, SS, 1, ROWS, K_STRIDE, nz, cst + K_T0, cst + K_T1, sirec + I_ACT, I_COUNT,
                           sirec + I_BAD, I_COUNT, lane);
+      PRIO_LO();
+    }
+    STAMP(16);
     __syncthreads();
+    STAMP(17);
 
     // ---- L7: V right-hand side with the new U (ocnint_mod.F90:62-69)
     if (active && do_ocnint) {
@@ -769,14 +833,20 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
         yV[k] = Vo;
       }
     }
+    STAMP(18);
     __syncthreads();
+    STAMP(19);
 
     // ---- M5: Thomas sweep for V on the stored momentum factorisation; ocnstep control
-    if (wv == 0) {
+    if (wv == mgr) {
+      PRIO_HI();
       if (do_ocnint) serial_thomas_v_n(W, slots, SS, 1, ROWS, K_STRIDE, nz, cst + K_T0, sirec + I_ACT, I_COUNT, lane);
       G();
+      PRIO_LO();
     }
+    STAMP(20);
     __syncthreads();
+    STAMP(21);
     if (!s_flags[1]) continue;
 
     // =========================== finish round ===========================
@@ -804,7 +874,7 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
       row(R_GM)[k] = (S - So) * (S - So) * hk / p.dm_nz;
     }
     __syncthreads();
-    if (wv == 0) {   // trap decision, one lane per (slot, profile) for the rmsd sums, then one per slot
+    if (wv == mgr) {   // trap decision, one lane per (slot, profile) for the rmsd sums, then one per slot
       bool over = false;
       if (lane < 4 * W) {
         const int ms = lane >> 2;
@@ -1017,33 +1087,31 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
       }
     }
     __syncthreads();   // every read of the finished slots' records is done: hand them to the queue
-    if (wv == 0) M0();
+    if (wv == mgr) M0();
     __syncthreads();
   }
+#undef STAMP
 }
 
 struct pk_geom { int nw, w, per_cu; };
 
-// Waves per workgroup / columns per workgroup / workgroups per CU for a column of L lanes.
-// 128 VGPRs -> 16 waves per CU; the serial sweeps want W <= 10 (bank-conflict-free lanes) and the
-// fewer lanes are left over at the end of the last wave the better.
-pk_geom pk_choose(int L, bool ext, int num_cu_lds_bytes)
+// Columns per workgroup / waves per workgroup / workgroups per CU for a column of L lanes (measured on
+// 1e5 columns at 40..150 levels): as many columns as fit 512 lanes - the manager phases cost the same
+// for one slot as for sixteen - in as few waves as hold them, two workgroups per CU (16 waves at 128
+// VGPRs) or more when the workgroup is small.  Odd-sized workgroups of 5 or 6 waves that leave the CU
+// at 12-15 waves measured 20-40 % slower than 4 or 8.
+pk_geom pk_choose(int L, bool ext, size_t cu_lds_bytes)
 {
-  pk_geom best{4, 1, 1};
-  double best_score = -1.0;
-  for (int nw = 4; nw <= 8; ++nw) {
-    const int w = (64 * nw) / L;
-    if (w < 1 || w > 10) continue;
-    int per_cu = 16 / nw;
-    const size_t lds = pk_lds_bytes(L, w, ext);
-    while (per_cu > 0 && (size_t)per_cu * ((lds + 1279) / 1280 * 1280) > (size_t)num_cu_lds_bytes) --per_cu;
-    if (per_cu < 1) continue;
-    const double util = (double)(w * L) / (64.0 * nw);
-    const double occ = (double)(per_cu * nw) / 16.0;
-    const double score = util * (0.5 + 0.5 * occ) * (nw == 5 || nw == 7 ? 0.97 : 1.0);
-    if (score > best_score) { best_score = score; best = {nw, w, per_cu}; }
-  }
-  return best;
+  int w = 512 / L;
+  if (w < 1) w = 1;
+  if (w > 16) w = 16;   // 4 lanes per slot in the trap's rmsd sums
+  auto granules = [&](int w_) { return (pk_lds_bytes(L, w_, ext) + 1279) / 1280 * 1280; };
+  while (w > 1 && 2 * granules(w) > cu_lds_bytes) --w;
+  const int nw = (w * L + 63) / 64;
+  int per_cu = 16 / nw;
+  while (per_cu > 1 && (size_t)per_cu * granules(w) > cu_lds_bytes) --per_cu;
+  if (per_cu < 1) per_cu = 1;
+  return {nw, w, per_cu};
 }
 
 }  // namespace
@@ -1056,7 +1124,7 @@ hipError_t mckpp_launch_column_kernel_pk(const mckpp_kparams &p, const mckpp_kpa
   const int L = p.nzp1 + 2;
   if (L > 512) return hipErrorInvalidValue;
   const bool ext = p.ext != 0;
-  pk_geom g = pk_choose(L, ext, 160 * 1024);
+  pk_geom g = pk_choose(L, ext, (size_t)160 * 1024);
   if (const char *e = getenv("MCKPP_PK")) {
     int nw = 0, b = 0;
     if (sscanf(e, "%dx%d", &nw, &b) >= 1 && nw >= 1 && nw <= 8 && (64 * nw) / L >= 1) {

@@ -21,8 +21,8 @@
 // crosses phases through the slot's LDS rows or its LDS scalar record, and
 // per-column inputs are re-read with scalar loads where they are used.
 //
-// Arithmetic is identical, operation for operation, to k_column in
-// mckpp_kernels.hip; the tests require bit-identical results from both.
+// Arithmetic is identical, operation for operation, to k_column_pk
+// (mckpp_kernels_pk.hip); the tests require bit-identical results from both.
 #include "mckpp_sweeps.h"
 
 #include <cstdio>
@@ -1075,10 +1075,12 @@ hipError_t launch_wg(const mckpp_kparams &p, const mckpp_kparams *dp, int nblock
 // Persistent grid: enough workgroups to fill every CU at the occupancy LDS and
 // registers allow, never more than there are W-column groups.
 // MCKPP_WG=<W>[x<blocks per CU>] overrides the geometry (experiments).
+// Only the one-level-per-lane instantiation (LPL = 1, columns of up to 61 levels) is built: deeper
+// columns run k_column_pk.
 hipError_t mckpp_launch_column_kernel_wg(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu, hipStream_t stream)
 {
   if (p.ncol <= 0) return hipSuccess;
-  const int lpl = (p.nzp1 + 2 + 63) / 64;
+  if (p.nzp1 + 2 > 64) return hipErrorInvalidValue;
   static int envW = -1, envB = 0;
   if (envW < 0) {
     envW = 0;
@@ -1087,42 +1089,22 @@ hipError_t mckpp_launch_column_kernel_wg(const mckpp_kparams &p, const mckpp_kpa
       if (sscanf(e, "%dx%d", &w, &b) >= 1) { envW = w; envB = b; }
     }
   }
-  int W, per_cu;
-  switch (lpl) {
-    case 1: W = 4; per_cu = 5; break;   // 31.9 KB LDS and <=96 VGPRs per wave: 20 waves per CU
-    case 2: W = 2; per_cu = 4; break;   // 33.8 KB LDS per workgroup, <=168 VGPRs
-    default: W = 4; per_cu = 1; break;
-  }
-  if (lpl == 1 && (envW == 4 || envW == 8)) { W = envW; per_cu = (W == 8) ? 2 : 5; }
-  if (lpl == 2 && (envW == 2 || envW == 4)) { W = envW; per_cu = (W == 2) ? 4 : 2; }
+  int W = 4, per_cu = 5;   // 31.9 KB LDS and <=96 VGPRs per wave: 20 waves per CU
+  if (envW == 4 || envW == 8) { W = envW; per_cu = (W == 8) ? 2 : 5; }
   if (envB > 0) per_cu = envB;
   int nblocks = num_cu * per_cu;
   const int groups = (p.ncol + W - 1) / W;
   if (nblocks > groups) nblocks = groups;
   if (nblocks < 1) nblocks = 1;
-  if (p.ext) {   // optional-physics build: W = 4, register budget of two (LPL=1) or one workgroup per SIMD set
-    per_cu = (lpl == 1) ? 4 : (lpl == 2 ? 2 : 1);
-    nblocks = num_cu * per_cu;
+  if (p.ext) {   // optional-physics build: W = 4, register budget of four workgroups per CU
+    nblocks = num_cu * 4;
     if (nblocks > (p.ncol + 3) / 4) nblocks = (p.ncol + 3) / 4;
     if (nblocks < 1) nblocks = 1;
-    switch (lpl) {
-      case 1: return launch_wg<1, 4, 4, true>(p, dp, nblocks, stream);
-      case 2: return launch_wg<2, 4, 2, true>(p, dp, nblocks, stream);
-      case 3: return launch_wg<3, 4, 1, true>(p, dp, nblocks, stream);
-      default: return hipErrorInvalidValue;
-    }
+    return launch_wg<1, 4, 4, true>(p, dp, nblocks, stream);
   }
-  switch (lpl) {
-    case 1:
-      if (W == 8) return (per_cu >= 2) ? launch_wg<1, 8, 4>(p, dp, nblocks, stream) : launch_wg<1, 8, 2>(p, dp, nblocks, stream);
-      if (per_cu >= 5) return launch_wg<1, 4, 5>(p, dp, nblocks, stream);   // 96-VGPR build
-      if (per_cu >= 4) return launch_wg<1, 4, 4>(p, dp, nblocks, stream);   // 128-VGPR build
-      if (per_cu == 3) return launch_wg<1, 4, 3>(p, dp, nblocks, stream);   // 168-VGPR build
-      return launch_wg<1, 4, 2>(p, dp, nblocks, stream);
-    case 2:
-      if (W == 2) return (per_cu >= 6) ? launch_wg<2, 2, 4>(p, dp, nblocks, stream) : launch_wg<2, 2, 3>(p, dp, nblocks, stream);
-      return launch_wg<2, 4, 2>(p, dp, nblocks, stream);
-    case 3: return launch_wg<3, 4, 1>(p, dp, nblocks, stream);
-    default: return hipErrorInvalidValue;
-  }
+  if (W == 8) return (per_cu >= 2) ? launch_wg<1, 8, 4>(p, dp, nblocks, stream) : launch_wg<1, 8, 2>(p, dp, nblocks, stream);
+  if (per_cu >= 5) return launch_wg<1, 4, 5>(p, dp, nblocks, stream);   // 96-VGPR build
+  if (per_cu >= 4) return launch_wg<1, 4, 4>(p, dp, nblocks, stream);   // 128-VGPR build
+  if (per_cu == 3) return launch_wg<1, 4, 3>(p, dp, nblocks, stream);   // 168-VGPR build
+  return launch_wg<1, 4, 2>(p, dp, nblocks, stream);
 }

@@ -88,7 +88,7 @@ struct mckpp_hip_ctx {
   int num_cu = 256;
   double *d_series = nullptr;   // [nrec][8][ncol] forcing records (mckpp_hip_set_flux_series)
   int series_rec0 = 0, series_nrec = 0;
-  int kernel_variant = 2;   // 1: one wave per column (v1), 2: k_column_wg, 3: k_column_mw, 4: k_column_pk (packed lanes)
+  int kernel_variant = 4;   // 2: k_column_wg (one wavefront per column), 4: k_column_pk (packed lanes)
   mckpp_launch_info last_launch{};   // geometry of this context's most recent cooperative launch
   double *d_stage = nullptr;
   size_t stage_elems = 0;
@@ -192,25 +192,28 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   h->ext = c->LDD || c->L_RELAX_SST || c->L_FCORR || c->L_FCORR_WITHZ || c->L_SFCORR || c->L_SFCORR_WITHZ ||
            c->L_RELAX_SAL || c->L_RELAX_OCNT || c->L_NO_FREEZE || c->L_NO_ISOTHERM || c->L_DAMP_CURR ||
            c->clim_present || c->L_ADVECT;
-  // deep columns (more than 62 levels) run one level per lane over
-  // several waves (mckpp_kernels_mw.hip); MCKPP_KERNEL=v1|wg|mw overrides (experiments, tests)
-  if (lpl > 1) h->kernel_variant = 3;
-  if (const char *kv = getenv("MCKPP_KERNEL")) {
-    if (strcmp(kv, "v1") == 0) h->kernel_variant = 1;
-    else if (strcmp(kv, "wg") == 0) h->kernel_variant = 2;
-    else if (strcmp(kv, "mw") == 0) h->kernel_variant = 3;
-    else if (strcmp(kv, "pk") == 0) h->kernel_variant = 4;
+  // Kernel choice.  k_column_pk (packed lanes) everywhere except where a column fills a wavefront almost
+  // exactly (59..64 lanes = 56..61 levels): there k_column_wg keeps the column's scalars in SGPRs and
+  // is ~6 % faster (measured, 1e5 columns).  MCKPP_KERNEL=v1|wg|mw|pk overrides (experiments, tests).
+  {
+    const int lanes = nzp1 + 2;
+    h->kernel_variant = (lanes >= 59 && lanes <= 64) ? 2 : 4;
   }
-  if (h->ext && h->kernel_variant == 1) {
+  if (const char *kv = getenv("MCKPP_KERNEL")) {
+    if (strcmp(kv, "wg") == 0) h->kernel_variant = 2;
+    else if (strcmp(kv, "pk") == 0) h->kernel_variant = 4;
+    else { delete h; return fail("mckpp_hip_init: MCKPP_KERNEL=%s (known: wg, pk)", kv); }
+  }
+  if (h->kernel_variant == 2 && nzp1 + 2 > 64) {
     delete h;
-    return fail("mckpp_hip_init: MCKPP_KERNEL=v1 carries the default physics only");
+    return fail("mckpp_hip_init: MCKPP_KERNEL=wg carries columns of up to 61 levels (nz=%d)", c->nz);
   }
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipMalloc(&h->d_qhead, sizeof(int)));
   HIPCHK(hipMalloc(&h->d_params, sizeof(mckpp_kparams)));
   if (getenv("MCKPP_STAMP")) {
-    HIPCHK(hipMalloc(&h->d_dbg, 16 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(h->d_dbg, 0, 16 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&h->d_dbg, 32 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(h->d_dbg, 0, 32 * sizeof(unsigned long long)));
   }
   HIPCHK(hipEventCreate(&h->ev0));
   HIPCHK(hipEventCreate(&h->ev1));
@@ -627,7 +630,7 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode, const forced_r
     return fail("optional-physics context: the relaxation / correction / advection inputs are not resident "
                 "(after mckpp_hip_load_restart call mckpp_hip_update_ancillaries before stepping)");
   HIPCHK(hipSetDevice(h->device));
-  if (h->kernel_variant != 1) {   // parameter block (identical for every launch of this call but ntime)
+  {   // parameter block (identical for every launch of this call but ntime)
     mckpp_kparams p0;
     fill_params(h, p0, ntime, mode);
     HIPCHK(hipMemcpyAsync(h->d_params, &p0, sizeof p0, hipMemcpyHostToDevice, h->stream));
@@ -642,17 +645,12 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode, const forced_r
       HIPCHK(mckpp_launch_fluxes(p, ntime + i, h->d_series + (size_t)rec * 8 * (size_t)h->ncol, forced->l_rest,
                                  forced->flsn, forced->el, h->stream));
     }
-    if (h->kernel_variant == 1) {
-      HIPCHK(mckpp_launch_column_kernel(p, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_qhead, 0, sizeof(int), h->stream));
+    if (h->kernel_variant == 4) {
+      HIPCHK(mckpp_launch_column_kernel_pk(p, h->d_params, h->num_cu, h->stream, &h->last_launch));
     } else {
-      HIPCHK(hipMemsetAsync(h->d_qhead, 0, sizeof(int), h->stream));
-      if (h->kernel_variant == 4) {
-        HIPCHK(mckpp_launch_column_kernel_pk(p, h->d_params, h->num_cu, h->stream, &h->last_launch));
-      } else {
-        if (h->kernel_variant == 3) HIPCHK(mckpp_launch_column_kernel_mw(p, h->d_params, h->num_cu, h->stream));
-        else HIPCHK(mckpp_launch_column_kernel_wg(p, h->d_params, h->num_cu, h->stream));
-        h->last_launch = g_mckpp_last_launch;
-      }
+      HIPCHK(mckpp_launch_column_kernel_wg(p, h->d_params, h->num_cu, h->stream));
+      h->last_launch = g_mckpp_last_launch;
     }
   }
   HIPCHK(hipEventRecord(h->ev1, h->stream));
@@ -713,11 +711,20 @@ int mckpp_hip_synchronize(mckpp_hip_handle h)
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
-  if (h->d_dbg) {   // MCKPP_STAMP=1: print and reset the per-segment cycle sums of wave 1 of every workgroup
-    unsigned long long t[16];
+  if (h->d_dbg) {   // MCKPP_STAMP=1: print and reset the per-segment cycle sums of the stamping wave of every workgroup
+    unsigned long long t[32];
     HIPCHK(hipMemcpy(t, h->d_dbg, sizeof t, hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(h->d_dbg, 0, sizeof t));
-    if (t[11]) {
+    if (h->kernel_variant == 4) {
+      if (t[31]) {
+        const char *nm[23] = {"L1", "w", "M1L2", "w", "L3", "w", "M2", "w", "L4", "w", "M3", "w", "L5", "w", "L6", "w",
+                              "M4", "w", "L7", "w", "M5", "w", "finish"};
+        fprintf(stderr, "[mckpp stamps pk] wave-passes %llu; cycles per wave-pass:", t[31]);
+        double tot = 0;
+        for (int i = 0; i < 23; ++i) { fprintf(stderr, " %s=%.0f", nm[i], (double)t[i] / (double)t[31]); tot += (double)t[i]; }
+        fprintf(stderr, " total=%.0f\n", tot / (double)t[31]);
+      }
+    } else if (t[11]) {
       const char *nm[11] = {"refill", "A", "waitA", "scan", "C", "waitC", "UTS", "E", "waitE", "V", "G"};
       fprintf(stderr, "[mckpp stamps] wave-passes %llu; cycles per wave-pass:", t[11]);
       for (int i = 0; i < 11; ++i) fprintf(stderr, " %s=%.0f", nm[i], (double)t[i] / (double)t[11]);
@@ -730,21 +737,15 @@ int mckpp_hip_synchronize(mckpp_hip_handle h)
 const char *mckpp_hip_kernel_name(mckpp_hip_handle h)
 {
   if (!h) return "none";
-  static const char *names[4][3] = {{"", "", ""},
-                                    {"k_column<1>", "k_column<2>", "k_column<3>"},
-                                    {"k_column_wg<1>", "k_column_wg<2>", "k_column_wg<3>"},
-                                    {"k_column_mw<1>", "k_column_mw<2>", "k_column_mw<3>"}};
-  if (h->ext && h->kernel_variant == 2) return h->lpl == 1 ? "k_column_wg<1,EXT>" : h->lpl == 2 ? "k_column_wg<2,EXT>" : "k_column_wg<3,EXT>";
-  if (h->ext && h->kernel_variant == 3) return h->lpl == 1 ? "k_column_mw<1,EXT>" : h->lpl == 2 ? "k_column_mw<2,EXT>" : "k_column_mw<3,EXT>";
-  if (h->kernel_variant == 4) return h->ext ? "k_column_pk<EXT>" : "k_column_pk";
-  return names[h->kernel_variant][h->lpl - 1];
+  if (h->kernel_variant == 2) return h->ext ? "k_column_wg<1,EXT>" : "k_column_wg<1>";
+  return h->ext ? "k_column_pk<EXT>" : "k_column_pk";
 }
 
 int mckpp_hip_kernel_residency(mckpp_hip_handle h, int32_t *blocks_per_cu, int32_t *max_blocks_per_cu,
                                int32_t *threads_per_block, int64_t *lds_bytes_per_block)
 {
   if (!h) return fail("null handle");
-  if (h->kernel_variant == 1 || h->last_launch.threads == 0)
+  if (h->last_launch.threads == 0)
     return fail("mckpp_hip_kernel_residency: no cooperative-kernel launch yet");
   if (blocks_per_cu) *blocks_per_cu = (h->last_launch.nblocks + h->num_cu - 1) / h->num_cu;
   if (max_blocks_per_cu) *max_blocks_per_cu = h->last_launch.max_blocks_per_cu;

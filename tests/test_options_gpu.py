@@ -189,13 +189,11 @@ def test_vary_bottom_temp(mk, nz, switches):
         ctx.bottomtemp(k3.bottom_temp)
 
 
-@pytest.mark.parametrize("variant", [None, "wg"])
-@pytest.mark.parametrize("nz", [69, 150])
+@pytest.mark.parametrize("nz,variant", [(69, None), (100, None), (150, None), (60, "pk"), (60, "wg")])
 def test_options_on_deep_columns(mk, monkeypatch, nz, variant):
-    """The optional physics on columns that span two or three wavefronts (k_column_mw<.,EXT>, and the
-    several-levels-per-lane form of k_column_wg as a second implementation): the level counts of
-    check_profile (damped levels, frozen levels), the isotherm sums and the double-diffusion neighbours
-    cross the 64-level wave boundary here."""
+    """The optional physics on columns that span two or three wavefronts (k_column_pk<EXT>): the level
+    counts of check_profile (damped levels, frozen levels), the isotherm sums and the double-diffusion
+    neighbours cross wave boundaries here; and the same cases at 60 levels on both kernels."""
     if variant is None:
         monkeypatch.delenv("MCKPP_KERNEL", raising=False)
     else:
@@ -216,12 +214,12 @@ def test_options_on_deep_columns(mk, monkeypatch, nz, variant):
 
     # current damping with strong deep currents (levels beyond the first wave are damped too)
     def prep_damp(k3, ob):
-        k3.U[::2, 60:, 0] = 3.0
-        k3.U[1::4, 66:, 1] = -2.5
+        k3.U[::2, min(60, nz - 8):, 0] = 3.0
+        k3.U[1::4, min(66, nz - 4):, 1] = -2.5
         ob.a["U"][:, 1:nzp1 + 1] = k3.U[:, :, 0]
         ob.a["V"][:, 1:nzp1 + 1] = k3.U[:, :, 1]
     k3, ob = _case(mk, 40, nz, dict(L_DAMP_CURR=1, dt_uvdamp=360), prep_damp, nsteps=2)
-    assert np.any(k3.dampu_flag > 64.0 / nzp1) or np.any(k3.dampv_flag > 0)
+    assert np.any(k3.dampu_flag > 0) or np.any(k3.dampv_flag > 0)
 
     # freeze clamp over the whole depth, isotherm check over 80 levels, climatology reset after a trap
     def prep_frz(k3, ob):
@@ -250,7 +248,7 @@ def test_options_on_deep_columns(mk, monkeypatch, nz, variant):
         _set2(k3, ob, "fcorr_withz", 5.0 * np.exp(-z / 10.0) * np.linspace(-1, 1, n)[:, None])
         _set2(k3, ob, "sfcorr_withz", 1e-7 * np.cos(z / 7.0) * np.ones((n, 1)))
     k3, ob = _case(mk, 40, nz, dict(L_RELAX_OCNT=1, L_RELAX_SAL=1, L_FCORR_WITHZ=1, L_SFCORR_WITHZ=1), prep_rel)
-    assert np.any(k3.ocnTcorr[:, 64:] != 0) and np.any(k3.scorr[:, 64:] != 0)
+    assert np.any(k3.ocnTcorr[:, min(64, nz - 2):] != 0) and np.any(k3.scorr[:, min(64, nz - 2):] != 0)
 
     # prescribed advection, all seven modes
     def prep_adv(k3, ob):
@@ -268,7 +266,7 @@ def test_options_on_deep_columns(mk, monkeypatch, nz, variant):
 
 def test_optional_physics_kernel_selection(mk, monkeypatch):
     monkeypatch.delenv("MCKPP_KERNEL", raising=False)
-    for nz, want in [(40, "k_column_wg<1,EXT>"), (69, "k_column_mw<2,EXT>"), (150, "k_column_mw<3,EXT>")]:
+    for nz, want in [(40, "k_column_pk<EXT>"), (60, "k_column_wg<1,EXT>"), (69, "k_column_pk<EXT>"), (150, "k_column_pk<EXT>")]:
         kc = mk.KppConstFields(nz)
         kc.L_DAMP_CURR = 1
         mk.mckpp_physics_lookup(kc)

@@ -467,10 +467,10 @@ def test_config4_100_levels_slice(mk):
 
 
 # ---- kernel variants -------------------------------------------------------------------------
-# The library holds three implementations of the same column step: k_column (one wave per
-# column), k_column_wg (cooperative, several levels per lane for deep columns) and k_column_mw
-# (cooperative, one level per lane over several waves).  MCKPP_KERNEL selects one at init; every
-# variant must reproduce the oracle's bits on every shape it accepts.
+# The library holds two implementations of the column step: k_column_pk (packed lanes: a column takes
+# nzp1+2 lanes wherever they fall in the workgroup; every depth) and k_column_wg (one wavefront per
+# column, up to 61 levels; the default where a column fills a wavefront almost exactly).
+# MCKPP_KERNEL=wg|pk selects one at init; both must reproduce the oracle's bits on every shape they accept.
 
 @pytest.fixture
 def kernel_env(monkeypatch):
@@ -484,8 +484,8 @@ def kernel_env(monkeypatch):
 
 def test_default_kernel_selection(mk, kernel_env):
     kernel_env(None)
-    for nz, want in [(40, "k_column_wg<1>"), (61, "k_column_wg<1>"), (62, "k_column_mw<2>"), (69, "k_column_mw<2>"),
-                     (125, "k_column_mw<2>"), (126, "k_column_mw<3>"), (150, "k_column_mw<3>")]:
+    for nz, want in [(40, "k_column_pk"), (55, "k_column_pk"), (56, "k_column_wg<1>"), (61, "k_column_wg<1>"),
+                     (62, "k_column_pk"), (69, "k_column_pk"), (100, "k_column_pk"), (150, "k_column_pk")]:
         kc = mk.KppConstFields(nz)
         mk.mckpp_physics_lookup(kc)
         ctx = mk.MckppHip(kc)
@@ -495,28 +495,36 @@ def test_default_kernel_selection(mk, kernel_env):
     kc.LDD = True
     mk.mckpp_physics_lookup(kc)
     ctx = mk.MckppHip(kc)
-    assert ctx.kernel_name == "k_column_mw<2,EXT>"     # deep columns: the one-level-per-lane kernel, optional-physics build
+    assert ctx.kernel_name == "k_column_pk<EXT>"     # optional-physics build
     ctx.close()
+    kernel_env("wg")                                 # the one-wavefront kernel refuses columns it cannot hold
+    with pytest.raises(mk.MckppHipError, match="61 levels"):
+        mk.MckppHip(kc)
+    kernel_env("v1")
+    with pytest.raises(mk.MckppHipError, match="known: wg, pk"):
+        mk.MckppHip(kc)
 
 
-@pytest.mark.parametrize("variant", ["v1", "wg", "mw", "pk"])
+@pytest.mark.parametrize("variant", ["wg", "pk"])
 @pytest.mark.parametrize("nz,ncol,nsteps,grid", [(40, 70, 2, "uniform"), (61, 67, 2, "uniform"), (62, 67, 2, "uniform"),
                                                  (69, 131, 2, "stretched"), (125, 35, 2, "uniform"),
                                                  (126, 35, 2, "uniform"), (150, 41, 2, "uniform")])
 def test_every_kernel_variant_bitexact(mk, kernel_env, variant, nz, ncol, nsteps, grid):
     """Same inputs through each implementation; 61/62 and 125/126 levels straddle the points where a
     column stops fitting one (two) wave(s) with its two virtual equation-of-state slots."""
+    if variant == "wg" and nz > 61:
+        pytest.skip("k_column_wg holds columns of up to 61 levels")
     kernel_env(variant)
     out, k3, ob, kc, oc = _run_both(mk, ncol, nz, nsteps, grid=grid, land_every=5, jerlov_mix=True)
-    want = {"v1": "k_column<", "wg": "k_column_wg<", "mw": "k_column_mw<", "pk": "k_column_pk"}[variant]
+    want = {"wg": "k_column_wg<", "pk": "k_column_pk"}[variant]
     assert kc._hip_ctx.kernel_name.startswith(want), kc._hip_ctx.kernel_name
     for tag, res in out:
         _assert_bitexact(res, f"{variant} nz={nz} {tag}")
 
 
-@pytest.mark.parametrize("variant,nz", [("mw", 40), ("mw", 69), ("mw", 150), ("wg", 69), ("pk", 40), ("pk", 69), ("pk", 100), ("pk", 150)])
+@pytest.mark.parametrize("variant,nz", [("wg", 40), ("wg", 60), ("pk", 40), ("pk", 60), ("pk", 69), ("pk", 100), ("pk", 150)])
 def test_instability_trap_every_variant(mk, kernel_env, variant, nz):
-    """The retry round of the deep-column kernel (cross-wave violation counts and rmsd sums)."""
+    """The retry round (violation counts and rmsd sums over lanes of several waves in k_column_pk)."""
     from oracle import orc
 
     kernel_env(variant)
@@ -550,12 +558,12 @@ def test_instability_trap_every_variant(mk, kernel_env, variant, nz):
 
 
 def test_config2_pass_every_variant(mk, kernel_env):
-    """configs[1]-style single vmix+ocnint pass on the deep-column kernel."""
+    """configs[1]-style single vmix+ocnint pass on both kernels."""
     from oracle import orc
 
     fields = ["U", "V", "T", "S", "hmix", "kmix", "uref", "vref", "rho", "cp", "buoy", "difm", "difs", "dift",
               "ghat", "Rig", "dbloc", "Shsq", "wXNT1"]
-    for variant, nz in [("mw", 60), ("mw", 100), ("mw", 150), ("pk", 40), ("pk", 69), ("pk", 100), ("pk", 150)]:
+    for variant, nz in [("wg", 60), ("pk", 40), ("pk", 60), ("pk", 69), ("pk", 100), ("pk", 150)]:
         kernel_env(variant)
         ncol = 300
         oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1)
@@ -564,7 +572,7 @@ def test_config2_pass_every_variant(mk, kernel_env):
         ob["sflux"] = sf
         cm.set_forcing_3d(k3, sf)
         ctx = mk.MckppHip(kc)
-        assert ctx.kernel_name.startswith("k_column_mw<" if variant == "mw" else "k_column_pk")
+        assert ctx.kernel_name.startswith("k_column_wg<" if variant == "wg" else "k_column_pk")
         ctx.upload(k3)
         ctx.vmix_pass(1)
         ctx.download(k3)
@@ -573,7 +581,7 @@ def test_config2_pass_every_variant(mk, kernel_env):
         ctx.close()
 
 
-@pytest.mark.parametrize("variant,nz", [("v1", 40), ("wg", 40), ("wg", 60), ("mw", 40), ("mw", 69), ("wg", 69), ("pk", 40), ("pk", 60), ("pk", 69), ("pk", 100)])
+@pytest.mark.parametrize("variant,nz", [("wg", 40), ("wg", 60), ("pk", 40), ("pk", 60), ("pk", 69), ("pk", 100)])
 def test_tiny_and_denormal_velocities_take_the_ieee_paths(mk, kernel_env, variant, nz):
     """The kernels drop the v_div_scale rescaling where operand ranges are known and guard the
     quotients whose numerators can be tiny non-zero numbers (velocities diffused down a deep column):
@@ -755,7 +763,7 @@ def test_seeded_sweep_of_shapes_and_forcings(mk, kernel_env):
         grid = "stretched" if (i % 3 == 1 and nz >= 10) else "uniform"
         dto = [3600.0, 1200.0, 900.0][i % 3]
         ncol = int(rng.integers(3, 40))
-        for variant in (None, "wg" if nz > 61 else "mw"):
+        for variant in ((None, "wg" if 56 > nz else "pk") if nz <= 61 else (None,)):
             kernel_env(variant)
             oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1, grid=grid, dto=dto)
             kc, k3 = cm.make_hip_case(ncol, nz, grid=grid, dto=dto, land_every=int(rng.integers(0, 6)))
@@ -826,11 +834,12 @@ def test_full_size_soak_determinism_and_sample_parity(mk):
     _assert_bitexact(cm.compare(sub, ob, nz, cm.PROFILE_FIELDS + cm.SCALAR_FIELDS + ["hmixd0", "hmixd1"]), "soak sample")
 
 
-@pytest.mark.parametrize("nz,ncol,want", [(60, 20000, 5), (40, 20000, 5), (69, 20000, 4), (100, 20000, 4), (150, 20000, 5)])
+@pytest.mark.parametrize("nz,ncol,want", [(60, 20000, 5), (40, 20000, 2), (69, 20000, 2), (100, 20000, 2), (150, 20000, 2)])
 def test_tuned_residency_is_what_the_device_grants(mk, kernel_env, nz, ncol, want):
-    """The cooperative kernels are tuned to a number of resident workgroups per CU (5 x 4 columns at
-    up to 61 levels: <= 96 VGPRs and <= 25 LDS granules of 1,280 B each).  One more LDS row or a few
-    more registers silently drops a workgroup per CU (-10 % or worse), so ask the runtime."""
+    """The cooperative kernels are tuned to a number of resident workgroups per CU (k_column_wg: 5 x 4
+    columns at 56..61 levels, <= 96 VGPRs and <= 25 LDS granules of 1,280 B each; k_column_pk: 2 workgroups
+    of 7 or 8 waves at 128 VGPRs).  One more LDS row or a few more registers silently drops a workgroup per
+    CU (-10 % or worse), so ask the runtime."""
     kernel_env(None)
     kc, k3 = cm.make_hip_case(ncol, nz)
     ctx = mk.MckppHip(kc)
