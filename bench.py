@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
 """bench.py - column-steps/s of the MC-KPP column-physics step on MI355X.
 
-Workload (BASELINE.json configs[2]): 1e5 synthetic columns x 60 levels per GPU
-(spun up for SPINUP model steps, see below), full ocnstep (KPP mixing stack with swfrac + equation of state, tridiagonal
-solves), fp64, state resident in HBM.  A "step" is one mckpp_physics_driver
+Headline workload (BASELINE.json configs[2]): 1e5 synthetic columns x 60 levels per GPU
+(spun up for SPINUP model steps, see below), full ocnstep (KPP mixing stack with swfrac + equation of
+state, tridiagonal solves), fp64, state resident in HBM.  A "step" is one mckpp_physics_driver
 call over the rank's columns.  Columns shard across GPUs with no data-path
 collective (weak scaling: 1e5 columns per GPU); a torch.distributed (RCCL)
 gather of hmix to rank 0 runs after the timed region only, as the diagnostics
 gather the path has.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with the two
-extra objects `roofline` and `cpu_baseline`.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`,
+plus (N=1 only, never part of `value`):
+  diurnal              the same columns through mckpp_hip_run_forced for 48 hourly steps of the
+                       SURVEY 8(d) diurnal short-wave cycle (pass counts vary, kbl moves), GPU and CPU port
+  other_shapes         1e5 x 69 levels on the stretched grid with 35 % land at dto = 1200 s (configs[4] shape)
+                       and 1e5 x 100 levels (configs[3] shape), each with its own roofline fraction
+  strong_scaling_proxy single-GPU rate at 12,500 columns (the per-GPU share of configs[3] on 8 GPUs)
+                       relative to the 1e5-column rate
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -29,6 +36,7 @@ import numpy as np  # noqa: E402
 # baseline) first run SPINUP untimed model steps as part of building the workload, so the warmup and
 # timed steps are ordinary ones whatever --warmup is.
 SPINUP = 3
+DIURNAL_STEPS = 48
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -65,11 +73,29 @@ def host_cores():
     return n
 
 
-def cpu_baseline(ncol_total, nz, warmup, nsteps, stride):
+def diurnal_series(ncol, nt_first, nsteps, dto, index=None):
+    """Eight surface forcing fields per hourly record (layout of mckpp_hip_set_flux_series) for model
+    steps nt_first .. nt_first+nsteps-1: the bench mix with swf = max(0, 800 sin(2 pi t / 86400))."""
+    import common as cm
+
+    series = np.zeros((nsteps, 8, ncol))
+    for r in range(nsteps):
+        sf = cm.synth.forcing(ncol, "bench", t_seconds=(nt_first - 1 + r) * dto, index=index)
+        series[r, 0] = sf[:, 0]       # taux
+        series[r, 1] = sf[:, 1]       # tauy
+        series[r, 2] = sf[:, 2]       # swf
+        series[r, 4] = sf[:, 3]       # lhf (lwf = shf = snow = 0)
+        series[r, 6] = sf[:, 5] - sf[:, 3] / cm.synth.EL   # rain
+    return series
+
+
+def cpu_baseline(ncol_total, nz, warmup, nsteps, stride, diurnal_stride, diurnal_nt0, dto):
     """Oracle (CPU restatement, OpenMP over columns, dynamic schedule like the reference's driver loop)
     on every `stride`-th column of the same workload: the same `warmup` untimed steps, then three
     consecutive blocks of `nsteps` model steps on all host cores (median reported; the first block is
-    the steps the GPU leg times), and one block on a single thread over every 16th of those columns."""
+    the steps the GPU leg times), and one block on a single thread over every 16th of those columns.
+    The oracle runs with the library's portable exp (exp_mode=1, "custom exp"), which is what makes it
+    bit-comparable with the device; its cost is that of libm's exp to within noise (2 calls per pass)."""
     import common as cm
     from oracle import orc
 
@@ -99,8 +125,9 @@ def cpu_baseline(ncol_total, nz, warmup, nsteps, stride):
     for k in range(warmup + 1, warmup + nsteps + 1):
         orc.physics_driver(oc1, ob1, k, nthreads=1)
     dt1 = time.perf_counter() - t0
-    return {
+    out = {
         "value": n * nsteps / dt, "unit": "column-steps/s", "cores": cores, "kind": "port",
+        "exp": "library's portable exp (oracle exp_mode=1), not libm",
         "sample": (f"all {n} columns" if stride == 1 else f"every {stride}th column ({n} of {ncol_total})")
                   + f" of the workload, three blocks of {nsteps} model "
                   f"steps from step {warmup + 1} on (median {dt:.1f} s; all three: "
@@ -109,18 +136,123 @@ def cpu_baseline(ncol_total, nz, warmup, nsteps, stride):
         "sample_1thread": f"{len(idx1)} columns, model steps {warmup + 1}-{warmup + nsteps}, {dt1:.1f} s",
         "mean_passes_per_column_step_last_step": passes,
     }
+    # the diurnal leg on the CPU port: every diurnal_stride-th column, the same model steps as the GPU leg
+    idxd = np.arange(0, ncol_total, diurnal_stride)
+    nd = len(idxd)
+    ocd, obd = cm.make_oracle(nd, nz, mix="bench", exp_mode=1, index=idxd, ntotal=ncol_total, dto=dto)
+    nt0 = diurnal_nt0
+    for k in range(1, nt0 + 1):
+        orc.physics_driver(ocd, obd, k, nthreads=cores)
+    series = diurnal_series(nd, nt0 + 1, DIURNAL_STEPS, dto, index=idxd)
+    names = ("taux", "tauy", "swf", "lwf", "lhf", "shf", "rain", "snow")
+    psum, pmax = 0.0, 0
+    t0 = time.perf_counter()
+    for r in range(DIURNAL_STEPS):
+        orc.fluxes(ocd, obd, nt0 + 1 + r, **dict(zip(names, series[r])))
+        orc.physics_driver(ocd, obd, nt0 + 1 + r, nthreads=cores)
+        psum += float(obd["npasses"].mean())
+        pmax = max(pmax, int(obd["npasses"].max()))
+    dtd = time.perf_counter() - t0
+    out["diurnal"] = {
+        "value": nd * DIURNAL_STEPS / dtd, "unit": "column-steps/s", "cores": cores,
+        "sample": f"every {diurnal_stride}th column ({nd}), model steps {nt0 + 1}-{nt0 + DIURNAL_STEPS}, {dtd:.1f} s",
+        "mean_passes_per_column_step": psum / DIURNAL_STEPS, "max_passes": pmax,
+    }
+    return out
+
+
+def time_steps(ctx, nt_first, nsteps, barrier):
+    barrier()
+    t0 = time.perf_counter()
+    ctx.step(nt_first, nsteps)
+    ctx.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    kms, nlaunch = ctx.last_kernel_ms()
+    return dt, (kms / max(nlaunch, 1)) * 1e-3
+
+
+def side_shape(mk, cm, ncol, nz, grid, dto, land_frac, steps, warmup, diag, dev_index):
+    """One more workload shape on the same GPU: build, init, spin up, time `steps` model steps."""
+    kc, k3 = cm.make_hip_case(ncol, nz, grid=grid, dto=dto)
+    if land_frac > 0:
+        land = (np.arange(ncol) * 7) % 20 < int(round(20 * land_frac))
+        k3.run_physics[land] = 0
+        k3.l_ocean[land] = 0
+    ctx = mk.MckppHip(kc, device=dev_index)
+    ctx.upload(k3)
+    ctx.set_diagnostics(diag)
+    ctx.init_ocean(0)
+    cm.set_forcing_3d(k3, cm.synth.forcing(ncol, "bench"))
+    ctx.set_forcing(k3.sflux)
+    ctx.step(1, SPINUP + warmup)
+    ctx.synchronize()
+    dt, kern_s = time_steps(ctx, 1 + SPINUP + warmup, steps, lambda: None)
+    st, nflag, npass = ctx.status()
+    nocean = int(ctx.ncolumns)
+    balg = alg_bytes_per_column_step(nz, diag)
+    achieved = balg * nocean / kern_s / 1e9
+    out = {
+        "workload": f"{ncol} grid points ({nocean} ocean columns) x {nz} levels, {grid} grid, dto={dto:.0f} s",
+        "value": nocean * steps / dt, "unit": "column-steps/s", "ms_per_step": dt / steps * 1e3,
+        "kernel": ctx.kernel_name, "kernel_avg_ms": kern_s * 1e3,
+        "roofline_frac": achieved / HBM_PEAK_GBS, "achieved_GBps": achieved,
+        "mean_passes_per_column_step_last_step": float(npass[k3.run_physics != 0].mean()),
+        "flagged_columns_last_step": int(nflag),
+    }
+    ctx.close()
+    del ctx, k3, kc
+    gc.collect()
+    return out
+
+
+def committed_counters(ncol, nz, kernel_name, build_id):
+    """PMC-derived figures committed under profiles/ (HBM traffic per launch, VALU instruction counts).
+    They describe one kernel build: returned only when recorded for the loaded library's build id and
+    this workload, otherwise None with the reason."""
+    tf = os.path.join(ROOT, "profiles", "counters.json")
+    if not os.path.exists(tf):
+        return None, None, "profiles/counters.json not present"
+    try:
+        cj = json.load(open(tf))
+    except Exception as e:   # noqa: BLE001
+        return None, None, f"profiles/counters.json unreadable: {e}"
+    if cj.get("build_id") != build_id:
+        return None, None, (f"profiles/counters.json was recorded for build {cj.get('build_id')}, the loaded "
+                            f"library is build {build_id}: not reported")
+    for rec in cj.get("workloads", []):
+        if rec.get("ncol") == ncol and rec.get("nz") == nz and rec.get("kernel") == kernel_name:
+            issue = None
+            if "SQ_INSTS_VALU" in rec:
+                passes = rec.get("passes_per_column", 6.0)
+                issue = {
+                    "source": f"profiles/counters.json ({cj.get('collected', 'rocprofv3 --pmc')}), build {build_id}",
+                    "valu_wave_instructions_per_launch": rec["SQ_INSTS_VALU"],
+                    "valu_instructions_per_column_pass": rec["SQ_INSTS_VALU"] / (ncol * passes),
+                }
+                if "SQ_ACTIVE_INST_VALU" in rec and "SQ_ACTIVE_INST_ANY" in rec:
+                    issue["valu_active_over_wave_busy"] = rec["SQ_ACTIVE_INST_VALU"] / rec["SQ_ACTIVE_INST_ANY"]
+                if "SQ_LDS_BANK_CONFLICT" in rec:
+                    issue["lds_bank_conflict_cycles"] = rec["SQ_LDS_BANK_CONFLICT"]
+            return rec.get("hbm_bytes_per_launch"), issue, None
+    return None, None, "no record for this workload in profiles/counters.json"
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--ncol", type=int, default=100000, help="columns per GPU")
     ap.add_argument("--nz", type=int, default=60)
     ap.add_argument("--diag", type=int, default=1, help="write the per-step diagnostic fields (reference behaviour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: skip diurnal / other_shapes / strong_scaling_proxy")
     ap.add_argument("--cpu-stride", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=10, help="model steps per timed block of the CPU baseline")
+    ap.add_argument("--grid", default="uniform")
+    ap.add_argument("--dto", type=float, default=3600.0)
+    ap.add_argument("--land", type=float, default=0.0, help="fraction of land points (run_physics = .F.)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -154,13 +286,18 @@ def main():
 
     import common as cm
     import mckpp_f90_amd as mk
+    from mckpp_f90_amd import api as mkapi
 
     ncol, nz = a.ncol, a.nz
     ntotal = ncol * world
     from mckpp_f90_amd import sharding
 
     idx = sharding.shard_indices(ntotal, rank, world)   # round-robin shard of one global closed-form set
-    kc, k3 = cm.make_hip_case(ncol, nz, index=idx, ntotal=ntotal)
+    kc, k3 = cm.make_hip_case(ncol, nz, grid=a.grid, dto=a.dto, index=idx, ntotal=ntotal)
+    if a.land > 0:
+        land = (np.arange(ncol) * 7) % 20 < int(round(20 * a.land))
+        k3.run_physics[land] = 0
+        k3.l_ocean[land] = 0
     ctx = mk.MckppHip(kc, device=dev_index)
     ctx.upload(k3)
     ctx.set_diagnostics(a.diag)
@@ -168,6 +305,7 @@ def main():
     cm.set_forcing_3d(k3, cm.synth.forcing(ncol, "bench", index=idx))
     ctx.set_forcing(k3.sflux)
     ctx.synchronize()
+    nocean = int(ctx.ncolumns)
 
     def barrier():
         if dist is not None:
@@ -177,19 +315,18 @@ def main():
     ctx.step(1, SPINUP)
     if a.warmup > 0:
         ctx.step(1 + SPINUP, a.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    ctx.step(1 + SPINUP + a.warmup, a.steps)
-    ctx.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    kms, nlaunch = ctx.last_kernel_ms()
+    dt, kern_s = time_steps(ctx, 1 + SPINUP + a.warmup, a.steps, barrier)
 
     st, nflag, npass = ctx.status()
+    ocean = k3.run_physics != 0
+    ncols_all = nocean
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        c = torch.tensor([float(nocean)], dtype=torch.float64, device=coll_dev if coll_dev is not None else "cpu")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        ncols_all = int(c.item())
         # diagnostics gather (not timed): hmix of every rank's columns to rank 0 over RCCL
         ctx.download(k3, mk.api.F_SCALARS)
         parts = sharding.gather_to_root(k3.hmix, dist, device=coll_dev)
@@ -197,38 +334,15 @@ def main():
             hmix_all = sharding.unshard(parts, ntotal)
             assert np.isfinite(hmix_all).all() and hmix_all.shape == (ntotal,)
 
+    out = None
     if rank == 0:
-        kern_s = (kms / max(nlaunch, 1)) * 1e-3
         balg = alg_bytes_per_column_step(nz, a.diag)
-        achieved = balg * ncol / kern_s / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                tj = json.load(open(tf))
-                if tj.get("ncol") == ncol and tj.get("nz") == nz:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # instruction-issue side of the story (the kernel is not HBM-bound): committed PMC counters of
-        # the same workload, per launch; profiles/r01/README.md says how they were collected
-        issue = None
-        pf = os.path.join(ROOT, "profiles", "r01", "pmc_sq_final.json")
-        if os.path.exists(pf) and ncol == 100000 and nz == 60:
-            try:
-                c = json.load(open(pf))["counters"]
-                issue = {
-                    "source": "profiles/r01/pmc_sq_final.json (rocprofv3 --pmc, same workload, 6 passes per column)",
-                    "valu_wave_instructions_per_launch": c["SQ_INSTS_VALU"],
-                    "valu_instructions_per_column_pass": c["SQ_INSTS_VALU"] / (ncol * 6.0),
-                    "valu_active_over_wave_busy": c["SQ_ACTIVE_INST_VALU"] / c["SQ_ACTIVE_INST_ANY"],
-                    "lds_bank_conflict_cycles": c["SQ_LDS_BANK_CONFLICT"],
-                }
-            except Exception:
-                issue = None
+        achieved = balg * nocean / kern_s / 1e9
+        build = mkapi.build_id()
+        traffic, issue, why_not = committed_counters(ncol, nz, ctx.kernel_name, build)
         out = {
             "metric": "column-steps/s at 1e5 cols x 60 levels, 1/2/4/8 GPU; % HBM roofline",
-            "value": ntotal * a.steps / dt,
+            "value": ncols_all * a.steps / dt,
             "unit": "column-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
@@ -237,25 +351,78 @@ def main():
             "config": {
                 "workload": f"{ncol} columns x {nz} levels per GPU, full ocnstep (kppmix stack + swfrac + "
                             "state equation + tridiagonal solves), bench forcing mix (1/3 stable, 1/3 convective, "
-                            "1/3 windy), dto=3600 s, BASELINE configs[2]",
-                "columns_per_gpu": ncol, "levels": nz, "diagnostics_written": bool(a.diag),
-                "spin_up_steps": SPINUP,
+                            f"1/3 windy), dto={a.dto:.0f} s, BASELINE configs[2]",
+                "columns_per_gpu": ncol, "ocean_columns_per_gpu": nocean, "levels": nz,
+                "diagnostics_written": bool(a.diag), "spin_up_steps": SPINUP,
                 "sharding": f"columns round-robin over {world} GPU(s), no data-path collective",
-                "mean_passes_per_column_step_last_step": float(npass.mean()),
+                "mean_passes_per_column_step_last_step": float(npass[ocean].mean()),
+                "max_passes_last_step": int(npass[ocean].max()),
                 "flagged_columns_last_step": int(nflag),
+                "library_build": build,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": ctx.kernel_name + " (cooperative, persistent)",
-                "kernel_avg_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": balg * ncol,
-                "note": "fp64 instruction-issue bound, not HBM-bound (DESIGN.md section 6)", "issue": issue,
+                "kernel_avg_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": balg * nocean,
+                "note": "fp64 instruction-issue / dependent-chain bound, not HBM-bound (DESIGN.md section 6)",
+                "issue": issue,
             },
         }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ncol, nz, a.warmup, a.steps, a.cpu_stride)
-        print(json.dumps(out), flush=True)
+        if why_not:
+            out["roofline"]["counters_note"] = why_not
+
+    extras = world == 1 and not a.no_extras
+    if extras:
+        # ---- diurnal leg: the reference's forced time loop from resident flux records ----
+        nt0 = SPINUP + a.warmup + a.steps
+        series = diurnal_series(ncol, nt0 + 1, DIURNAL_STEPS, a.dto, index=idx)
+        ctx.set_flux_series(nt0, series)
+        del series
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.run_forced(nt0 + 1, DIURNAL_STEPS, 1)
+        ctx.synchronize()
+        dtd = time.perf_counter() - t0
+        kms, nl = ctx.last_kernel_ms()
+        st, nflag, npass = ctx.status()
+        out["diurnal"] = {
+            "workload": f"same {nocean} columns, model steps {nt0 + 1}-{nt0 + DIURNAL_STEPS} through mckpp_hip_run_forced: "
+                        "hourly flux records resident in HBM, mckpp_fluxes on the stream before every step, bench mix "
+                        "with swf = max(0, 800 sin(2 pi t / 86400))",
+            "value": nocean * DIURNAL_STEPS / dtd, "unit": "column-steps/s", "ms_per_step": dtd / DIURNAL_STEPS * 1e3,
+            "stream_ms_per_step_incl_fluxes": kms / max(nl, 1),
+            "mean_passes_per_column_step_last_step": float(npass[ocean].mean()),
+            "max_passes_last_step": int(npass[ocean].max()), "flagged_columns_last_step": int(nflag),
+        }
     ctx.close()
+    del ctx, k3, kc
+    gc.collect()
+
+    if extras:
+        out["other_shapes"] = [
+            side_shape(mk, cm, 100000, 69, "stretched", 1200.0, 0.35, 10, 2, a.diag, dev_index),
+            side_shape(mk, cm, 100000, 100, "uniform", 3600.0, 0.0, 10, 2, a.diag, dev_index),
+        ]
+        small100 = side_shape(mk, cm, 12500, 100, "uniform", 3600.0, 0.0, 20, 2, a.diag, dev_index)
+        small60 = side_shape(mk, cm, 12500, 60, "uniform", 3600.0, 0.0, 20, 2, a.diag, dev_index)
+        out["strong_scaling_proxy"] = {
+            "what": "one GPU on 12,500 columns = the per-GPU share of configs[3] (1e5 x 100 over 8 GPUs); "
+                    "ratio to the same GPU's rate on 1e5 columns bounds the 8-GPU strong-scaling efficiency",
+            "nz100": {"value": small100["value"], "ms_per_step": small100["ms_per_step"],
+                      "ratio_to_1e5": small100["value"] / out["other_shapes"][1]["value"]},
+            "nz60": {"value": small60["value"], "ms_per_step": small60["ms_per_step"],
+                     "ratio_to_1e5": small60["value"] / out["value"]},
+        }
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            cb = cpu_baseline(ncol, nz, a.warmup, a.cpu_steps, a.cpu_stride, 4, SPINUP + a.warmup + a.steps, a.dto)
+            if extras:
+                out["diurnal"]["cpu_port"] = cb.pop("diurnal")
+            else:
+                cb.pop("diurnal", None)
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

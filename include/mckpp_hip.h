@@ -123,6 +123,10 @@ typedef struct mckpp_hip_ctx *mckpp_hip_handle;
 
 const char *mckpp_hip_last_error(void);
 
+/* Twelve hex digits identifying the kernel sources this library was built from
+ * (measurement bookkeeping: profiles/ records it next to counter values). */
+const char *mckpp_hip_build_id(void);
+
 /* Number of visible gfx950 devices (<0 on error). */
 int mckpp_hip_device_count(void);
 

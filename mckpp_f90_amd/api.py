@@ -82,6 +82,7 @@ def _bind(lib):
         return lib
     lib.mckpp_hip_last_error.restype = C.c_char_p
     lib.mckpp_hip_device_count.restype = C.c_int
+    lib.mckpp_hip_build_id.restype = C.c_char_p
     lib.mckpp_hip_init.argtypes = [C.POINTER(_ConstC), C.c_int, C.POINTER(C.c_void_p)]
     lib.mckpp_hip_finalize.argtypes = [C.c_void_p]
     lib.mckpp_host_lookup.argtypes = [C.c_double, _dp, _dp]
@@ -124,6 +125,11 @@ def _lib():
     from . import load_library
 
     return _bind(load_library())
+
+
+def build_id():
+    """Identifier of the kernel sources the loaded library was built from."""
+    return _lib().mckpp_hip_build_id().decode()
 
 
 def _chk(rc):

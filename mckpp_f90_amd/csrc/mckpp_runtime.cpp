@@ -102,6 +102,11 @@ extern "C" {
 
 const char *mckpp_hip_last_error(void) { return g_err.c_str(); }
 
+#ifndef MCKPP_BUILD_ID
+#define MCKPP_BUILD_ID "unknown"
+#endif
+const char *mckpp_hip_build_id(void) { return MCKPP_BUILD_ID; }
+
 int mckpp_hip_device_count(void)
 {
   int n = 0;
