@@ -137,7 +137,8 @@ void mckpp_host_lookup(double vonk, double *wmt, double *wst)
       } else {
         wm = (zeta > zetam) ? vonk * usta * std::pow(1. - c2 * zeta, 1. / 4.)
                             : vonk * std::pow(am * u3 - cm * zehat, 1. / 3.);
-        ws = (zeta > zetas) ? vonk * usta * std::pow(1. - c3 * zeta, 1. / 2.)
+        // **(1./2.) is a square root in the reference's build (oracle/conv_probe.F90), not libm's pow
+        ws = (zeta > zetas) ? vonk * usta * std::sqrt(1. - c3 * zeta)
                             : vonk * std::pow(as * u3 - cs * zehat, 1. / 3.);
       }
       wmt[(size_t)j * n1 + i] = wm;

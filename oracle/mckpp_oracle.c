@@ -284,6 +284,26 @@ void orc_z121(int kmp1, double vlo, double vhi, double *V, double *w)
  * x**3 = (x*x)*x, x**4 = ((x*x)*x)*x.
  * ---------------------------------------------------------------------- */
 #define TBL(i, j) ((j) * (ORC_NI + 2) + (i))
+/* The C lowering this file uses for the Fortran power operators and literals on the path
+ * (checked against amdflang's by tests/test_oracle_cpu.py::test_compiler_conventions, oracle/conv_probe.F90):
+ *   x**3 -> (x*x)*x, x**4 -> ((x*x)*x)*x, x**(1./2.) -> sqrt(x), x**(1./3.) -> pow(x, 1./3.), x**(1./4.) -> pow(x, 1./4.) */
+void orc_conv_probe(int n, const double *x, double *p3, double *p4, double *ph, double *pt, double *pq)
+{
+  for (int i = 0; i < n; ++i) {
+    const double y = x[i];
+    p3[i] = (y * y) * y;
+    p4[i] = ((y * y) * y) * y;
+    ph[i] = sqrt(y);
+    pt[i] = pow(y, 1. / 3.);
+    pq[i] = pow(y, 1. / 4.);
+  }
+}
+void orc_conv_literals(double *out)
+{
+  out[0] = 1.257; out[1] = 8.380; out[2] = 98.96; out[3] = -28.86; out[4] = 4.e-7; out[5] = 0.033;
+  out[6] = 1. / 3.; out[7] = 0.04 / 49.; out[8] = 1.E-12; out[9] = 6.536332E-9; out[10] = 0.1;
+}
+
 void orc_lookup(double vonk, double *wmt, double *wst)
 {
   const int ni = ORC_NI, nj = ORC_NJ;
@@ -307,7 +327,7 @@ void orc_lookup(double vonk, double *wmt, double *wst)
         else
           wmt[TBL(i, j)] = vonk * pow(am * u3 - cm * zehat, 1. / 3.);
         if (zeta > zetas)                                 /* :60-64 */
-          wst[TBL(i, j)] = vonk * usta * pow(1. - c3 * zeta, 1. / 2.);
+          wst[TBL(i, j)] = vonk * usta * sqrt(1. - c3 * zeta);   /* **(1./2.): a square root under amdflang, conv_probe.F90 */
         else
           wst[TBL(i, j)] = vonk * pow(as * u3 - cs * zehat, 1. / 3.);
       }

@@ -112,6 +112,8 @@ void orc_abk80_batch(int n, const double *s, const double *t, const double *p,
                      double *alpha, double *beta, double *sig0, double *sig);
 void orc_cpsw_batch(int n, const double *s, const double *t, const double *p, double *cp);
 void orc_z121(int kmp1, double vlo, double vhi, double *V, double *w);
+void orc_conv_probe(int n, const double *x, double *p3, double *p4, double *ph, double *pt, double *pq);
+void orc_conv_literals(double *out);
 void orc_lookup(double vonk, double *wmt, double *wst);
 void orc_wscale(const orc_const *c, double sigma, double hbl, double ustar,
                 double bfsfc, double *wm, double *ws);

@@ -69,6 +69,8 @@ def lib():
         L.orc_cpsw_batch.argtypes = [C.c_int] + [C.POINTER(C.c_double)] * 4
         L.orc_z121.argtypes = [C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_lookup.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_conv_probe.argtypes = [C.c_int] + [C.POINTER(C.c_double)] * 6
+        L.orc_conv_literals.argtypes = [C.POINTER(C.c_double)]
         L.orc_wscale.argtypes = [C.POINTER(OrcConst)] + [C.c_double] * 4 + [C.POINTER(C.c_double)] * 2
         L.orc_swfrac.restype = C.c_double
         L.orc_swfrac.argtypes = [C.POINTER(OrcConst), C.c_double, C.c_double, C.c_int]
@@ -92,6 +94,25 @@ def lib():
         L.orc_fluxes.argtypes = [C.POINTER(OrcConst), C.c_void_p, C.c_int] + [C.POINTER(C.c_double)] * 8 + [C.c_int, C.c_double, C.c_double]
         _lib = L
     return _lib
+
+
+PROBELIB = os.path.join(HERE, "_ref", "libconv_probe.so")
+_probe = None
+
+
+def conv_probe():
+    """amdflang build of oracle/conv_probe.F90 (own source; needs the compiler only), or None."""
+    global _probe
+    if _probe is None:
+        if not os.path.exists(PROBELIB) and os.path.exists("/opt/rocm/bin/amdflang"):
+            subprocess.check_call(["make", "-C", HERE, "probe"], stdout=subprocess.DEVNULL)
+        if not os.path.exists(PROBELIB):
+            return None
+        P = C.CDLL(PROBELIB)
+        P.conv_probe_powers.argtypes = [C.c_int] + [C.POINTER(C.c_double)] * 6
+        P.conv_probe_literals.argtypes = [C.POINTER(C.c_double)]
+        _probe = P
+    return _probe
 
 
 def have_ref():

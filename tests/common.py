@@ -144,9 +144,11 @@ def compare(k3, ob, nz, fields, active=None):
             o = ob.a[name][:, lo:lo + n]
         h = np.asarray(h)[sel]
         o = np.asarray(o)[sel]
-        d = np.abs(h - o)
+        with np.errstate(invalid="ignore"):
+            d = np.abs(h - o)
         den = np.maximum(np.abs(o), 1e-300)
-        bits = int((np.ascontiguousarray(h).view(np.int64) != np.ascontiguousarray(o).view(np.int64)).sum()
-                   - ((h == 0) & (o == 0) & (np.signbit(h) != np.signbit(o))).sum())
+        # bit mismatches; +0/-0 and NaN/NaN (sign and payload of a NaN are the platform's choice) count as equal
+        differ = np.ascontiguousarray(h).view(np.int64) != np.ascontiguousarray(o).view(np.int64)
+        bits = int((differ & ~((h == 0) & (o == 0)) & ~(np.isnan(h) & np.isnan(o))).sum())
         out[name] = (float(d.max()) if d.size else 0.0, float((d / den).max()) if d.size else 0.0, bits)
     return out

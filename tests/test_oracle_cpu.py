@@ -238,3 +238,44 @@ def test_bottomtemp_override():
     assert np.array_equal(ob["tinc_fcorr"][:, nz + 1], bt - t_old)
     assert np.array_equal(ob["ocnTcorr"][:, nz + 1], (bt - t_old) * rho * cp / 3600.0)
     assert np.all(ob["tinc_fcorr"][:, 1:nz + 1] == 0)
+
+
+def _conv_check(x, p3, p4, ph, pt, pq, lit):
+    L = orc.lib()
+    n = len(x)
+    o = [np.zeros(n) for _ in range(5)]
+    L.orc_conv_probe(n, dp(x), *[dp(a) for a in o])
+    for name, mine, want in zip(("x**3", "x**4", "x**(1./2.)", "x**(1./3.)", "x**(1./4.)"), o, (p3, p4, ph, pt, pq)):
+        bad = mine.view(np.int64) != want.view(np.int64)
+        assert not bad.any(), f"{name}: the oracle's C lowering differs from amdflang's on {int(bad.sum())} of {n} values"
+    ol = np.zeros(11)
+    L.orc_conv_literals(dp(ol))
+    assert np.array_equal(ol.view(np.int64), lit[:11].view(np.int64)), "unkinded literals are not full doubles"
+    assert lit[11] == 8.0     # KIND of default REAL under -fdefault-real-8
+
+
+def test_compiler_conventions_golden():
+    """The Fortran constructs the oracle lowers by hand - integer powers, **(1./2.), **(1./3.), **(1./4.),
+    unkinded literals - against what amdflang produced for them (tests/golden/conv_probe.npz, made by
+    tests/golden/make_conv_golden.py from oracle/conv_probe.F90).  Found with this probe: **(1./2.) is a
+    square root, which differs from libm's pow(x, .5) in 28 entries of the wst table."""
+    g = np.load(os.path.join(GOLD, "conv_probe.npz"))
+    _conv_check(np.ascontiguousarray(g["x"]), g["p3"], g["p4"], g["ph"], g["pt"], g["pq"], g["literals"])
+    x = g["x"]
+    assert np.array_equal(g["ph"], np.sqrt(x)) and np.array_equal(g["p4"], ((x * x) * x) * x)
+    assert not np.array_equal(g["p4"], (x * x) * (x * x))      # the association matters
+
+
+def test_compiler_conventions_live():
+    """Same check against a fresh amdflang build of the probe, where the compiler is installed."""
+    P = orc.conv_probe()
+    if P is None:
+        pytest.skip("amdflang not installed here")
+    rng = np.random.default_rng(5)
+    x = np.ascontiguousarray(np.concatenate([rng.uniform(0, 20, 50000), 10 ** rng.uniform(-15, 5, 50000)]))
+    n = len(x)
+    o = [np.zeros(n) for _ in range(5)]
+    P.conv_probe_powers(n, dp(x), *[dp(a) for a in o])
+    lit = np.zeros(12)
+    P.conv_probe_literals(dp(lit))
+    _conv_check(x, *o, lit)
