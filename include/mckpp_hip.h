@@ -208,6 +208,13 @@ int mckpp_hip_step(mckpp_hip_handle h, int ntime, int nsteps);
  * followed by mckpp_physics_ocnint (src/mckpp_physics_ocnint_mod.F90:19). */
 int mckpp_hip_vmix_pass(mckpp_hip_handle h, int ntime);
 
+/* mckpp_physics_verticalmixing alone (src/mckpp_physics_verticalmixing_mod.F90:14-161; the reference
+ * also calls it from src/mckpp_initialize_ocean.F90:60) on every resident column with the column's own
+ * l_initflag: hmix / kmix receive its hmixn / kmixn, uref / vref its scratch values (:115-125), and the
+ * MCKPP_F_DIAG fields of a vmix (rho, cp, buoy, Rig, dbloc, Shsq, difm, difs, dift, ghat, wU(0), wX(0),
+ * wXNT) are rewritten; profiles, saved time levels and hmixd stay as they are. */
+int mckpp_hip_vmix_only(mckpp_hip_handle h, int ntime);
+
 int mckpp_hip_synchronize(mckpp_hip_handle h);
 
 /* device -> 3D: scatter half of mckpp_fields_1dto3d

@@ -105,6 +105,7 @@ def _bind(lib):
     lib.mckpp_hip_init_ocean.argtypes = [C.c_void_p, C.c_int]
     lib.mckpp_hip_step.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.mckpp_hip_vmix_pass.argtypes = [C.c_void_p, C.c_int]
+    lib.mckpp_hip_vmix_only.argtypes = [C.c_void_p, C.c_int]
     lib.mckpp_hip_synchronize.argtypes = [C.c_void_p]
     lib.mckpp_hip_download.argtypes = [C.c_void_p, C.POINTER(_StateC), C.c_uint32]
     lib.mckpp_hip_status.argtypes = [C.c_void_p, _ip, C.POINTER(C.c_int64), _ip]
@@ -340,6 +341,9 @@ class MckppHip:
 
     def vmix_pass(self, ntime):
         _chk(_lib().mckpp_hip_vmix_pass(self._h, int(ntime)))
+
+    def vmix_only(self, ntime):
+        _chk(_lib().mckpp_hip_vmix_only(self._h, int(ntime)))
 
     def synchronize(self):
         _chk(_lib().mckpp_hip_synchronize(self._h))

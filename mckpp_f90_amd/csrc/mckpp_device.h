@@ -26,7 +26,9 @@ enum {
 // ci[] slots
 enum { CI_OLD = 0, CI_NEW, CI_JERLOV, CI_INITFLAG, CI_STATUS, CI_NPASS, CI_LOCEAN, CI_IPT };
 
-enum { MCKPP_MODE_STEP = 0, MCKPP_MODE_INIT = 1, MCKPP_MODE_PASS = 2 };
+// STEP: ocnstep + check_profile; INIT: initial vmix + seeds (initialize_ocean.F90); PASS: one vmix + ocnint
+// (configs[1]); VMIX: mckpp_physics_verticalmixing alone - diagnostics and hmix/kmix only, state untouched
+enum { MCKPP_MODE_STEP = 0, MCKPP_MODE_INIT = 1, MCKPP_MODE_PASS = 2, MCKPP_MODE_VMIX = 3 };
 
 struct mckpp_kparams {
   int nz, nzp1, ncol, ld;

@@ -171,7 +171,8 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
   int col = 0;
   const double lambda = 0.5;
   const double epsln16 = 1.e-16, Ricr = 0.30, eps01 = 0.1, cekman = 0.7, cmonob = 1.0, epsln20 = 1.e-20;
-  const bool do_ocnint = p.mode != MCKPP_MODE_INIT;
+  const bool do_ocnint = p.mode == MCKPP_MODE_STEP || p.mode == MCKPP_MODE_PASS;
+  const bool flux_diag = p.mode == MCKPP_MODE_STEP || p.mode == MCKPP_MODE_INIT;   // wU, wX(1:nz) of ocnstep / initialize_ocean
 
   auto rowoff = [&]() -> size_t { return (size_t)col * p.ld; };
   auto ld_old = [&](const double *src) -> double { return act ? src[(size_t)col * p.ld + (k - 1)] : 0.0; };
@@ -924,7 +925,7 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
     __syncthreads();
     fin = active ? si[I_FIN] : F_NONE;
     // the diagnostic fluxes need the k+1 neighbours of the final profiles
-    if (fin == F_FINAL && p.diag && p.mode != MCKPP_MODE_PASS && act) {
+    if (fin == F_FINAL && p.diag && flux_diag && act) {
       row(R_YU)[k] = U; row(R_YT)[k] = V; row(R_YS)[k] = T; row(R_GM)[k] = S;
     }
     __syncthreads();
@@ -940,7 +941,7 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
       if (actz) {
         p.ghat[o] = gh;
         p.wXNT1[o] = (ntime >= 1) ? -sflux3 * p.swdk_tab[si[I_JER] * p.ldc + k] / rho0cp0 : 0.0;
-        if (p.mode != MCKPP_MODE_PASS) {
+        if (flux_diag) {
           double deltaz = 0.5 * (c_hm[k] + c_hm[k + 1]);
           double uk1 = tU[k + 1], vk1 = tV[k + 1], tk1 = tT[k + 1], sk1 = tS[k + 1];
           double wX1 = -dfs * ((T - tk1) / deltaz - gh * wX0_1);
@@ -1077,7 +1078,7 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
           ci[CI_STATUS] = si[I_STATUS]; ci[CI_NPASS] = si[I_NPASS];
         }
       } else {
-        if (act) { p.U[o] = U; p.V[o] = V; p.T[o] = T; p.S[o] = S; }
+        if (p.mode == MCKPP_MODE_PASS && act) { p.U[o] = U; p.V[o] = V; p.T[o] = T; p.S[o] = S; }
         if (is1) {
           cs[CS_HMIX] = sc[C_HBL];
           cs[CS_KMIX] = (double)si[I_KBL];

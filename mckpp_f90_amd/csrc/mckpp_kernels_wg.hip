@@ -721,7 +721,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     if (p.diag) {
       const double wX0_1 = sc[C_WX01], wX0_2 = sc[C_WX02];
       double *tU = row(R_YU), *tV = row(R_YT), *tT = row(R_YS), *tS = row(R_GM);
-      if (p.mode != MCKPP_MODE_PASS) {
+      if (p.mode == MCKPP_MODE_STEP || p.mode == MCKPP_MODE_INIT) {
         WAVE_LDS_SYNC();
         FORJ if (act[j]) { int k = kk[j]; tU[k] = U[j]; tV[k] = V[j]; tT[k] = T[j]; tS[k] = S[j]; }
         WAVE_LDS_SYNC();
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
         if (actz[j]) {
           p.ghat[o] = gh;
           p.wXNT1[o] = (ntime >= 1) ? -sflux3 * p.swdk_tab[jer * p.ldc + k] / rho0cp0 : 0.0;
-          if (p.mode != MCKPP_MODE_PASS) {
+          if (p.mode == MCKPP_MODE_STEP || p.mode == MCKPP_MODE_INIT) {
             double deltaz = 0.5 * (c_hm[k] + c_hm[k + 1]);
             double uk1 = tU[k + 1], vk1 = tV[k + 1], tk1 = tT[k + 1], sk1 = tS[k + 1];
             double wX1 = -dfs * ((T[j] - tk1) / deltaz - gh * wX0_1);
@@ -881,9 +881,11 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
         ci[CI_STATUS] = status; ci[CI_NPASS] = npass;
       }
     } else {
-      FORJ if (act[j]) {
-        size_t o = ro + lane + 64 * j;
-        p.U[o] = U[j]; p.V[o] = V[j]; p.T[o] = T[j]; p.S[o] = S[j];
+      if (p.mode == MCKPP_MODE_PASS) {
+        FORJ if (act[j]) {
+          size_t o = ro + lane + 64 * j;
+          p.U[o] = U[j]; p.V[o] = V[j]; p.T[o] = T[j]; p.S[o] = S[j];
+        }
       }
       if (lane == 0) {
         cs[CS_HMIX] = sc[C_HBL];
@@ -905,7 +907,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
     if (p.mode != MCKPP_MODE_INIT && sbad[wave]) status |= 1;
     ++npass;
     if (p.mode != MCKPP_MODE_STEP) {
-      if (p.mode != MCKPP_MODE_INIT) load_solution();
+      if (p.mode == MCKPP_MODE_PASS) load_solution();
       finalize();
       return;
     }
@@ -1003,7 +1005,7 @@ __global__ __launch_bounds__(64 * W, MINW) void k_column_wg(const mckpp_kparams 
       tlast = t_;                                             \
     }                                                         \
   } while (0)
-  const bool do_ocnint = p.mode != MCKPP_MODE_INIT;
+  const bool do_ocnint = p.mode == MCKPP_MODE_STEP || p.mode == MCKPP_MODE_PASS;
   for (;;) {
     if (state == S_EMPTY) refill();
     const bool active = state == S_ACTIVE;

@@ -672,6 +672,7 @@ int mckpp_hip_step(mckpp_hip_handle h, int ntime, int nsteps)
   return run(h, ntime, nsteps, MCKPP_MODE_STEP);
 }
 int mckpp_hip_vmix_pass(mckpp_hip_handle h, int ntime) { return run(h, ntime, 1, MCKPP_MODE_PASS); }
+int mckpp_hip_vmix_only(mckpp_hip_handle h, int ntime) { return run(h, ntime, 1, MCKPP_MODE_VMIX); }
 
 int mckpp_hip_set_flux_series(mckpp_hip_handle h, int rec0, int nrec, const double *fields)
 {

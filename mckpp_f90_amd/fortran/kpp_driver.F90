@@ -14,6 +14,7 @@ program kpp_driver
   use mckpp_initialize_ocean, only: mckpp_initialize_ocean_model
   use mckpp_physics_driver_mod, only: mckpp_physics_driver, mckpp_physics_finalize
   use mckpp_physics_ocnstep_mod, only: mckpp_physics_ocnstep
+  use mckpp_physics_verticalmixing_mod, only: mckpp_physics_verticalmixing
   use mckpp_fluxes_mod, only: mckpp_fluxes
   implicit none
   character(len=512) :: fin, fout
@@ -22,13 +23,18 @@ program kpp_driver
   real(c_double), allocatable :: sf6(:,:), mask(:)
   type(kpp_1d_type) :: q
   real(c_double) :: t0, t1
+  real(c_double), allocatable :: vm_h(:), vm_k(:), vm_difm(:,:), vm_difs(:,:), vm_dift(:,:), vm_ghat(:,:)
+  real(c_double) :: hmixn
+  integer :: kmixn
 
   call get_command_argument(1, fin)
   call get_command_argument(2, fout)
   open (newunit=u, file=trim(fin), access='stream', form='unformatted', status='old')
   read (u) hdr
   ncol = hdr(1); nlev = hdr(2); nsteps = hdr(3); use_1d = hdr(4)
-  flags = hdr(6)   ! 1: forcing through mckpp_fluxes (constant forcing, L_FLUXDATA=.F.) every step; 2: L_VARY_BOTTOM_TEMP
+  ! flags: 1 forcing through mckpp_fluxes (constant forcing, L_FLUXDATA=.F.) every step; 2 L_VARY_BOTTOM_TEMP;
+  !        4 after the run, mckpp_physics_verticalmixing on every column of the final state (appended to the output)
+  flags = hdr(6)
   call mckpp_set_dimensions(ncol, 1, nlev, hdr(5))
   call mckpp_allocate_const_fields()
   call mckpp_allocate_3d_fields()
@@ -84,6 +90,18 @@ program kpp_driver
   write (u) kpp_3d_fields%hmix, kpp_3d_fields%kmix, kpp_3d_fields%hmixd, kpp_3d_fields%Tref, kpp_3d_fields%Ssurf
   write (u) kpp_3d_fields%old, kpp_3d_fields%new
   write (u) kpp_3d_fields%difm, kpp_3d_fields%ghat, kpp_3d_fields%rho
+  if (iand(flags, 4) /= 0) then
+    allocate (vm_h(ncol), vm_k(ncol), vm_difm(ncol,0:nztmax), vm_difs(ncol,0:nztmax), vm_dift(ncol,0:nztmax), vm_ghat(ncol,nztmax))
+    vm_h = 0; vm_k = 0; vm_difm = 0; vm_difs = 0; vm_dift = 0; vm_ghat = 0
+    do ipt = 1, npts
+      if (.not. kpp_3d_fields%run_physics(ipt)) cycle
+      call gather_1d(ipt, q)
+      call mckpp_physics_verticalmixing(q, kpp_const_fields, hmixn, kmixn)
+      vm_h(ipt) = hmixn; vm_k(ipt) = kmixn
+      vm_difm(ipt,:) = q%difm; vm_difs(ipt,:) = q%difs; vm_dift(ipt,:) = q%dift; vm_ghat(ipt,:) = q%ghat
+    end do
+    write (u) vm_h, vm_k, vm_difm, vm_difs, vm_dift, vm_ghat
+  end if
   close (u)
   call mckpp_physics_finalize()
 

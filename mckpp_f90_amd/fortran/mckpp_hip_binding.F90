@@ -148,6 +148,12 @@ module mckpp_hip_binding
       integer(c_int), value :: ntime, nsteps
       integer(c_int) :: rc
     end function
+    function mckpp_hip_vmix_only(handle, ntime) bind(C, name="mckpp_hip_vmix_only") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int), value :: ntime
+      integer(c_int) :: rc
+    end function
     function mckpp_hip_synchronize(handle) bind(C, name="mckpp_hip_synchronize") result(rc)
       import :: c_int, c_ptr
       type(c_ptr), value :: handle

@@ -1515,6 +1515,28 @@ void orc_vmix_batch(const orc_const *c, orc_batch *b, int ntime, int nthreads)
   }
 }
 
+/* mckpp_physics_verticalmixing alone (verticalmixing_mod.F90:14-161) on every column: hmix/kmix <- hmixn/kmixn */
+void orc_vmix_only_batch(const orc_const *c, orc_batch *b, int ntime, int nthreads)
+{
+  int nt = pick_threads(nthreads);
+  (void)nt;
+#pragma omp parallel num_threads(nt)
+  {
+    orc_col *q = col_new(c->nz);
+#pragma omp for schedule(dynamic, 8)
+    for (long col = 0; col < b->ncol; col++) {
+      double h;
+      int km;
+      gather(c, b, col, q);
+      vmix(c, q, ntime, &h, &km);
+      q->hmix = h;
+      q->kmix = (double)km;
+      scatter(c, b, col, q);
+    }
+    col_free(q);
+  }
+}
+
 /* mckpp_fluxes.  mckpp_fluxes_mod.F90:35-89 (forcing arrays given, l_fluxdata semantics left to the caller) */
 /* mckpp_physics_overrides_bottomtemp, overrides.F90:12-24 (called by the driver after the column
  * loop when L_VARY_BOTTOM_TEMP, physics_driver_mod.F90:67-71) */

@@ -145,6 +145,7 @@ void orc_fluxes(const orc_const *c, orc_batch *b, int ntime, const double *taux,
 /* mckpp_physics_overrides_bottomtemp (overrides.F90:12-24) */
 void orc_bottomtemp(const orc_const *c, orc_batch *b, const double *bottom_temp);
 /* one vmix + ocnint pass on every column (config-2 style kernel-level check) */
+void orc_vmix_only_batch(const orc_const *c, orc_batch *b, int ntime, int nthreads);
 void orc_vmix_batch(const orc_const *c, orc_batch *b, int ntime, int nthreads);
 
 #ifdef __cplusplus

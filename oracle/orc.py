@@ -88,7 +88,7 @@ def lib():
         L.orc_batch_free.argtypes = [C.c_void_p]
         L.orc_batch_set.restype = C.c_int
         L.orc_batch_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
-        for fn in ("orc_init_ocean", "orc_physics_driver", "orc_vmix_batch"):
+        for fn in ("orc_init_ocean", "orc_physics_driver", "orc_vmix_batch", "orc_vmix_only_batch"):
             getattr(L, fn).argtypes = [C.POINTER(OrcConst), C.c_void_p, C.c_int, C.c_int]
         L.orc_bottomtemp.argtypes = [C.POINTER(OrcConst), C.c_void_p, C.POINTER(C.c_double)]
         L.orc_fluxes.argtypes = [C.POINTER(OrcConst), C.c_void_p, C.c_int] + [C.POINTER(C.c_double)] * 8 + [C.c_int, C.c_double, C.c_double]
@@ -270,6 +270,10 @@ def physics_driver(const, batch, ntime, nthreads=0):
 
 def vmix_batch(const, batch, ntime, nthreads=0):
     _run("orc_vmix_batch", const, batch, ntime, nthreads)
+
+
+def vmix_only(const, batch, ntime, nthreads=0):
+    _run("orc_vmix_only_batch", const, batch, ntime, nthreads)
 
 
 def bottomtemp(const, batch, bottom_temp):

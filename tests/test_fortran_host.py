@@ -30,7 +30,7 @@ def _write_case(path, kc, k3, sf6, nsteps, use_1d, flags=0):
         np.asarray(sf6).ravel(order="F").tofile(f)
 
 
-def _read_out(path, kc, npts):
+def _read_out(path, kc, npts, vmix=False):
     nz, nzp1, nzt = kc.nz, kc.nzp1, kc.nztmax
     out = {}
     with open(path, "rb") as f:
@@ -43,6 +43,10 @@ def _read_out(path, kc, npts):
         out["Tref"] = rd((npts,)); out["Ssurf"] = rd((npts,))
         out["old"] = rd((npts,), np.int32); out["new_"] = rd((npts,), np.int32)
         out["difm"] = rd((npts, nzt + 1)); out["ghat"] = rd((npts, nzt)); out["rho"] = rd((npts, nzt + 2))
+        if vmix:
+            out["vm_h"] = rd((npts,)); out["vm_k"] = rd((npts,))
+            out["vm_difm"] = rd((npts, nzt + 1)); out["vm_difs"] = rd((npts, nzt + 1)); out["vm_dift"] = rd((npts, nzt + 1))
+            out["vm_ghat"] = rd((npts, nzt))
     return out
 
 
@@ -107,3 +111,32 @@ def test_fortran_fluxes_and_bottomtemp_wrappers(built, tmp_path, flags):
     if flags & 2:
         act = np.nonzero(k3.run_physics)[0]
         assert np.array_equal(got["X"][act, nz, 0], k3.bottom_temp[act])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ncol,nz,land", [(40, 40, 0), (30, 69, 4)])
+def test_fortran_verticalmixing_wrapper(built, tmp_path, ncol, nz, land):
+    """mckpp_physics_verticalmixing(kpp_1d_fields, kpp_const_fields, hmixn, kmixn) - the third signature
+    of the reference's call surface (src/mckpp_physics_verticalmixing_mod.F90:14) - called by kpp_driver
+    for every column of its final state: hmixn, kmixn and the mixing coefficients equal the oracle's vmix
+    on the same state."""
+    from oracle import orc
+
+    nsteps = 2
+    kc, k3 = cm.make_hip_case(ncol, nz, land_every=land)
+    sf = cm.synth.forcing(ncol, "bench")
+    _write_case(tmp_path / "case.bin", kc, k3, sf, nsteps, 0, flags=4)
+    r = subprocess.run([DRIVER, str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = _read_out(tmp_path / "out.bin", kc, ncol, vmix=True)
+    oc, ob = cm.make_oracle(ncol, nz, init=True, exp_mode=1)
+    for nt in range(1, nsteps + 1):
+        orc.physics_driver(oc, ob, nt)
+    act = np.nonzero(k3.run_physics)[0]
+    assert np.array_equal(got["hmix"][act], ob["hmix"][act])
+    orc.vmix_only(oc, ob, nsteps)
+    assert np.array_equal(got["vm_h"][act], ob["hmix"][act])
+    assert np.array_equal(got["vm_k"][act], ob["kmix"][act])
+    for n, o in (("vm_difm", "difm"), ("vm_difs", "difs"), ("vm_dift", "dift")):
+        assert np.array_equal(got[n][act][:, :nz + 2], ob[o][act][:, :nz + 2]), n
+    assert np.array_equal(got["vm_ghat"][act][:, :nz], ob["ghat"][act][:, 1:nz + 1])

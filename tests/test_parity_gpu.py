@@ -947,3 +947,35 @@ def test_long_iteration_status_on_device(mk, kernel_env, variant, nz):
         assert np.all(npass[long_it] > 5)
         seen += int(long_it.sum())
     assert seen > 0, "no column exceeded itermax+1 passes"
+
+
+@pytest.mark.parametrize("variant,nz", [("wg", 60), ("pk", 40), ("pk", 60), ("pk", 69), ("pk", 100)])
+def test_verticalmixing_alone(mk, kernel_env, variant, nz):
+    """mckpp_hip_vmix_only = mckpp_physics_verticalmixing (src/mckpp_physics_verticalmixing_mod.F90:14) by
+    itself, the third routine of the reference's call surface: after two model steps, one more vmix on the
+    resident state must give the oracle's hmixn / kmixn and vmix diagnostics and leave the state alone."""
+    from oracle import orc
+
+    kernel_env(variant)
+    ncol = 150
+    oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1)
+    kc, k3 = cm.make_hip_case(ncol, nz, land_every=7)
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    orc.init_ocean(oc, ob, 0)
+    sf = cm.synth.forcing(ncol, "bench")
+    ob["sflux"] = sf
+    cm.set_forcing_3d(k3, sf)
+    for nt in (1, 2):
+        mk.mckpp_physics_driver(k3, kc, nt)
+        orc.physics_driver(oc, ob, nt)
+    active = np.nonzero(k3.run_physics)[0]
+    before = {n: np.array(getattr(k3, n), copy=True) for n in ("U", "X", "Us", "Xs", "hmixd", "Tref", "Ssurf", "old", "new_")}
+    ctx.vmix_only(3)
+    orc.vmix_only(oc, ob, 3)
+    ctx.download(k3)
+    fields = ["hmix", "kmix", "uref", "vref", "rho", "cp", "buoy", "difm", "difs", "dift", "ghat", "Rig", "dbloc",
+              "Shsq", "wXNT1"]
+    _assert_bitexact(cm.compare(k3, ob, nz, fields, active), f"vmix only {variant} nz={nz}")
+    assert np.array_equal(k3.wU[active, 0, :2], np.stack([ob["wU1"][active, 0], ob["wU2"][active, 0]], axis=1))
+    for n, v in before.items():
+        assert np.array_equal(getattr(k3, n), v), n
