@@ -74,19 +74,10 @@ def host_cores():
 
 
 def diurnal_series(ncol, nt_first, nsteps, dto, index=None):
-    """Eight surface forcing fields per hourly record (layout of mckpp_hip_set_flux_series) for model
-    steps nt_first .. nt_first+nsteps-1: the bench mix with swf = max(0, 800 sin(2 pi t / 86400))."""
+    """Hourly flux records of the SURVEY 8(d) diurnal cycle (mckpp_f90_amd/synth.py: flux_series)."""
     import common as cm
 
-    series = np.zeros((nsteps, 8, ncol))
-    for r in range(nsteps):
-        sf = cm.synth.forcing(ncol, "bench", t_seconds=(nt_first - 1 + r) * dto, index=index)
-        series[r, 0] = sf[:, 0]       # taux
-        series[r, 1] = sf[:, 1]       # tauy
-        series[r, 2] = sf[:, 2]       # swf
-        series[r, 4] = sf[:, 3]       # lhf (lwf = shf = snow = 0)
-        series[r, 6] = sf[:, 5] - sf[:, 3] / cm.synth.EL   # rain
-    return series
+    return cm.synth.flux_series(ncol, nt_first, nsteps, dto, "bench", index)
 
 
 def cpu_baseline(ncol_total, nz, warmup, nsteps, stride, diurnal_stride, diurnal_nt0, dto):

@@ -95,6 +95,28 @@ def forcing(ncol, mix="bench", t_seconds=None, index=None):
     return sflux
 
 
+def flux_series(ncol, nt_first, nsteps, dto, mix="bench", index=None):
+    """Surface forcing records for model steps nt_first .. nt_first+nsteps-1 in the layout of
+    mckpp_hip_set_flux_series, shape (nsteps, 8, ncol): taux, tauy, swf, lwf, lhf, shf, rain, snow as
+    kpp_3d_fields holds them after the flux reader.  The `mix` of forcing() with the diurnal short-wave
+    cycle swf = max(0, 800 sin(2 pi t / 86400)), t = (nt-1) dto; mckpp_fluxes assembles the same
+    sflux(1:6) from them that forcing(t_seconds=t) returns."""
+    series = np.zeros((nsteps, 8, ncol))
+    sf = forcing(ncol, mix, t_seconds=0.0, index=index)        # everything but swf is constant in time
+    lit = forcing(ncol, mix, index=index)[:, 2] > 0.0          # columns that see the sun at all
+    series[:, 0] = sf[:, 0]                      # taux
+    series[:, 1] = sf[:, 1]                      # tauy
+    series[:, 4] = sf[:, 3]                      # lhf (lwf = shf = snow = 0)
+    series[:, 6] = sf[:, 5] - sf[:, 3] / EL      # rain
+    for r in range(nsteps):
+        t_seconds = (nt_first - 1 + r) * dto
+        series[r, 2] = np.where(lit, max(0.0, 800.0 * np.sin(2.0 * np.pi * t_seconds / 86400.0)), 0.0)   # swf
+    return series
+
+
+FLUX_NAMES = ("taux", "tauy", "swf", "lwf", "lhf", "shf", "rain", "snow")
+
+
 def columns(ncol, nz, dmax=200.0, zm=None, index=None, ntotal=None):
     """Initial T, S(minus Sref), U, V on the grid and the per-column scalars.
 

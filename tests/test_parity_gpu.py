@@ -979,3 +979,72 @@ def test_verticalmixing_alone(mk, kernel_env, variant, nz):
     assert np.array_equal(k3.wU[active, 0, :2], np.stack([ob["wU1"][active, 0], ob["wU2"][active, 0]], axis=1))
     for n, v in before.items():
         assert np.array_equal(getattr(k3, n), v), n
+
+
+def test_config4_full_length_1000_steps(mk):
+    """BASELINE configs[3] at its stated size and length on one GPU: 1e5 columns x 100 levels for 1000
+    hourly steps of the diurnal bench forcing through mckpp_hip_run_forced (the reference's time loop,
+    src/mckpp_ocean_model_3D.F90:38-58), state never leaving HBM, flux records uploaded per 100-step
+    window.  A strided sample of 250 columns is compared bit for bit with the oracle at steps 24, 240 and
+    1000 (status words included); flagged columns must be the oracle's; a second, independent run must
+    end bitwise identical (the column queue assigns columns to workgroups differently every launch)."""
+    import hashlib
+
+    from oracle import orc
+
+    ncol, nz, nsteps, window = 100000, 100, 1000, 100
+    checkpoints = (24, 240, 1000)
+    sample = np.arange(37, ncol, 400)
+    assert len(sample) >= 200
+
+    def gpu_run(snapshots):
+        kc, k3 = cm.make_hip_case(ncol, nz)
+        ctx = mk.MckppHip(kc)
+        ctx.upload(k3)
+        ctx.set_diagnostics(0)
+        ctx.init_ocean(0)
+        nt = 1
+        while nt <= nsteps:
+            stop = min([c for c in checkpoints if c >= nt] + [nsteps])
+            n = min(window, stop - nt + 1)
+            ctx.set_flux_series(nt - 1, cm.synth.flux_series(ncol, nt, n, kc.dto))
+            ctx.run_forced(nt, n, 1)
+            nt += n
+            if nt - 1 in checkpoints and snapshots is not None:
+                ctx.download(k3, mk.api.F_RESTART)
+                st, nf, npass = ctx.status()
+                snapshots[nt - 1] = ({f: np.array(getattr(k3, f)[sample]) for f in
+                                      ("U", "X", "Us", "Xs", "hmixd", "hmix", "kmix", "Tref", "uref", "vref", "Ssurf", "reset_flag")},
+                                     st[sample].copy(), npass[sample].copy(), int(nf))
+        ctx.download(k3, mk.api.F_RESTART)
+        h = hashlib.sha256()
+        for f in ("U", "X", "Us", "Xs", "hmixd", "hmix", "kmix"):
+            h.update(np.ascontiguousarray(getattr(k3, f)).tobytes())
+        finite = bool(np.isfinite(k3.X).all() and np.isfinite(k3.U).all() and (k3.hmix > 0).all())
+        ctx.close()
+        return h.hexdigest(), finite
+
+    snaps = {}
+    digest1, finite = gpu_run(snaps)
+    assert finite and set(snaps) == set(checkpoints)
+
+    oc, ob = cm.make_oracle(len(sample), nz, exp_mode=1, index=sample, ntotal=ncol)
+    for nt in range(1, nsteps + 1):
+        rec = cm.synth.flux_series(len(sample), nt, 1, oc.c.dto, index=sample)[0]
+        orc.fluxes(oc, ob, nt, **dict(zip(cm.synth.FLUX_NAMES, rec)))
+        orc.physics_driver(oc, ob, nt)
+        if nt in checkpoints:
+            fields, st, npass, nflag = snaps[nt]
+
+            class _Sub:
+                pass
+
+            sub = _Sub()
+            for n_, v in fields.items():
+                setattr(sub, n_, v)
+            assert np.array_equal(st, ob["status"]), f"status words at step {nt}"
+            assert np.array_equal(npass, ob["npasses"]), f"pass counts at step {nt}"
+            _assert_bitexact(cm.compare(sub, ob, nz, cm.PROFILE_FIELDS + cm.SCALAR_FIELDS + ["hmixd0", "hmixd1"]),
+                             f"config4 sample at step {nt}")
+    digest2, _ = gpu_run(None)
+    assert digest1 == digest2, "two runs of 1000 steps differ"
