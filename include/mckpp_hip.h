@@ -284,6 +284,48 @@ int mckpp_hip_exp_batch(mckpp_hip_handle h, int64_t n, const double *x, double *
  * compiler's IEEE n/d (csrc/mckpp_colmath.h); for the tests. */
 int mckpp_hip_div_batch(mckpp_hip_handle h, int64_t n, const double *num, const double *den, double *q4);
 
+/* ---------------------------------------------------------------------------
+ * Several GPUs of one node behind one handle, for a host that is a single
+ * process (the reference's program is one OpenMP process,
+ * src/mckpp_physics_driver_mod.F90:27-65: one call covers all npts).  The
+ * run_physics columns are dealt round-robin to the devices; each shard is an
+ * ordinary context (mckpp_hip_multi_ctx) and every per-context entry point
+ * above may be applied to it with the full-size Fortran arrays - a shard reads
+ * and writes only its own columns.  The multi_* forms below do exactly that
+ * for every shard; multi_step returns once all shards are launched.  There is
+ * no collective inside a step.  mckpp_hip_multi_gather is the output gather:
+ * shards -> root device over the GPU interconnect, relayout there, one
+ * device-to-host transfer.
+ * --------------------------------------------------------------------------- */
+typedef struct mckpp_hip_multi *mckpp_hip_multi_handle;
+
+/* run_physics mask of shard `dev` of `ndev` (host helper, no device work): the
+ * j-th run_physics point in ipt order belongs to shard j mod ndev.  Returns the
+ * number of columns of the shard, <0 on bad arguments. */
+int64_t mckpp_host_shard_mask(int64_t npts, const int32_t *run_physics, int32_t ndev, int32_t dev, int32_t *mask_out);
+
+/* devices == NULL: HIP devices 0 .. ndev-1. */
+int mckpp_hip_multi_init(const mckpp_const_c *c, int32_t ndev, const int32_t *devices, mckpp_hip_multi_handle *out);
+int mckpp_hip_multi_finalize(mckpp_hip_multi_handle m);
+int32_t mckpp_hip_multi_ndev(mckpp_hip_multi_handle m);
+mckpp_hip_handle mckpp_hip_multi_ctx(mckpp_hip_multi_handle m, int32_t shard);
+int mckpp_hip_multi_upload(mckpp_hip_multi_handle m, const mckpp_state_ptrs_c *s);
+int mckpp_hip_multi_set_forcing(mckpp_hip_multi_handle m, const double *sflux);
+int mckpp_hip_multi_set_diagnostics(mckpp_hip_multi_handle m, int on);
+int mckpp_hip_multi_update_ancillaries(mckpp_hip_multi_handle m, const mckpp_state_ptrs_c *s);
+int mckpp_hip_multi_bottomtemp(mckpp_hip_multi_handle m, const double *bottom_temp);
+int mckpp_hip_multi_fluxes(mckpp_hip_multi_handle m, int ntime, const double *taux, const double *tauy,
+                           const double *swf, const double *lwf, const double *lhf, const double *shf,
+                           const double *rain, const double *snow, int l_rest, double flsn, double el);
+int mckpp_hip_multi_init_ocean(mckpp_hip_multi_handle m, int ntime);
+int mckpp_hip_multi_step(mckpp_hip_multi_handle m, int ntime, int nsteps);
+int mckpp_hip_multi_synchronize(mckpp_hip_multi_handle m);
+int mckpp_hip_multi_download(mckpp_hip_multi_handle m, mckpp_state_ptrs_c *s, uint32_t field_mask);
+int mckpp_hip_multi_status(mckpp_hip_multi_handle m, int32_t *per_col, int64_t *n_flagged, int32_t *npasses);
+int64_t mckpp_hip_multi_ncolumns(mckpp_hip_multi_handle m);
+/* field: 0 U, 1 V, 2 T, 3 S -> out(npts,nzp1); 4 hmix -> out(npts); root: shard index that collects. */
+int mckpp_hip_multi_gather(mckpp_hip_multi_handle m, int32_t field, int32_t root, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,7 +34,9 @@ from .api import (  # noqa: E402,F401
     KppConstFields,
     Kpp3dFields,
     MckppHip,
+    MckppHipMulti,
     MckppHipError,
+    host_shard_mask,
     mckpp_initialize_ocean_model,
     mckpp_physics_driver,
     mckpp_physics_lookup,

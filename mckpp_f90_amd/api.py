@@ -118,6 +118,24 @@ def _bind(lib):
     lib.mckpp_hip_eos_batch.argtypes = [C.c_void_p, C.c_int64] + [_dp] * 7
     lib.mckpp_hip_exp_batch.argtypes = [C.c_void_p, C.c_int64, _dp, _dp]
     lib.mckpp_hip_div_batch.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp]
+    lib.mckpp_host_shard_mask.argtypes = [C.c_int64, _ip, C.c_int32, C.c_int32, _ip]
+    lib.mckpp_host_shard_mask.restype = C.c_int64
+    lib.mckpp_hip_multi_init.argtypes = [C.POINTER(_ConstC), C.c_int32, _ip, C.POINTER(C.c_void_p)]
+    lib.mckpp_hip_multi_finalize.argtypes = [C.c_void_p]
+    lib.mckpp_hip_multi_ndev.argtypes = [C.c_void_p]
+    lib.mckpp_hip_multi_ctx.argtypes = [C.c_void_p, C.c_int32]
+    lib.mckpp_hip_multi_ctx.restype = C.c_void_p
+    lib.mckpp_hip_multi_upload.argtypes = [C.c_void_p, C.POINTER(_StateC)]
+    lib.mckpp_hip_multi_set_forcing.argtypes = [C.c_void_p, _dp]
+    lib.mckpp_hip_multi_set_diagnostics.argtypes = [C.c_void_p, C.c_int]
+    lib.mckpp_hip_multi_init_ocean.argtypes = [C.c_void_p, C.c_int]
+    lib.mckpp_hip_multi_step.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.mckpp_hip_multi_synchronize.argtypes = [C.c_void_p]
+    lib.mckpp_hip_multi_download.argtypes = [C.c_void_p, C.POINTER(_StateC), C.c_uint32]
+    lib.mckpp_hip_multi_status.argtypes = [C.c_void_p, _ip, C.POINTER(C.c_int64), _ip]
+    lib.mckpp_hip_multi_ncolumns.argtypes = [C.c_void_p]
+    lib.mckpp_hip_multi_ncolumns.restype = C.c_int64
+    lib.mckpp_hip_multi_gather.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp]
     lib._mckpp_bound = True
     return lib
 
@@ -403,6 +421,70 @@ class MckppHip:
         y = np.zeros_like(x)
         _chk(_lib().mckpp_hip_exp_batch(self._h, len(x), x.ctypes.data_as(_dp), y.ctypes.data_as(_dp)))
         return y
+
+
+class MckppHipMulti:
+    """Several GPUs behind one handle (mckpp_hip_multi_*): columns dealt round-robin to the devices."""
+
+    def __init__(self, kpp_const_fields, devices):
+        self._h = C.c_void_p()
+        self._c = kpp_const_fields
+        cc = kpp_const_fields.as_c()
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        _chk(_lib().mckpp_hip_multi_init(C.byref(cc), len(dev), dev.ctypes.data_as(_ip), C.byref(self._h)))
+        self._npts = 0
+
+    def close(self):
+        if self._h:
+            _lib().mckpp_hip_multi_finalize(self._h)
+            self._h = C.c_void_p()
+
+    def upload(self, k3):
+        sc = k3.as_c()
+        _chk(_lib().mckpp_hip_multi_upload(self._h, C.byref(sc)))
+        self._npts = k3.npts
+
+    def set_forcing(self, sflux):
+        _chk(_lib().mckpp_hip_multi_set_forcing(self._h, sflux.ctypes.data_as(_dp)))
+
+    def init_ocean(self, ntime=0):
+        _chk(_lib().mckpp_hip_multi_init_ocean(self._h, int(ntime)))
+
+    def step(self, ntime, nsteps=1):
+        _chk(_lib().mckpp_hip_multi_step(self._h, int(ntime), int(nsteps)))
+
+    def synchronize(self):
+        _chk(_lib().mckpp_hip_multi_synchronize(self._h))
+
+    def download(self, k3, mask=F_ALL):
+        sc = k3.as_c()
+        _chk(_lib().mckpp_hip_multi_download(self._h, C.byref(sc), mask))
+
+    def status(self):
+        st = np.zeros(self._npts, dtype=np.int32)
+        npass = np.zeros(self._npts, dtype=np.int32)
+        nf = C.c_int64()
+        _chk(_lib().mckpp_hip_multi_status(self._h, st.ctypes.data_as(_ip), C.byref(nf), npass.ctypes.data_as(_ip)))
+        return st, nf.value, npass
+
+    @property
+    def ncolumns(self):
+        return _lib().mckpp_hip_multi_ncolumns(self._h)
+
+    def gather(self, field, root, out):
+        """field 0 U, 1 V, 2 T, 3 S -> out(npts, nzp1) Fortran order; 4 hmix -> out(npts)."""
+        assert out.flags["F_CONTIGUOUS"] and out.dtype == np.float64
+        _chk(_lib().mckpp_hip_multi_gather(self._h, int(field), int(root), out.ctypes.data_as(_dp)))
+
+
+def host_shard_mask(run_physics, ndev, dev):
+    """run_physics mask of shard dev of ndev (mckpp_host_shard_mask; host only)."""
+    rp = np.ascontiguousarray(run_physics, dtype=np.int32)
+    out = np.zeros(len(rp), dtype=np.int32)
+    n = _lib().mckpp_host_shard_mask(len(rp), rp.ctypes.data_as(_ip), int(ndev), int(dev), out.ctypes.data_as(_ip))
+    if n < 0:
+        raise MckppHipError("mckpp_host_shard_mask: bad arguments")
+    return out, int(n)
 
 
 # ---------------------------------------------------------------------------

@@ -1135,4 +1135,216 @@ int mckpp_hip_exp_batch(mckpp_hip_handle h, int64_t n, const double *x, double *
   return 0;
 }
 
+
+// ---------------------------------------------------------------------------
+// Several GPUs behind one handle: the run_physics columns are dealt round-robin to the
+// devices (pass counts vary along a latitude band, so a contiguous split would unbalance the shards),
+// every device holds the constants, a step launches on every device's stream before anything waits,
+// and nothing crosses devices inside a step.  The only exchange is the output gather to one root
+// device over the GPU interconnect (xGMI peer copies), relayout there, one transfer to the host.
+// ---------------------------------------------------------------------------
+struct mckpp_hip_multi {
+  std::vector<mckpp_hip_ctx *> ctx;
+  int64_t npts = 0;
+  std::vector<std::vector<int32_t>> mask;   // run_physics of each shard
+  // root-side buffers of the gather (owned by the root device of the last gather)
+  int root = -1;
+  double *d_out = nullptr, *d_stage = nullptr;
+  int *d_gipt = nullptr;
+  size_t out_elems = 0, stage_elems = 0, gipt_elems = 0;
+};
+
+// run_physics mask of shard `dev` of `ndev`: the j-th ocean point (in ipt order) goes to shard j mod ndev
+int64_t mckpp_host_shard_mask(int64_t npts, const int32_t *run_physics, int32_t ndev, int32_t dev, int32_t *mask_out)
+{
+  if (npts < 0 || ndev < 1 || dev < 0 || dev >= ndev || !mask_out) return -1;
+  int64_t j = 0, mine = 0;
+  for (int64_t i = 0; i < npts; ++i) {
+    const bool ocean = !run_physics || run_physics[i];
+    mask_out[i] = (ocean && (j % ndev) == dev) ? 1 : 0;
+    if (ocean) { mine += mask_out[i]; ++j; }
+  }
+  return mine;
+}
+
+int mckpp_hip_multi_init(const mckpp_const_c *c, int32_t ndev, const int32_t *devices, mckpp_hip_multi_handle *out)
+{
+  if (!c || !out || ndev < 1) return fail("mckpp_hip_multi_init: bad argument (ndev=%d)", ndev);
+  mckpp_hip_multi *m = new mckpp_hip_multi();
+  for (int d = 0; d < ndev; ++d) {
+    mckpp_hip_handle h = nullptr;
+    if (mckpp_hip_init(c, devices ? devices[d] : d, &h) != 0) {
+      for (auto *x : m->ctx) mckpp_hip_finalize(x);
+      delete m;
+      return -1;   // message of mckpp_hip_init
+    }
+    m->ctx.push_back(h);
+  }
+  m->mask.resize(ndev);
+  *out = m;
+  return 0;
+}
+
+int mckpp_hip_multi_finalize(mckpp_hip_multi_handle m)
+{
+  if (!m) return 0;
+  if (m->root >= 0) {
+    hipSetDevice(m->ctx[m->root]->device);
+    if (m->d_out) hipFree(m->d_out);
+    if (m->d_stage) hipFree(m->d_stage);
+    if (m->d_gipt) hipFree(m->d_gipt);
+  }
+  for (auto *x : m->ctx) mckpp_hip_finalize(x);
+  delete m;
+  return 0;
+}
+
+int32_t mckpp_hip_multi_ndev(mckpp_hip_multi_handle m) { return m ? (int32_t)m->ctx.size() : -1; }
+mckpp_hip_handle mckpp_hip_multi_ctx(mckpp_hip_multi_handle m, int32_t i)
+{
+  if (!m || i < 0 || i >= (int)m->ctx.size()) { fail("mckpp_hip_multi_ctx: shard %d", i); return nullptr; }
+  return m->ctx[i];
+}
+
+int mckpp_hip_multi_upload(mckpp_hip_multi_handle m, const mckpp_state_ptrs_c *s)
+{
+  if (!m || !s) return fail("mckpp_hip_multi_upload: null argument");
+  if (s->npts <= 0) return fail("mckpp_hip_multi_upload: npts=%lld", (long long)s->npts);
+  const int ndev = (int)m->ctx.size();
+  m->npts = s->npts;
+  for (int d = 0; d < ndev; ++d) {
+    m->mask[d].assign((size_t)s->npts, 0);
+    mckpp_host_shard_mask(s->npts, s->run_physics, ndev, d, m->mask[d].data());
+    mckpp_state_ptrs_c sd = *s;
+    sd.run_physics = m->mask[d].data();
+    if (mckpp_hip_upload(m->ctx[d], &sd) != 0) return -1;
+  }
+  return 0;
+}
+
+#define MULTI_EACH(call)                                           \
+  do {                                                             \
+    if (!m) return fail("null multi handle");                      \
+    for (auto *x : m->ctx) { if ((call) != 0) return -1; }         \
+    return 0;                                                      \
+  } while (0)
+
+int mckpp_hip_multi_set_forcing(mckpp_hip_multi_handle m, const double *sflux) { MULTI_EACH(mckpp_hip_set_forcing(x, sflux)); }
+int mckpp_hip_multi_set_diagnostics(mckpp_hip_multi_handle m, int on) { MULTI_EACH(mckpp_hip_set_diagnostics(x, on)); }
+int mckpp_hip_multi_init_ocean(mckpp_hip_multi_handle m, int ntime) { MULTI_EACH(mckpp_hip_init_ocean(x, ntime)); }
+// asynchronous on every device: all shards are launched before the caller can wait on any of them
+int mckpp_hip_multi_step(mckpp_hip_multi_handle m, int ntime, int nsteps) { MULTI_EACH(mckpp_hip_step(x, ntime, nsteps)); }
+int mckpp_hip_multi_synchronize(mckpp_hip_multi_handle m) { MULTI_EACH(mckpp_hip_synchronize(x)); }
+int mckpp_hip_multi_update_ancillaries(mckpp_hip_multi_handle m, const mckpp_state_ptrs_c *s) { MULTI_EACH(mckpp_hip_update_ancillaries(x, s)); }
+int mckpp_hip_multi_bottomtemp(mckpp_hip_multi_handle m, const double *bottom_temp) { MULTI_EACH(mckpp_hip_bottomtemp(x, bottom_temp)); }
+int mckpp_hip_multi_fluxes(mckpp_hip_multi_handle m, int ntime, const double *taux, const double *tauy, const double *swf,
+                           const double *lwf, const double *lhf, const double *shf, const double *rain, const double *snow,
+                           int l_rest, double flsn, double el)
+{
+  MULTI_EACH(mckpp_hip_fluxes(x, ntime, taux, tauy, swf, lwf, lhf, shf, rain, snow, l_rest, flsn, el));
+}
+// every shard scatters its own columns into the same Fortran arrays
+int mckpp_hip_multi_download(mckpp_hip_multi_handle m, mckpp_state_ptrs_c *s, uint32_t mask) { MULTI_EACH(mckpp_hip_download(x, s, mask)); }
+
+int64_t mckpp_hip_multi_ncolumns(mckpp_hip_multi_handle m)
+{
+  if (!m) return -1;
+  int64_t n = 0;
+  for (auto *x : m->ctx) n += x->ncol;
+  return n;
+}
+
+int mckpp_hip_multi_status(mckpp_hip_multi_handle m, int32_t *per_col, int64_t *n_flagged, int32_t *npasses)
+{
+  if (!m) return fail("null multi handle");
+  int64_t nf = 0;
+  std::vector<int32_t> st, np_;
+  if (per_col) { st.assign((size_t)m->npts, 0); for (int64_t i = 0; i < m->npts; ++i) per_col[i] = 0; }
+  if (npasses) { np_.assign((size_t)m->npts, 0); for (int64_t i = 0; i < m->npts; ++i) npasses[i] = 0; }
+  for (auto *x : m->ctx) {
+    int64_t f = 0;
+    if (mckpp_hip_status(x, per_col ? st.data() : nullptr, &f, npasses ? np_.data() : nullptr) != 0) return -1;
+    nf += f;
+    for (int64_t c = 0; c < x->ncol; ++c) {
+      const int i = x->ipt[(size_t)c];
+      if (per_col) per_col[i] = st[(size_t)i];
+      if (npasses) npasses[i] = np_[(size_t)i];
+    }
+  }
+  if (n_flagged) *n_flagged = nf;
+  return 0;
+}
+
+// Output gather: `field` 0 U, 1 V, 2 T, 3 S -> out(npts,nzp1), 4 hmix -> out(npts), in the Fortran
+// layout.  Every shard's rows travel device-to-device to shard `root` (peer copies behind an event on the
+// owner's stream, so a gather queued behind a step overlaps the other shards' tail), are re-laid there
+// into the 3D order, and cross PCIe once.  Land points keep what `out` held.
+int mckpp_hip_multi_gather(mckpp_hip_multi_handle m, int32_t field, int32_t root, double *out)
+{
+  if (!m || !out) return fail("mckpp_hip_multi_gather: null argument");
+  const int ndev = (int)m->ctx.size();
+  if (root < 0 || root >= ndev) return fail("mckpp_hip_multi_gather: root %d of %d", root, ndev);
+  if (field < 0 || field > 4) return fail("mckpp_hip_multi_gather: field %d", field);
+  if (m->npts <= 0) return fail("mckpp_hip_multi_gather: nothing uploaded");
+  mckpp_hip_ctx *r = m->ctx[root];
+  const int nlev = field < 4 ? r->nzp1 : 1;
+  const size_t nout = (size_t)m->npts * nlev;
+  size_t nstage = 0, ngipt = 0;
+  for (auto *x : m->ctx) {
+    nstage += (size_t)x->ncol * (field < 4 ? (size_t)x->ld : (size_t)MCKPP_CS);
+    ngipt += (size_t)x->ncol;
+  }
+  HIPCHK(hipSetDevice(r->device));
+  if (m->root != root) {   // buffers live on the root device
+    if (m->root >= 0) {
+      hipSetDevice(m->ctx[m->root]->device);
+      if (m->d_out) hipFree(m->d_out);
+      if (m->d_stage) hipFree(m->d_stage);
+      if (m->d_gipt) hipFree(m->d_gipt);
+      hipSetDevice(r->device);
+    }
+    m->d_out = m->d_stage = nullptr; m->d_gipt = nullptr;
+    m->out_elems = m->stage_elems = m->gipt_elems = 0;
+    m->root = root;
+    for (int d = 0; d < ndev; ++d)
+      if (d != root && m->ctx[d]->device != r->device) {
+        hipError_t e = hipDeviceEnablePeerAccess(m->ctx[d]->device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // staged copies still work
+      }
+  }
+  if (nout > m->out_elems) { if (m->d_out) hipFree(m->d_out); HIPCHK(hipMalloc(&m->d_out, nout * sizeof(double))); m->out_elems = nout; }
+  if (nstage > m->stage_elems) { if (m->d_stage) hipFree(m->d_stage); HIPCHK(hipMalloc(&m->d_stage, nstage * sizeof(double))); m->stage_elems = nstage; }
+  if (ngipt > m->gipt_elems) { if (m->d_gipt) hipFree(m->d_gipt); HIPCHK(hipMalloc(&m->d_gipt, ngipt * sizeof(int))); m->gipt_elems = ngipt; }
+  if (ngipt < (size_t)m->npts)   // land points: keep the caller's values
+    HIPCHK(hipMemcpyAsync(m->d_out, out, nout * sizeof(double), hipMemcpyHostToDevice, r->stream));
+  size_t so = 0, go = 0;
+  for (int d = 0; d < ndev; ++d) {
+    mckpp_hip_ctx *x = m->ctx[d];
+    if (x->ncol == 0) continue;
+    const int ld = field < 4 ? x->ld : MCKPP_CS;
+    const double *src = field == 0 ? x->d_prof[P_U] : field == 1 ? x->d_prof[P_V] : field == 2 ? x->d_prof[P_T]
+                      : field == 3 ? x->d_prof[P_S] : x->d_cs;
+    const size_t n = (size_t)x->ncol * ld;
+    // order the copy behind whatever the owner's stream still has queued
+    HIPCHK(hipSetDevice(x->device));
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev, x->stream));
+    HIPCHK(hipSetDevice(r->device));
+    HIPCHK(hipStreamWaitEvent(r->stream, ev, 0));
+    if (x->device == r->device) HIPCHK(hipMemcpyAsync(m->d_stage + so, src, n * sizeof(double), hipMemcpyDeviceToDevice, r->stream));
+    else HIPCHK(hipMemcpyPeerAsync(m->d_stage + so, r->device, src, x->device, n * sizeof(double), r->stream));
+    HIPCHK(hipMemcpyAsync(m->d_gipt + go, x->ipt.data(), (size_t)x->ncol * sizeof(int), hipMemcpyHostToDevice, r->stream));
+    HIPCHK(mckpp_launch_scatter_rows(m->d_stage + so, ld, field < 4 ? 0 : CS_HMIX, m->d_gipt + go, x->ncol, m->d_out,
+                                     m->npts, nlev, 0, r->stream));
+    HIPCHK(hipStreamSynchronize(r->stream));   // x->ipt is pageable host memory; also lets the event go
+    HIPCHK(hipEventDestroy(ev));
+    so += n;
+    go += (size_t)x->ncol;
+  }
+  HIPCHK(hipMemcpyAsync(out, m->d_out, nout * sizeof(double), hipMemcpyDeviceToHost, r->stream));
+  HIPCHK(hipStreamSynchronize(r->stream));
+  return 0;
+}
+
 }  // extern "C"

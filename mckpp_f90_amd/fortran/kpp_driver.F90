@@ -16,6 +16,7 @@ program kpp_driver
   use mckpp_physics_ocnstep_mod, only: mckpp_physics_ocnstep
   use mckpp_physics_verticalmixing_mod, only: mckpp_physics_verticalmixing
   use mckpp_fluxes_mod, only: mckpp_fluxes
+  use mckpp_hip_session, only: mckpp_hip_ndevices, mckpp_hip_device_list, mckpp_hip_gather_field
   implicit none
   character(len=512) :: fin, fout
   integer :: u, nt, nsteps, ncol, nlev, use_1d, ipt, flags
@@ -35,6 +36,15 @@ program kpp_driver
   ! flags: 1 forcing through mckpp_fluxes (constant forcing, L_FLUXDATA=.F.) every step; 2 L_VARY_BOTTOM_TEMP;
   !        4 after the run, mckpp_physics_verticalmixing on every column of the final state (appended to the output)
   flags = hdr(6)
+  ! hdr(7) > 0: that many device shards; hdr(8) = 1 puts them all on HIP device 0 (one-GPU rehearsal of the
+  ! multi-device path), otherwise devices 0 .. hdr(7)-1
+  if (hdr(7) > 0) then
+    mckpp_hip_ndevices = hdr(7)
+    if (hdr(8) == 1) then
+      allocate (mckpp_hip_device_list(hdr(7)))
+      mckpp_hip_device_list = 0
+    end if
+  end if
   call mckpp_set_dimensions(ncol, 1, nlev, hdr(5))
   call mckpp_allocate_const_fields()
   call mckpp_allocate_3d_fields()
@@ -90,6 +100,14 @@ program kpp_driver
   write (u) kpp_3d_fields%hmix, kpp_3d_fields%kmix, kpp_3d_fields%hmixd, kpp_3d_fields%Tref, kpp_3d_fields%Ssurf
   write (u) kpp_3d_fields%old, kpp_3d_fields%new
   write (u) kpp_3d_fields%difm, kpp_3d_fields%ghat, kpp_3d_fields%rho
+  if (iand(flags, 8) /= 0) then   ! the output gather (hmix, T) over the device interconnect instead of the download
+    allocate (vm_h(ncol), vm_difm(ncol, nzp1))
+    vm_h = -1; vm_difm = -1
+    call mckpp_hip_gather_field(4, max(0, mckpp_hip_ndevices - 1), vm_h)
+    call mckpp_hip_gather_field(2, 0, vm_difm)
+    write (u) vm_h, vm_difm
+    deallocate (vm_h, vm_difm)
+  end if
   if (iand(flags, 4) /= 0) then
     allocate (vm_h(ncol), vm_k(ncol), vm_difm(ncol,0:nztmax), vm_difs(ncol,0:nztmax), vm_dift(ncol,0:nztmax), vm_ghat(ncol,nztmax))
     vm_h = 0; vm_k = 0; vm_difm = 0; vm_difs = 0; vm_dift = 0; vm_ghat = 0

@@ -23,7 +23,7 @@ contains
         s%lhf = -150; s%shf = 0; s%rain = 6e-5_c_double; s%snow = 0
       end if
       call mckpp_hip_push_state()
-      call mckpp_hip_check(mckpp_hip_fluxes(mckpp_hip_handle, int(ntime, c_int), s%taux, s%tauy, s%swf, s%lwf, &
+      call mckpp_hip_check(mckpp_hip_multi_fluxes(mckpp_hip_multi_handle, int(ntime, c_int), s%taux, s%tauy, s%swf, s%lwf, &
                            s%lhf, s%shf, s%rain, s%snow, l2i(kpp_const_fields%L_REST), kpp_const_fields%FLSN, &
                            kpp_const_fields%EL), 'mckpp_hip_fluxes')
       call mckpp_hip_pull_state(MCKPP_F_SCALARS)   ! sflux(:,1:6,5,0) back for callers that read it

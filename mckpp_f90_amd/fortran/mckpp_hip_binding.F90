@@ -148,6 +148,90 @@ module mckpp_hip_binding
       integer(c_int), value :: ntime, nsteps
       integer(c_int) :: rc
     end function
+    ! ---- several GPUs behind one handle (include/mckpp_hip.h, mckpp_hip_multi_*) ----
+    function mckpp_hip_multi_init(c, ndev, devices, handle) bind(C, name="mckpp_hip_multi_init") result(rc)
+      import :: c_int, c_int32_t, c_ptr, mckpp_const_c
+      type(mckpp_const_c), intent(in) :: c
+      integer(c_int32_t), value :: ndev
+      integer(c_int32_t), intent(in) :: devices(*)
+      type(c_ptr), intent(out) :: handle
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_finalize(handle) bind(C, name="mckpp_hip_multi_finalize") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_ctx(handle, shard) bind(C, name="mckpp_hip_multi_ctx") result(h)
+      import :: c_int32_t, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: shard
+      type(c_ptr) :: h
+    end function
+    function mckpp_hip_multi_upload(handle, s) bind(C, name="mckpp_hip_multi_upload") result(rc)
+      import :: c_int, c_ptr, mckpp_state_ptrs_c
+      type(c_ptr), value :: handle
+      type(mckpp_state_ptrs_c), intent(in) :: s
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_update_ancillaries(handle, s) bind(C, name="mckpp_hip_multi_update_ancillaries") result(rc)
+      import :: c_int, c_ptr, mckpp_state_ptrs_c
+      type(c_ptr), value :: handle
+      type(mckpp_state_ptrs_c), intent(in) :: s
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_set_forcing(handle, sflux) bind(C, name="mckpp_hip_multi_set_forcing") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: handle
+      real(c_double), intent(in) :: sflux(*)
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_fluxes(handle, ntime, taux, tauy, swf, lwf, lhf, shf, rain, snow, l_rest, flsn, el) &
+        bind(C, name="mckpp_hip_multi_fluxes") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: handle
+      integer(c_int), value :: ntime, l_rest
+      real(c_double), intent(in) :: taux(*), tauy(*), swf(*), lwf(*), lhf(*), shf(*), rain(*), snow(*)
+      real(c_double), value :: flsn, el
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_bottomtemp(handle, bottom_temp) bind(C, name="mckpp_hip_multi_bottomtemp") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: handle
+      real(c_double), intent(in) :: bottom_temp(*)
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_init_ocean(handle, ntime) bind(C, name="mckpp_hip_multi_init_ocean") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int), value :: ntime
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_step(handle, ntime, nsteps) bind(C, name="mckpp_hip_multi_step") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int), value :: ntime, nsteps
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_synchronize(handle) bind(C, name="mckpp_hip_multi_synchronize") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_download(handle, s, mask) bind(C, name="mckpp_hip_multi_download") result(rc)
+      import :: c_int, c_int32_t, c_ptr, mckpp_state_ptrs_c
+      type(c_ptr), value :: handle
+      type(mckpp_state_ptrs_c), intent(in) :: s
+      integer(c_int32_t), value :: mask
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_gather(handle, field, root, out) bind(C, name="mckpp_hip_multi_gather") result(rc)
+      import :: c_int, c_int32_t, c_ptr, c_double
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: field, root
+      real(c_double), intent(inout) :: out(*)
+      integer(c_int) :: rc
+    end function
     function mckpp_hip_vmix_only(handle, ntime) bind(C, name="mckpp_hip_vmix_only") result(rc)
       import :: c_int, c_ptr
       type(c_ptr), value :: handle

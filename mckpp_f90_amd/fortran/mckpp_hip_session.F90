@@ -13,8 +13,18 @@ module mckpp_hip_session
   public :: mckpp_hip_attach, mckpp_hip_push_state, mckpp_hip_pull_state, mckpp_hip_detach
   public :: mckpp_hip_handle, mckpp_hip_check, mckpp_hip_output_mask, mckpp_hip_device
   public :: mckpp_hip_push_ancillaries, mckpp_hip_ancillaries_every_step
+  public :: mckpp_hip_multi_handle, mckpp_hip_ndevices, mckpp_hip_device_list, mckpp_hip_gather_field
   public :: mckpp_hip_const_view, mckpp_hip_state_view, l2i
 
+  !> All devices of the run behind one handle (include/mckpp_hip.h, mckpp_hip_multi_*): the columns of
+  !! kpp_3d_fields are dealt round-robin over mckpp_hip_ndevices GPUs, HIP devices mckpp_hip_device,
+  !! mckpp_hip_device+1, ... unless mckpp_hip_device_list names them.  One Fortran process drives them
+  !! all - no MPI - exactly as the reference's single mckpp_physics_driver call covers all npts
+  !! (src/mckpp_physics_driver_mod.F90:27-65).  mckpp_hip_handle is shard 0 (the whole run when
+  !! mckpp_hip_ndevices = 1).
+  type(c_ptr), save :: mckpp_hip_multi_handle = c_null_ptr
+  integer(c_int), save :: mckpp_hip_ndevices = 1
+  integer(c_int32_t), allocatable, save :: mckpp_hip_device_list(:)
   type(c_ptr), save :: mckpp_hip_handle = c_null_ptr
   integer(c_int), save :: mckpp_hip_output_mask = MCKPP_F_ALL   !< fields copied back after each driver call
   integer(c_int), save :: mckpp_hip_device = 0
@@ -111,9 +121,20 @@ contains
   !> Create the device context from kpp_const_fields (idempotent).
   subroutine mckpp_hip_attach()
     type(mckpp_const_c) :: c
-    if (c_associated(mckpp_hip_handle)) return
+    integer(c_int32_t), allocatable :: dev(:)
+    integer :: i
+    if (c_associated(mckpp_hip_multi_handle)) return
     call mckpp_hip_const_view(kpp_const_fields, c)
-    call mckpp_hip_check(mckpp_hip_init(c, mckpp_hip_device, mckpp_hip_handle), 'mckpp_hip_init')
+    if (allocated(mckpp_hip_device_list)) then
+      dev = mckpp_hip_device_list
+      mckpp_hip_ndevices = size(dev)
+    else
+      allocate (dev(mckpp_hip_ndevices))
+      dev = [(int(mckpp_hip_device + i - 1, c_int32_t), i = 1, mckpp_hip_ndevices)]
+    end if
+    call mckpp_hip_check(mckpp_hip_multi_init(c, int(mckpp_hip_ndevices, c_int32_t), dev, mckpp_hip_multi_handle), &
+                         'mckpp_hip_multi_init')
+    mckpp_hip_handle = mckpp_hip_multi_ctx(mckpp_hip_multi_handle, 0_c_int32_t)
   end subroutine mckpp_hip_attach
 
   !> Optional-physics inputs only (relaxation, corrections, climatologies, advection): host -> HBM.
@@ -121,7 +142,7 @@ contains
     type(mckpp_state_ptrs_c) :: s
     if (.not. resident) return   ! the full upload that is still to come carries them
     call mckpp_hip_state_view(kpp_3d_fields, npts, s)
-    call mckpp_hip_check(mckpp_hip_update_ancillaries(mckpp_hip_handle, s), 'mckpp_hip_update_ancillaries')
+    call mckpp_hip_check(mckpp_hip_multi_update_ancillaries(mckpp_hip_multi_handle, s), 'mckpp_hip_update_ancillaries')
   end subroutine mckpp_hip_push_ancillaries
 
   !> kpp_3d_fields -> HBM (once; afterwards the state lives on the device).  A forced re-upload
@@ -141,7 +162,7 @@ contains
       if (missing /= 0) call mckpp_hip_pull_state(missing)
     end if
     call mckpp_hip_state_view(kpp_3d_fields, npts, s)
-    call mckpp_hip_check(mckpp_hip_upload(mckpp_hip_handle, s), 'mckpp_hip_upload')
+    call mckpp_hip_check(mckpp_hip_multi_upload(mckpp_hip_multi_handle, s), 'mckpp_hip_upload')
     resident = .true.
   end subroutine mckpp_hip_push_state
 
@@ -151,12 +172,23 @@ contains
     type(mckpp_state_ptrs_c) :: s
     if (mask == 0) return
     call mckpp_hip_state_view(kpp_3d_fields, npts, s)
-    call mckpp_hip_check(mckpp_hip_download(mckpp_hip_handle, s, int(mask, c_int32_t)), 'mckpp_hip_download')
+    call mckpp_hip_check(mckpp_hip_multi_download(mckpp_hip_multi_handle, s, int(mask, c_int32_t)), 'mckpp_hip_download')
   end subroutine mckpp_hip_pull_state
+
+  !> Output gather without a full download: field 0 U, 1 V, 2 T, 3 S -> out(npts,nzp1), 4 hmix -> out(npts);
+  !! the shards' rows travel over the GPU interconnect to device `root` (0-based shard index) and cross
+  !! PCIe once (SURVEY 8(e): the diagnostics gather is the path's only exchange).
+  subroutine mckpp_hip_gather_field(field, root, out)
+    integer, intent(in) :: field, root
+    real(c_double), intent(inout) :: out(*)
+    call mckpp_hip_check(mckpp_hip_multi_gather(mckpp_hip_multi_handle, int(field, c_int32_t), int(root, c_int32_t), out), &
+                         'mckpp_hip_multi_gather')
+  end subroutine mckpp_hip_gather_field
 
   subroutine mckpp_hip_detach()
     integer(c_int) :: rc
-    if (c_associated(mckpp_hip_handle)) rc = mckpp_hip_finalize(mckpp_hip_handle)
+    if (c_associated(mckpp_hip_multi_handle)) rc = mckpp_hip_multi_finalize(mckpp_hip_multi_handle)
+    mckpp_hip_multi_handle = c_null_ptr
     mckpp_hip_handle = c_null_ptr
     resident = .false.
   end subroutine mckpp_hip_detach

@@ -18,7 +18,7 @@ contains
       return
     end if
     call mckpp_hip_push_state(force=.true.)
-    call mckpp_hip_check(mckpp_hip_init_ocean(mckpp_hip_handle, int(ntime, c_int)), 'mckpp_hip_init_ocean')
+    call mckpp_hip_check(mckpp_hip_multi_init_ocean(mckpp_hip_multi_handle, int(ntime, c_int)), 'mckpp_hip_init_ocean')
     call mckpp_hip_pull_state(MCKPP_F_ALL)
   end subroutine mckpp_initialize_ocean_model
 end module mckpp_initialize_ocean

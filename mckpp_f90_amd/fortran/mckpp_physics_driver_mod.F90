@@ -1,8 +1,8 @@
 !> mckpp_physics_driver with the reference's interface: no arguments, works on
 !! the module globals kpp_3d_fields / kpp_const_fields and reads ntime
 !! (src/mckpp_physics_driver_mod.F90:15-73).  The OpenMP column loop with its
-!! per-column 3D<->1D copies is replaced by one kernel launch over all
-!! run_physics columns; state stays in HBM between calls and only the field
+!! per-column 3D<->1D copies is replaced by one kernel launch per GPU over its
+!! share of the run_physics columns (mckpp_hip_session: mckpp_hip_ndevices); state stays in HBM between calls and only the field
 !! groups in mckpp_hip_output_mask come back each step.
 module mckpp_physics_driver_mod
   use iso_c_binding, only: c_int
@@ -17,15 +17,16 @@ contains
     ! what mckpp_boundary_update may have rewritten since the last step (src/mckpp_ocean_model_3D.F90:51-55)
     if (mckpp_hip_ancillaries_every_step) call mckpp_hip_push_ancillaries()
     ! forcing written by mckpp_fluxes into sflux(:,1:6,5,0) (src/mckpp_fluxes_mod.F90:62-69)
-    call mckpp_hip_check(mckpp_hip_set_forcing(mckpp_hip_handle, kpp_3d_fields%sflux), 'mckpp_hip_set_forcing')
-    call mckpp_hip_check(mckpp_hip_step(mckpp_hip_handle, int(ntime, c_int), 1_c_int), 'mckpp_hip_step')
+    call mckpp_hip_check(mckpp_hip_multi_set_forcing(mckpp_hip_multi_handle, kpp_3d_fields%sflux), 'mckpp_hip_set_forcing')
+    ! every device's shard is launched before anything waits (the download below is the first wait)
+    call mckpp_hip_check(mckpp_hip_multi_step(mckpp_hip_multi_handle, int(ntime, c_int), 1_c_int), 'mckpp_hip_step')
     ! mckpp_physics_overrides_bottomtemp after the column loop (src/mckpp_physics_driver_mod.F90:67-71)
     if (kpp_const_fields%L_VARY_BOTTOM_TEMP) then
       if (.not. allocated(kpp_3d_fields%bottom_temp)) then
         write (0, '(a)') 'MCKPP-HIP ERROR: L_VARY_BOTTOM_TEMP needs kpp_3d_fields%bottom_temp (mckpp_allocate_3d_optional)'
         error stop 1
       end if
-      call mckpp_hip_check(mckpp_hip_bottomtemp(mckpp_hip_handle, kpp_3d_fields%bottom_temp), 'mckpp_hip_bottomtemp')
+      call mckpp_hip_check(mckpp_hip_multi_bottomtemp(mckpp_hip_multi_handle, kpp_3d_fields%bottom_temp), 'mckpp_hip_bottomtemp')
     end if
     call mckpp_hip_pull_state(mckpp_hip_output_mask)
   end subroutine mckpp_physics_driver

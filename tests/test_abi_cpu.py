@@ -121,3 +121,25 @@ def test_synthetic_generators_are_sliceable():
     for k in ("T", "S", "U", "f", "Sref"):
         assert np.array_equal(a[k][idx], b[k])
     assert np.array_equal(cm.synth.forcing(30)[idx], cm.synth.forcing(len(idx), index=idx))
+
+
+def test_shard_mask_logic(built):
+    """mckpp_host_shard_mask (the column-to-device map of mckpp_hip_multi_upload): the j-th run_physics
+    point goes to shard j mod ndev - shards are disjoint, cover the ocean, differ by at most one column."""
+    import mckpp_f90_amd as mk
+
+    rng = np.random.default_rng(3)
+    for npts, ndev in [(1, 1), (17, 3), (1000, 8), (1000, 7), (5, 8)]:
+        rp = (rng.uniform(size=npts) > 0.35).astype(np.int32)
+        total = np.zeros(npts, dtype=np.int32)
+        counts = []
+        ocean = np.flatnonzero(rp)
+        for d in range(ndev):
+            m, n = mk.host_shard_mask(rp, ndev, d)
+            assert n == int(m.sum())
+            assert np.array_equal(np.flatnonzero(m), ocean[d::ndev])      # round-robin in ipt order
+            total += m
+            counts.append(n)
+        assert np.array_equal(total, rp) and max(counts) - min(counts) <= 1
+    with pytest.raises(mk.MckppHipError):
+        mk.host_shard_mask(np.ones(4, dtype=np.int32), 2, 2)

@@ -14,10 +14,10 @@ import common as cm
 DRIVER = os.path.join(cm.ROOT, "mckpp_f90_amd", "kpp_driver")
 
 
-def _write_case(path, kc, k3, sf6, nsteps, use_1d, flags=0):
+def _write_case(path, kc, k3, sf6, nsteps, use_1d, flags=0, shards=0):
     npts, nz = k3.npts, kc.nz
     with open(path, "wb") as f:
-        np.array([npts, nz, nsteps, use_1d, kc.nztmax, flags, 0, 0], dtype=np.int32).tofile(f)
+        np.array([npts, nz, nsteps, use_1d, kc.nztmax, flags, shards, 1 if shards else 0], dtype=np.int32).tofile(f)
         np.array([kc.dto]).tofile(f)
         for a in (kc.zm, kc.hm, kc.dm):
             np.asarray(a, dtype=np.float64).tofile(f)
@@ -30,7 +30,7 @@ def _write_case(path, kc, k3, sf6, nsteps, use_1d, flags=0):
         np.asarray(sf6).ravel(order="F").tofile(f)
 
 
-def _read_out(path, kc, npts, vmix=False):
+def _read_out(path, kc, npts, vmix=False, gather=False):
     nz, nzp1, nzt = kc.nz, kc.nzp1, kc.nztmax
     out = {}
     with open(path, "rb") as f:
@@ -43,6 +43,8 @@ def _read_out(path, kc, npts, vmix=False):
         out["Tref"] = rd((npts,)); out["Ssurf"] = rd((npts,))
         out["old"] = rd((npts,), np.int32); out["new_"] = rd((npts,), np.int32)
         out["difm"] = rd((npts, nzt + 1)); out["ghat"] = rd((npts, nzt)); out["rho"] = rd((npts, nzt + 2))
+        if gather:
+            out["g_hmix"] = rd((npts,)); out["g_T"] = rd((npts, nzp1))
         if vmix:
             out["vm_h"] = rd((npts,)); out["vm_k"] = rd((npts,))
             out["vm_difm"] = rd((npts, nzt + 1)); out["vm_difs"] = rd((npts, nzt + 1)); out["vm_dift"] = rd((npts, nzt + 1))
@@ -140,3 +142,29 @@ def test_fortran_verticalmixing_wrapper(built, tmp_path, ncol, nz, land):
     for n, o in (("vm_difm", "difm"), ("vm_difs", "difs"), ("vm_dift", "dift")):
         assert np.array_equal(got[n][act][:, :nz + 2], ob[o][act][:, :nz + 2]), n
     assert np.array_equal(got["vm_ghat"][act][:, :nz], ob["ghat"][act][:, 1:nz + 1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ncol,nz,shards,land", [(301, 60, 3, 5), (200, 69, 2, 0)])
+def test_fortran_driver_on_several_device_shards(built, tmp_path, ncol, nz, shards, land):
+    """kpp_driver with mckpp_hip_ndevices = 2 or 3 (all shards on device 0: the box has one GPU): the
+    drop-in mckpp_physics_driver drives every shard from the one Fortran process, and the output gather
+    (mckpp_hip_gather_field -> mckpp_hip_multi_gather) returns the same hmix and T as the download."""
+    import mckpp_f90_amd as mk
+
+    nsteps = 3
+    kc, k3 = cm.make_hip_case(ncol, nz, land_every=land)
+    sf = cm.synth.forcing(ncol, "bench")
+    _write_case(tmp_path / "case.bin", kc, k3, sf, nsteps, 0, flags=8, shards=shards)
+    r = subprocess.run([DRIVER, str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = _read_out(tmp_path / "out.bin", kc, ncol, gather=True)
+    mk.mckpp_initialize_ocean_model(k3, kc)
+    cm.set_forcing_3d(k3, sf)
+    for nt in range(1, nsteps + 1):
+        mk.mckpp_physics_driver(k3, kc, nt)
+    for n in ("U", "X", "Us", "Xs", "hmix", "kmix", "hmixd", "Tref", "Ssurf", "old", "new_", "difm", "ghat", "rho"):
+        assert np.array_equal(got[n], getattr(k3, n)), n
+    ocean = k3.run_physics != 0
+    assert np.array_equal(got["g_hmix"][ocean], k3.hmix[ocean]) and np.all(got["g_hmix"][~ocean] == -1)
+    assert np.array_equal(got["g_T"][ocean], k3.X[ocean, :, 0]) and np.all(got["g_T"][~ocean] == -1)

@@ -1048,3 +1048,43 @@ def test_config4_full_length_1000_steps(mk):
                              f"config4 sample at step {nt}")
     digest2, _ = gpu_run(None)
     assert digest1 == digest2, "two runs of 1000 steps differ"
+
+
+@pytest.mark.parametrize("nz,shards", [(60, 1), (60, 3), (69, 4)])
+def test_multi_device_handle_equals_single_context(mk, nz, shards):
+    """mckpp_hip_multi_*: columns dealt round-robin over `shards` contexts (all on device 0 here - the box
+    has one GPU - which exercises the sharding, the per-shard scatter into shared host arrays and the
+    gather-to-root with its relayout exactly as N devices would).  State after init + 3 steps, status
+    words and the gathered U/T/hmix must equal the single-context path bit for bit."""
+    ncol = 997
+    sf = cm.synth.forcing(ncol, "bench")
+    kc, k3 = cm.make_hip_case(ncol, nz, land_every=6)
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    cm.set_forcing_3d(k3, sf)
+    for nt in (1, 2, 3):
+        mk.mckpp_physics_driver(k3, kc, nt)
+    st1, nf1, np1 = ctx.status()
+
+    kc2, k3m = cm.make_hip_case(ncol, nz, land_every=6)
+    m = mk.MckppHipMulti(kc2, [0] * shards)
+    m.upload(k3m)
+    assert m.ncolumns == ctx.ncolumns
+    m.init_ocean(0)
+    cm.set_forcing_3d(k3m, sf)
+    m.set_forcing(k3m.sflux)
+    m.step(1, 3)
+    m.synchronize()
+    m.download(k3m)
+    for n in ("U", "X", "Us", "Xs", "hmixd", "hmix", "kmix", "Tref", "uref", "vref", "Ssurf", "old", "new_", "difm", "rho", "wX"):
+        assert np.array_equal(getattr(k3, n), getattr(k3m, n)), n
+    st2, nf2, np2 = m.status()
+    assert np.array_equal(st1, st2) and np.array_equal(np1, np2) and nf1 == nf2
+    for field, want in ((0, k3.U[:, :, 0]), (2, k3.X[:, :, 0]), (3, k3.X[:, :, 1])):
+        out = np.full((ncol, nz + 1), -7.0, order="F")
+        m.gather(field, shards - 1, out)
+        land = k3.run_physics == 0
+        assert np.array_equal(out[~land], np.asarray(want)[~land]) and np.all(out[land] == -7.0), field
+    h = np.zeros(ncol, order="F")
+    m.gather(4, 0, h)
+    assert np.array_equal(h, k3.hmix)
+    m.close()
