@@ -242,11 +242,28 @@ int mckpp_hip_load_restart(mckpp_hip_handle h, const char *path);
  * No-op on a default-physics context. */
 int mckpp_hip_update_ancillaries(mckpp_hip_handle h, const mckpp_state_ptrs_c *s);
 
-/* Output-window reductions on the device (replace the XIOS temporal operations
- * "average" / "minimum" / "maximum" of run/iodef.xml:91-116 on the fields sent
- * at src/mckpp_xios_io.F90:74-210): reset at the start of an output window,
- * accumulate once after each step, fetch at the end.
- * field: 0 U, 1 V, 2 T, 3 S -> out(npts,nzp1); 4 hmix -> out(npts).  op: 0 mean, 1 min, 2 max. */
+/* Output fields and their temporal operations on the device: what mckpp_xios_output_control sends
+ * every step (src/mckpp_xios_io.F90:74-210) and what XIOS then does with it ("instant", "average",
+ * "minimum", "maximum", run/iodef.xml:88-157), so that only reduced fields leave the GPU.
+ * MCKPP_OUT_* names follow the XIOS field ids; 3-D fields come back as out(npts,nzp1) on the vertical
+ * axis the reference sends them on (levels 1..nzp1 for u, v, T, S, B, rho, cp, Rig, dbloc (0 at nzp1),
+ * Shsq and the correction increments; interfaces 0..nz for wu..wTnt and for difm/dift/difs, whose
+ * shifted copy at :136-148 is dif*(0:nz)), 2-D fields as out(npts).  S is X(:,:,2)+Sref as at :108-111;
+ * MCKPP_OUT_S_ANOM is the bare X(:,:,2).  cplwght (a coupling weight, not on this path) is not offered.
+ *   window_select: the fields accumulate reduces (default u, v, T, S_ANOM, hmix); resets the window
+ *   window_reset / window_accumulate: start of an output window / once after each step
+ *   window_fetch: op 0 mean, 1 min, 2 max over the window (selected fields); op 3 instant - the field as
+ *     it stands on the device now, any field, no accumulate needed.  Land points keep what `out` held. */
+enum {
+  MCKPP_OUT_U = 0, MCKPP_OUT_V, MCKPP_OUT_T, MCKPP_OUT_S_ANOM, MCKPP_OUT_HMIX,
+  MCKPP_OUT_S, MCKPP_OUT_B, MCKPP_OUT_WU, MCKPP_OUT_WV, MCKPP_OUT_WT, MCKPP_OUT_WS, MCKPP_OUT_WB, MCKPP_OUT_WTNT,
+  MCKPP_OUT_DIFM, MCKPP_OUT_DIFT, MCKPP_OUT_DIFS, MCKPP_OUT_RHO, MCKPP_OUT_CP, MCKPP_OUT_SCORR, MCKPP_OUT_RIG,
+  MCKPP_OUT_DBLOC, MCKPP_OUT_SHSQ, MCKPP_OUT_TINC_FCORR, MCKPP_OUT_FCORR_Z, MCKPP_OUT_SINC_FCORR,
+  MCKPP_OUT_FCORR, MCKPP_OUT_TAUX_IN, MCKPP_OUT_TAUY_IN, MCKPP_OUT_SOLAR_IN, MCKPP_OUT_NSOLAR_IN, MCKPP_OUT_PMINUSE_IN,
+  MCKPP_OUT_FREEZE_FLAG, MCKPP_OUT_COMP_FLAG, MCKPP_OUT_DAMPU_FLAG, MCKPP_OUT_DAMPV_FLAG,
+  MCKPP_OUT_COUNT
+};
+int mckpp_hip_window_select(mckpp_hip_handle h, const int32_t *fields, int32_t nfields);
 int mckpp_hip_window_reset(mckpp_hip_handle h);
 int mckpp_hip_window_accumulate(mckpp_hip_handle h);
 int mckpp_hip_window_fetch(mckpp_hip_handle h, int field, int op, double *out);

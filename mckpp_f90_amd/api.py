@@ -73,6 +73,15 @@ class _StateC(C.Structure):
     )
 
 
+# output fields of mckpp_hip_window_* (MCKPP_OUT_* of include/mckpp_hip.h; the XIOS field ids of
+# src/mckpp_xios_io.F90:74-210)
+OUT_FIELDS = ("u", "v", "T", "S_anom", "hmix", "S", "B", "wu", "wv", "wT", "wS", "wB", "wTnt", "difm", "dift", "difs",
+              "rho", "cp", "scorr", "Rig", "dbloc", "Shsq", "tinc_fcorr", "fcorr_z", "sinc_fcorr", "fcorr", "taux_in",
+              "tauy_in", "solar_in", "nsolar_in", "PminusE_in", "freeze_flag", "comp_flag", "dampu_flag", "dampv_flag")
+OUT = {n: i for i, n in enumerate(OUT_FIELDS)}
+OP_MEAN, OP_MIN, OP_MAX, OP_INSTANT = 0, 1, 2, 3
+
+
 class MckppHipError(RuntimeError):
     pass
 
@@ -93,6 +102,7 @@ def _bind(lib):
     lib.mckpp_hip_set_forcing.argtypes = [C.c_void_p, _dp]
     lib.mckpp_hip_set_diagnostics.argtypes = [C.c_void_p, C.c_int]
     lib.mckpp_hip_window_reset.argtypes = [C.c_void_p]
+    lib.mckpp_hip_window_select.argtypes = [C.c_void_p, _ip, C.c_int32]
     lib.mckpp_hip_window_accumulate.argtypes = [C.c_void_p]
     lib.mckpp_hip_window_fetch.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
     lib.mckpp_hip_save_restart.argtypes = [C.c_void_p, C.c_char_p]
@@ -342,6 +352,11 @@ class MckppHip:
 
     def window_accumulate(self):
         _chk(_lib().mckpp_hip_window_accumulate(self._h))
+
+    def window_select(self, fields):
+        """Choose the OUT_* fields window_accumulate reduces (resets the window)."""
+        f = np.ascontiguousarray(fields, dtype=np.int32)
+        _chk(_lib().mckpp_hip_window_select(self._h, f.ctypes.data_as(_ip), len(f)))
 
     def window_fetch(self, field, op, out):
         assert out.flags["F_CONTIGUOUS"] and out.dtype == np.float64

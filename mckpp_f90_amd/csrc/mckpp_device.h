@@ -89,9 +89,9 @@ hipError_t mckpp_launch_exp_batch(int64_t n, const double *x, double *y, hipStre
 hipError_t mckpp_launch_bottomtemp(const mckpp_kparams &p, const double *bt, hipStream_t stream);
 hipError_t mckpp_launch_fluxes(const mckpp_kparams &p, int ntime, const double *f8, int l_rest, double flsn,
                                double el, hipStream_t stream);
-hipError_t mckpp_launch_window_accumulate(const double *u, const double *v, const double *t, const double *s,
-                                          double *acc, size_t nelem, const double *cs, double *hacc, int ncol,
-                                          int first, hipStream_t stream);
+hipError_t mckpp_launch_out_sample(const double *src, int src_ld, int src_off, const double *cs, int add_sref,
+                                   int64_t ncol, int nlev, int ld_out, double *sum, double *mn, double *mx, int first,
+                                   double *inst, hipStream_t stream);
 hipError_t mckpp_launch_window_mean(const double *sum, double *out, size_t n, double count, hipStream_t stream);
 // layout kernels: Fortran (npts-fastest) <-> device rows
 hipError_t mckpp_launch_gather_rows(const double *src3d, int64_t npts, int nlev, int lev_off,

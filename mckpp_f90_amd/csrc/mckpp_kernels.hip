@@ -151,40 +151,34 @@ __global__ void k_bottomtemp(mckpp_kparams p, const double *__restrict__ bt)
 }
 
 // ---------------------------------------------------------------------------
-// Output-window reductions: running sum / min / max of the
-// profile rows and of hmix, replacing XIOS's temporal operations
-// (run/iodef.xml:91-116) so only reduced fields leave the device.  Pure
-// streaming: 16 B per lane per access, one pass over the rows per step.
-// acc layout: [field][3][ncol*ld] with 3 = {sum, min, max}; hacc: [3][ncol].
+// Output-window reductions: what XIOS does with the fields mckpp_xios_output_control
+// sends (src/mckpp_xios_io.F90:74-210; operations instant / average / minimum / maximum of
+// run/iodef.xml:88-157), on the device so that only reduced fields cross PCIe / xGMI.
+// One output field = nlev values per column taken from a device row array (element src_off + l of
+// the column's row, row length src_ld) or from the column record (src_ld = MCKPP_CS, nlev = 1),
+// optionally plus the column's Sref (the reference sends S = X(:,:,2) + Sref).  One thread per
+// (column, level): either one sample into `inst`, or the running sum / min / max.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_window_accumulate(const double2 *__restrict__ u, const double2 *__restrict__ v,
-                                                         const double2 *__restrict__ t, const double2 *__restrict__ s,
-                                                         double2 *__restrict__ acc, size_t n2, const double *__restrict__ cs,
-                                                         double *__restrict__ hacc, int ncol, int first)
+__global__ __launch_bounds__(256) void k_out_sample(const double *__restrict__ src, int src_ld, int src_off,
+                                                   const double *__restrict__ cs, int add_sref, int64_t ncol, int nlev,
+                                                   int ld_out, double *__restrict__ sum, double *__restrict__ mn,
+                                                   double *__restrict__ mx, int first, double *__restrict__ inst)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const double2 *src[4] = {u, v, t, s};
-  if (i < n2) {
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const double2 x = src[f][i];
-      double2 *a = acc + (size_t)f * 3 * n2;
-      double2 sm = a[i], mn = a[n2 + i], mx = a[2 * n2 + i];
-      if (first) { sm = make_double2(0.0, 0.0); mn = x; mx = x; }
-      sm.x = sm.x + x.x; sm.y = sm.y + x.y;
-      mn.x = x.x < mn.x ? x.x : mn.x; mn.y = x.y < mn.y ? x.y : mn.y;
-      mx.x = x.x > mx.x ? x.x : mx.x; mx.y = x.y > mx.y ? x.y : mx.y;
-      a[i] = sm; a[n2 + i] = mn; a[2 * n2 + i] = mx;
-    }
+  if (i >= (size_t)ncol * ld_out) return;
+  const int64_t c = (int64_t)(i / ld_out);
+  const int l = (int)(i - (size_t)c * ld_out);
+  double v = 0.0;
+  if (l < nlev) {
+    v = src[(size_t)c * src_ld + src_off + l];
+    if (add_sref) v = v + cs[(size_t)c * MCKPP_CS + CS_SREF];
   }
-  if (i < (size_t)ncol) {
-    const double h = cs[i * MCKPP_CS + CS_HMIX];
-    double sm = hacc[i], mn = hacc[ncol + i], mx = hacc[2 * (size_t)ncol + i];
-    if (first) { sm = 0.0; mn = h; mx = h; }
-    hacc[i] = sm + h;
-    hacc[ncol + i] = h < mn ? h : mn;
-    hacc[2 * (size_t)ncol + i] = h > mx ? h : mx;
-  }
+  if (inst) { inst[i] = v; return; }
+  double s_ = sum[i], a = mn[i], b = mx[i];
+  if (first) { s_ = 0.0; a = v; b = v; }
+  sum[i] = s_ + v;
+  mn[i] = v < a ? v : a;
+  mx[i] = v > b ? v : b;
 }
 
 __global__ void k_window_mean(const double *__restrict__ sum, double *__restrict__ out, size_t n, double count)
@@ -258,16 +252,14 @@ hipError_t mckpp_launch_bottomtemp(const mckpp_kparams &p, const double *bt, hip
   return hipGetLastError();
 }
 
-hipError_t mckpp_launch_window_accumulate(const double *u, const double *v, const double *t, const double *s,
-                                          double *acc, size_t nelem, const double *cs, double *hacc, int ncol,
-                                          int first, hipStream_t stream)
+hipError_t mckpp_launch_out_sample(const double *src, int src_ld, int src_off, const double *cs, int add_sref,
+                                   int64_t ncol, int nlev, int ld_out, double *sum, double *mn, double *mx, int first,
+                                   double *inst, hipStream_t stream)
 {
-  const size_t n2 = nelem / 2;   // rows are 64*LPL doubles: always even
-  const size_t nthreads = n2 > (size_t)ncol ? n2 : (size_t)ncol;
-  hipLaunchKernelGGL(k_window_accumulate, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream,
-                     reinterpret_cast<const double2 *>(u), reinterpret_cast<const double2 *>(v),
-                     reinterpret_cast<const double2 *>(t), reinterpret_cast<const double2 *>(s),
-                     reinterpret_cast<double2 *>(acc), n2, cs, hacc, ncol, first);
+  const size_t n = (size_t)ncol * ld_out;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_out_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, src_ld, src_off, cs,
+                     add_sref, ncol, nlev, ld_out, sum, mn, mx, first, inst);
   return hipGetLastError();
 }
 

@@ -78,7 +78,9 @@ struct mckpp_hip_ctx {
   double *d_ext_out[O_COUNT] = {};
   double *d_xs = nullptr, *d_adv_d = nullptr, *d_dm = nullptr, *d_hsum = nullptr;
   int *d_adv_i = nullptr;
-  double *d_wacc = nullptr, *d_whacc = nullptr;   // output-window accumulators
+  // output-window reductions: selected MCKPP_OUT_* fields, three accumulators (sum, min, max) each
+  std::vector<int> wsel{0, 1, 2, 3, 4};
+  std::vector<double *> d_wacc;   // [wsel.size()], each 3 * (ncol*ld | ncol) doubles
   int window_count = 0;
   double *d_cs = nullptr;
   int *d_ci = nullptr;
@@ -295,9 +297,8 @@ static void free_state(mckpp_hip_ctx *h)
   h->d_xs = nullptr; h->d_adv_d = nullptr; h->d_adv_i = nullptr;
   if (h->d_series) hipFree(h->d_series);
   h->d_series = nullptr; h->series_nrec = 0;
-  if (h->d_wacc) hipFree(h->d_wacc);
-  if (h->d_whacc) hipFree(h->d_whacc);
-  h->d_wacc = nullptr; h->d_whacc = nullptr; h->window_count = 0;
+  for (auto *p : h->d_wacc) if (p) hipFree(p);
+  h->d_wacc.clear(); h->window_count = 0;
   if (h->d_cs) hipFree(h->d_cs);
   if (h->d_ci) hipFree(h->d_ci);
   if (h->d_ipt) hipFree(h->d_ipt);
@@ -1001,6 +1002,78 @@ int mckpp_hip_update_ancillaries(mckpp_hip_handle h, const mckpp_state_ptrs_c *s
 // ---------------------------------------------------------------------------
 // Output-window reductions
 // ---------------------------------------------------------------------------
+namespace {
+// Where an output field lives on the device.  3-D fields give nzp1 values per column (the vertical axes of
+// src/mckpp_xios_io.F90:96-176: levels 1..nzp1, or interfaces 0..nz for fluxes and diffusivities, whose
+// shifted copies temp_2d(:,1)=0, temp_2d(:,2:NZP1)=dif*(:,1:NZ) are exactly dif*(0:nz)); 2-D fields one.
+struct out_desc { const double *src; int ld, off, nlev, add_sref; };
+
+int out_field(mckpp_hip_ctx *h, int f, out_desc &d)
+{
+  const int nzp1 = h->nzp1;
+  auto prof = [&](int p) { d = {h->d_prof[p], h->ld, 0, nzp1, 0}; return 0; };             // element j <-> level j+1
+  auto diag = [&](int q, int off) { d = {h->d_diag[q], h->ld, off, nzp1, 0}; return 0; };   // element k <-> index k
+  auto corr = [&](int o) {
+    if (!h->d_ext_out[o]) return fail("mckpp_hip_window: field %d needs the correction rows (optional physics or bottomtemp)", f);
+    d = {h->d_ext_out[o], h->ld, 1, nzp1, 0};
+    return 0;
+  };
+  auto scal = [&](int slot) { d = {h->d_cs, MCKPP_CS, slot, 1, 0}; return 0; };
+  switch (f) {
+    case MCKPP_OUT_U: return prof(P_U);
+    case MCKPP_OUT_V: return prof(P_V);
+    case MCKPP_OUT_T: return prof(P_T);
+    case MCKPP_OUT_S_ANOM: return prof(P_S);
+    case MCKPP_OUT_HMIX: return scal(CS_HMIX);
+    case MCKPP_OUT_S: prof(P_S); d.add_sref = 1; return 0;
+    case MCKPP_OUT_B: return diag(D_BUOY, 1);
+    case MCKPP_OUT_WU: return diag(D_WU1, 0);
+    case MCKPP_OUT_WV: return diag(D_WU2, 0);
+    case MCKPP_OUT_WT: return diag(D_WX1, 0);
+    case MCKPP_OUT_WS: return diag(D_WX2, 0);
+    case MCKPP_OUT_WB: return diag(D_WX3, 0);
+    case MCKPP_OUT_WTNT: return diag(D_WXNT1, 0);
+    case MCKPP_OUT_DIFM: return diag(D_DIFM, 0);
+    case MCKPP_OUT_DIFT: return diag(D_DIFT, 0);
+    case MCKPP_OUT_DIFS: return diag(D_DIFS, 0);
+    case MCKPP_OUT_RHO: return diag(D_RHO, 1);
+    case MCKPP_OUT_CP: return diag(D_CP, 1);
+    case MCKPP_OUT_SCORR: return corr(O_SCORR);
+    case MCKPP_OUT_RIG: return diag(D_RIG, 1);
+    case MCKPP_OUT_DBLOC: return diag(D_DBLOC, 1);
+    case MCKPP_OUT_SHSQ: return diag(D_SHSQ, 1);
+    case MCKPP_OUT_TINC_FCORR: return corr(O_TINC);
+    case MCKPP_OUT_FCORR_Z: return corr(O_OCNTCORR);
+    case MCKPP_OUT_SINC_FCORR: return corr(O_SINC);
+    case MCKPP_OUT_FCORR: return scal(CS_FCORR);
+    case MCKPP_OUT_TAUX_IN: return scal(CS_SFLUX1);
+    case MCKPP_OUT_TAUY_IN: return scal(CS_SFLUX2);
+    case MCKPP_OUT_SOLAR_IN: return scal(CS_SFLUX3);
+    case MCKPP_OUT_NSOLAR_IN: return scal(CS_SFLUX4);
+    case MCKPP_OUT_PMINUSE_IN: return scal(CS_SFLUX6);
+    case MCKPP_OUT_FREEZE_FLAG: return scal(CS_FREEZE);
+    case MCKPP_OUT_COMP_FLAG: return scal(CS_RESET);
+    case MCKPP_OUT_DAMPU_FLAG: return scal(CS_DAMPU);
+    case MCKPP_OUT_DAMPV_FLAG: return scal(CS_DAMPV);
+    default: return fail("mckpp_hip_window: unknown output field %d", f);
+  }
+}
+}  // namespace
+
+int mckpp_hip_window_select(mckpp_hip_handle h, const int32_t *fields, int32_t nfields)
+{
+  if (!h || (nfields > 0 && !fields) || nfields < 0) return fail("mckpp_hip_window_select: bad argument");
+  for (int i = 0; i < nfields; ++i)
+    if (fields[i] < 0 || fields[i] >= MCKPP_OUT_COUNT) return fail("mckpp_hip_window_select: unknown output field %d", fields[i]);
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (auto *p : h->d_wacc) if (p) hipFree(p);
+  h->d_wacc.clear();
+  h->wsel.assign(fields, fields + nfields);
+  h->window_count = 0;
+  return 0;
+}
+
 int mckpp_hip_window_reset(mckpp_hip_handle h)
 {
   if (!h) return fail("null handle");
@@ -1013,13 +1086,18 @@ int mckpp_hip_window_accumulate(mckpp_hip_handle h)
   if (!h) return fail("null handle");
   if (h->ncol == 0) return 0;
   HIPCHK(hipSetDevice(h->device));
-  const size_t nelem = (size_t)h->ncol * h->ld;
-  if (!h->d_wacc) {
-    HIPCHK(hipMalloc(&h->d_wacc, 12 * nelem * sizeof(double)));
-    HIPCHK(hipMalloc(&h->d_whacc, 3 * (size_t)h->ncol * sizeof(double)));
+  if (h->d_wacc.size() != h->wsel.size()) h->d_wacc.assign(h->wsel.size(), nullptr);
+  for (size_t i = 0; i < h->wsel.size(); ++i) {
+    out_desc d;
+    if (out_field(h, h->wsel[i], d)) return -1;
+    if ((h->wsel[i] >= MCKPP_OUT_B && h->wsel[i] <= MCKPP_OUT_SINC_FCORR) && !h->diag)
+      return fail("mckpp_hip_window_accumulate: field %d is a diagnostic, and diagnostics are switched off", h->wsel[i]);
+    const int ld_out = d.nlev == 1 ? 1 : h->ld;
+    const size_t n = (size_t)h->ncol * ld_out;
+    if (!h->d_wacc[i]) HIPCHK(hipMalloc(&h->d_wacc[i], 3 * n * sizeof(double)));
+    HIPCHK(mckpp_launch_out_sample(d.src, d.ld, d.off, h->d_cs, d.add_sref, h->ncol, d.nlev, ld_out, h->d_wacc[i],
+                                   h->d_wacc[i] + n, h->d_wacc[i] + 2 * n, h->window_count == 0, nullptr, h->stream));
   }
-  HIPCHK(mckpp_launch_window_accumulate(h->d_prof[P_U], h->d_prof[P_V], h->d_prof[P_T], h->d_prof[P_S], h->d_wacc,
-                                        nelem, h->d_cs, h->d_whacc, (int)h->ncol, h->window_count == 0, h->stream));
   h->window_count += 1;
   return 0;
 }
@@ -1027,31 +1105,35 @@ int mckpp_hip_window_accumulate(mckpp_hip_handle h)
 int mckpp_hip_window_fetch(mckpp_hip_handle h, int field, int op, double *out)
 {
   if (!h || !out) return fail("mckpp_hip_window_fetch: null argument");
-  if (field < 0 || field > 4 || op < 0 || op > 2) return fail("mckpp_hip_window_fetch: field %d / op %d", field, op);
-  if (h->window_count == 0) return fail("mckpp_hip_window_fetch: empty window");
+  if (op < 0 || op > 3) return fail("mckpp_hip_window_fetch: op %d (0 mean, 1 min, 2 max, 3 instant)", op);
+  out_desc d;
+  if (out_field(h, field, d)) return -1;
   if (h->ncol == 0) return 0;
   HIPCHK(hipSetDevice(h->device));
-  const size_t nelem = (size_t)h->ncol * h->ld;
-  if (ensure_stage(h, 2 * nelem + (size_t)h->npts * h->nzp1)) return -1;
-  double *tmp = h->d_stage + (size_t)h->npts * h->nzp1;   // behind the region down_rows stages into
-  if (field < 4) {
-    const double *src = h->d_wacc + ((size_t)field * 3 + op) * nelem;
+  const int ld_out = d.nlev == 1 ? 1 : h->ld;
+  const size_t n = (size_t)h->ncol * ld_out, n3d = (size_t)h->npts * d.nlev;
+  if (ensure_stage(h, n3d + n)) return -1;
+  double *tmp = h->d_stage + n3d;   // behind the region the row scatter stages into
+  const double *src = nullptr;
+  if (op == 3) {   // the field as it stands (XIOS operation "instant" at the output step)
+    HIPCHK(mckpp_launch_out_sample(d.src, d.ld, d.off, h->d_cs, d.add_sref, h->ncol, d.nlev, ld_out, nullptr, nullptr,
+                                   nullptr, 0, tmp, h->stream));
+    src = tmp;
+  } else {
+    size_t i = 0;
+    while (i < h->wsel.size() && h->wsel[i] != field) ++i;
+    if (i == h->wsel.size()) return fail("mckpp_hip_window_fetch: field %d is not among the selected window fields", field);
+    if (h->window_count == 0 || i >= h->d_wacc.size() || !h->d_wacc[i]) return fail("mckpp_hip_window_fetch: empty window");
+    src = h->d_wacc[i] + (size_t)op * n;
     if (op == 0) {
-      HIPCHK(mckpp_launch_window_mean(src, tmp, nelem, (double)h->window_count, h->stream));
+      HIPCHK(mckpp_launch_window_mean(src, tmp, n, (double)h->window_count, h->stream));
       src = tmp;
     }
-    // reuse the row scatter: stage region [0, npts*nzp1) is free, tmp lives behind it
-    const size_t n = (size_t)h->npts * h->nzp1;
-    if (h->ncol < h->npts) HIPCHK(hipMemcpyAsync(h->d_stage, out, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(mckpp_launch_scatter_rows(src, h->ld, 0, h->d_ipt, h->ncol, h->d_stage, h->npts, h->nzp1, 0, h->stream));
-    HIPCHK(hipMemcpyAsync(out, h->d_stage, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-  } else {
-    std::vector<double> hv((size_t)h->ncol);
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(hv.data(), h->d_whacc + (size_t)op * h->ncol, hv.size() * sizeof(double), hipMemcpyDeviceToHost));
-    for (int64_t c = 0; c < h->ncol; ++c) out[h->ipt[c]] = (op == 0) ? hv[c] / (double)h->window_count : hv[c];
   }
+  if (h->ncol < h->npts) HIPCHK(hipMemcpyAsync(h->d_stage, out, n3d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(mckpp_launch_scatter_rows(src, ld_out, 0, h->d_ipt, h->ncol, h->d_stage, h->npts, d.nlev, 0, h->stream));
+  HIPCHK(hipMemcpyAsync(out, h->d_stage, n3d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 

@@ -7,6 +7,16 @@ module mckpp_hip_binding
 
   integer(c_int), parameter :: MCKPP_F_PROFILES = 1, MCKPP_F_SAVED = 2, MCKPP_F_SCALARS = 4, MCKPP_F_DIAG = 8
   integer(c_int), parameter :: MCKPP_F_RESTART = 7, MCKPP_F_ALL = 15
+  ! MCKPP_OUT_* (XIOS field ids, src/mckpp_xios_io.F90:74-210) and the window operations
+  integer(c_int), parameter :: MCKPP_OUT_U = 0, MCKPP_OUT_V = 1, MCKPP_OUT_T = 2, MCKPP_OUT_S_ANOM = 3, MCKPP_OUT_HMIX = 4, &
+    MCKPP_OUT_S = 5, MCKPP_OUT_B = 6, MCKPP_OUT_WU = 7, MCKPP_OUT_WV = 8, MCKPP_OUT_WT = 9, MCKPP_OUT_WS = 10, &
+    MCKPP_OUT_WB = 11, MCKPP_OUT_WTNT = 12, MCKPP_OUT_DIFM = 13, MCKPP_OUT_DIFT = 14, MCKPP_OUT_DIFS = 15, &
+    MCKPP_OUT_RHO = 16, MCKPP_OUT_CP = 17, MCKPP_OUT_SCORR = 18, MCKPP_OUT_RIG = 19, MCKPP_OUT_DBLOC = 20, &
+    MCKPP_OUT_SHSQ = 21, MCKPP_OUT_TINC_FCORR = 22, MCKPP_OUT_FCORR_Z = 23, MCKPP_OUT_SINC_FCORR = 24, &
+    MCKPP_OUT_FCORR = 25, MCKPP_OUT_TAUX_IN = 26, MCKPP_OUT_TAUY_IN = 27, MCKPP_OUT_SOLAR_IN = 28, &
+    MCKPP_OUT_NSOLAR_IN = 29, MCKPP_OUT_PMINUSE_IN = 30, MCKPP_OUT_FREEZE_FLAG = 31, MCKPP_OUT_COMP_FLAG = 32, &
+    MCKPP_OUT_DAMPU_FLAG = 33, MCKPP_OUT_DAMPV_FLAG = 34
+  integer(c_int), parameter :: MCKPP_OP_MEAN = 0, MCKPP_OP_MIN = 1, MCKPP_OP_MAX = 2, MCKPP_OP_INSTANT = 3
 
   type, bind(C) :: mckpp_const_c
     integer(c_int32_t) :: nz, nztmax, nsflxs, njdt, itermax
@@ -229,6 +239,31 @@ module mckpp_hip_binding
       import :: c_int, c_int32_t, c_ptr, c_double
       type(c_ptr), value :: handle
       integer(c_int32_t), value :: field, root
+      real(c_double), intent(inout) :: out(*)
+      integer(c_int) :: rc
+    end function
+    ! ---- output fields with XIOS' temporal operations on the device (MCKPP_OUT_* of include/mckpp_hip.h) ----
+    function mckpp_hip_window_select(handle, fields, nfields) bind(C, name="mckpp_hip_window_select") result(rc)
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int32_t), intent(in) :: fields(*)
+      integer(c_int32_t), value :: nfields
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_window_reset(handle) bind(C, name="mckpp_hip_window_reset") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_window_accumulate(handle) bind(C, name="mckpp_hip_window_accumulate") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_window_fetch(handle, field, op, out) bind(C, name="mckpp_hip_window_fetch") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: handle
+      integer(c_int), value :: field, op
       real(c_double), intent(inout) :: out(*)
       integer(c_int) :: rc
     end function

@@ -414,6 +414,84 @@ def test_output_window_reductions_n4(mk):
         ctx.window_fetch(2, 0, np.zeros((ncol, nz + 1), order="F"))
 
 
+def test_output_fields_as_xios_receives_them(mk):
+    """The field set of mckpp_xios_output_control (src/mckpp_xios_io.F90:74-210: 23 3-D and 11 2-D fields)
+    with the operations of run/iodef.xml:88-157: every field "instant" at an output step, and mean / min /
+    max over a window for a selection that includes diagnostics - against numpy on per-step downloads
+    arranged the way the reference arranges them before xios_send_field (S + Sref, dif*(0:nz), dbloc
+    padded with 0, fluxes on interfaces 0..nz)."""
+    A = mk.api
+    ncol, nz, nsteps = 260, 60, 4
+    nzp1 = nz + 1
+    kc, k3 = cm.make_hip_case(ncol, nz, land_every=5)
+    kc.L_FCORR_WITHZ = 1
+    kc.L_SFCORR_WITHZ = 1
+    kc.L_DAMP_CURR = 1
+    z = np.arange(nzp1)[None, :]
+    k3.fcorr_withz[:, :] = 5.0 * np.exp(-z / 10.0) * np.linspace(-1, 1, ncol)[:, None]
+    k3.sfcorr_withz[:, :] = 1e-7 * np.cos(z / 7.0) * np.ones((ncol, 1))
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    cm.set_forcing_3d(k3, cm.synth.forcing(ncol, "bench"))
+    ctx.set_forcing(k3.sflux)
+    ocean = k3.run_physics != 0
+
+    def as_sent(k3):
+        """name -> array in the layout xios_send_field gets (src/mckpp_xios_io.F90:96-210)"""
+        pad = lambda a: np.concatenate([np.asarray(a), np.zeros((ncol, 1))], axis=1)   # noqa: E731
+        d = {
+            "u": k3.U[:, :, 0], "v": k3.U[:, :, 1], "T": k3.X[:, :, 0], "S_anom": k3.X[:, :, 1],
+            "S": k3.X[:, :, 1] + np.asarray(k3.Sref)[:, None], "B": k3.buoy[:, :nzp1],
+            "wu": k3.wU[:, :nzp1, 0], "wv": k3.wU[:, :nzp1, 1], "wT": k3.wX[:, :nzp1, 0], "wS": k3.wX[:, :nzp1, 1],
+            "wB": k3.wX[:, :nzp1, 2], "wTnt": k3.wXNT[:, :nzp1, 0],
+            "difm": k3.difm[:, :nzp1], "dift": k3.dift[:, :nzp1], "difs": k3.difs[:, :nzp1],
+            "rho": k3.rho[:, 1:nzp1 + 1], "cp": k3.cp[:, 1:nzp1 + 1], "scorr": k3.scorr, "Rig": k3.Rig,
+            "dbloc": pad(k3.dbloc[:, :nz]), "Shsq": k3.Shsq, "tinc_fcorr": k3.tinc_fcorr, "fcorr_z": k3.ocnTcorr,
+            "sinc_fcorr": k3.sinc_fcorr, "hmix": k3.hmix, "fcorr": k3.fcorr,
+            "taux_in": k3.sflux[:, 0, 4, 0], "tauy_in": k3.sflux[:, 1, 4, 0], "solar_in": k3.sflux[:, 2, 4, 0],
+            "nsolar_in": k3.sflux[:, 3, 4, 0], "PminusE_in": k3.sflux[:, 5, 4, 0],
+            "freeze_flag": k3.freeze_flag, "comp_flag": k3.reset_flag, "dampu_flag": k3.dampu_flag, "dampv_flag": k3.dampv_flag,
+        }
+        return {k: np.array(v, dtype=np.float64, copy=True) for k, v in d.items()}
+
+    reduced = ["T", "S", "hmix", "difm", "rho", "wT", "Rig", "dbloc", "tinc_fcorr", "solar_in", "dampu_flag"]
+    ctx.window_select([A.OUT[n] for n in reduced])
+    hist = []
+    for nt in range(1, nsteps + 1):
+        ctx.step(nt, 1)
+        ctx.window_accumulate()
+        ctx.download(k3)
+        hist.append(as_sent(k3))
+        if nt in (2, nsteps):      # an output step: every field, operation "instant"
+            for name in A.OUT_FIELDS:
+                ref = hist[-1][name]
+                out = np.full(ref.shape, -7.0, order="F")
+                ctx.window_fetch(A.OUT[name], A.OP_INSTANT, out)
+                if name in ("Rig", "Shsq"):      # level nzp1 of these is never written by the model
+                    out, ref = out[:, :nz], ref[:, :nz]
+                assert np.array_equal(out[ocean], ref[ocean]), (name, nt)
+                assert np.all(out[~ocean] == -7.0)
+    for name in reduced:
+        stack = np.stack([h_[name] for h_ in hist])
+        shape = stack.shape[1:]
+        for op, red in ((A.OP_MEAN, None), (A.OP_MIN, np.min), (A.OP_MAX, np.max)):
+            out = np.full(shape, -7.0, order="F")
+            ctx.window_fetch(A.OUT[name], op, out)
+            if red is None:
+                acc = np.zeros(shape)
+                for x in stack:
+                    acc = acc + x
+                ref = acc / nsteps
+            else:
+                ref = red(stack, axis=0)
+            if name == "Rig":
+                out, ref = out[:, :nz], ref[:, :nz]
+            assert np.array_equal(out[ocean], ref[ocean]), (name, op)
+    with pytest.raises(mk.MckppHipError, match="not among the selected"):
+        ctx.window_fetch(A.OUT["u"], A.OP_MEAN, np.zeros((ncol, nzp1), order="F"))
+    with pytest.raises(mk.MckppHipError, match="unknown output field"):
+        ctx.window_select([99])
+
+
 def test_config5_terramaris_shape_land_masked(mk):
     """BASELINE configs[4] shape: the shipped namelist's grid (run/3D_ocn.nml:2-4,23: 453 x 319 points,
     nz=69, nztmax=83, dto=1200 s) with a synthetic ~35 % land mask (lsm.nc / kpp_vgrid.nc are not in
