@@ -1053,19 +1053,21 @@ template <int LPL, int W, int MINW, bool EXT = false>
 hipError_t launch_wg(const mckpp_kparams &p, const mckpp_kparams *dp, int nblocks, hipStream_t stream)
 {
   const size_t lds = wg_lds_bytes<LPL, W, EXT>();
-  static bool attr_set = false;
-  if (!attr_set) {
+  // per device (a process may hold contexts on several GPUs): the dynamic-LDS attribute and the occupancy query
+  static bool attr_set[64] = {};
+  static int max_blocks_dev[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_column_wg<LPL, W, MINW, EXT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  static int max_blocks = -1;
-  if (max_blocks < 0) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k_column_wg<LPL, W, MINW, EXT>), 64 * W, lds) != hipSuccess) nb = 0;
-    max_blocks = nb;
+    max_blocks_dev[dev] = nb;
+    attr_set[dev] = true;
   }
+  const int max_blocks = max_blocks_dev[dev];
   g_mckpp_last_launch = {nblocks, 64 * W, max_blocks, lds};
   hipLaunchKernelGGL((k_column_wg<LPL, W, MINW, EXT>), dim3((unsigned)nblocks), dim3(64 * W), lds, stream, dp,
                      p.ntime);

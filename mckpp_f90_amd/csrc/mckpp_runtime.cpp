@@ -189,6 +189,8 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
     return fail("mckpp_hip_init: device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
 
   mckpp_hip_ctx *h = new mckpp_hip_ctx();
+  // any failure below releases what has been created so far (the HIPCHK returns included)
+  struct guard { mckpp_hip_ctx *p; ~guard() { if (p) mckpp_hip_finalize(p); } } g{h};
   h->device = device;
   h->c = *c;
   h->nz = c->nz;
@@ -210,10 +212,9 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   if (const char *kv = getenv("MCKPP_KERNEL")) {
     if (strcmp(kv, "wg") == 0) h->kernel_variant = 2;
     else if (strcmp(kv, "pk") == 0) h->kernel_variant = 4;
-    else { delete h; return fail("mckpp_hip_init: MCKPP_KERNEL=%s (known: wg, pk)", kv); }
+    else return fail("mckpp_hip_init: MCKPP_KERNEL=%s (known: wg, pk)", kv);
   }
   if (h->kernel_variant == 2 && nzp1 + 2 > 64) {
-    delete h;
     return fail("mckpp_hip_init: MCKPP_KERNEL=wg carries columns of up to 61 levels (nz=%d)", c->nz);
   }
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -281,6 +282,7 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   HIPCHK(hipMemcpy(h->d_wtab, wtab.data(), nt * sizeof(double2), hipMemcpyHostToDevice));
   // the host pointers are not kept
   h->c.zm = h->c.hm = h->c.dm = h->c.tri = h->c.wmt = h->c.wst = nullptr;
+  g.p = nullptr;
   *out = h;
   return 0;
 }
@@ -316,6 +318,7 @@ int mckpp_hip_finalize(mckpp_hip_handle h)
   free_state(h);
   hipFree(h->d_zm); hipFree(h->d_hm); hipFree(h->d_tri0); hipFree(h->d_tri1);
   hipFree(h->d_swfrac_tab); hipFree(h->d_swdk_tab); hipFree(h->d_wtab); hipFree(h->d_qhead); hipFree(h->d_params); hipFree(h->d_dm); hipFree(h->d_hsum);
+  if (h->d_dbg) hipFree(h->d_dbg);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->stream) hipStreamDestroy(h->stream);
