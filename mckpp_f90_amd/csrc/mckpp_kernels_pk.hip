@@ -95,7 +95,10 @@ struct strided {   // x[i] of a level-interleaved row
 #endif
 
 template <bool EXT>
-__global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__restrict__ pp, const int ntime, const int L,
+#ifndef MCKPP_PK_MINW
+#define MCKPP_PK_MINW 4
+#endif
+__global__ __launch_bounds__(1024, MCKPP_PK_MINW) void k_column_pk(const mckpp_kparams *__restrict__ pp, const int ntime, const int L,
                                                      const int W)
 {
   const mckpp_kparams &p = *pp;
@@ -463,21 +466,28 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
 
   // =========================== persistent pass loop ===========================
   // p.dbg != nullptr (MCKPP_STAMP=1): wave 0 of every workgroup accumulates shader cycles per segment
-  unsigned long long tlast = p.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
-#define STAMP(i)                                                       \
-  do {                                                                 \
-    if (p.dbg && wv == mgr) {                                            \
-      unsigned long long t_ = __builtin_amdgcn_s_memtime();            \
-      if (lane == 0) atomicAdd(p.dbg + (i), t_ - tlast);               \
-      tlast = t_;                                                      \
-    }                                                                  \
+#ifdef MCKPP_PK_STAMPS   // profiling build: per-segment cycle sums kept in registers by the manager wave
+  unsigned long long tacc[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) tacc[i] = 0;
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#define STAMP(i)                                              \
+  do {                                                        \
+    unsigned long long t_ = __builtin_amdgcn_s_memtime();     \
+    tacc[i] += t_ - tlast;                                    \
+    tlast = t_;                                               \
   } while (0)
+#else
+#define STAMP(i)
+#endif
   if (wv == mgr) M0();
   __syncthreads();
   for (;;) {
     if (!s_flags[0]) break;
     STAMP(22);
-    if (p.dbg && wv == mgr && lane == 0) atomicAdd(p.dbg + 31, 1ull);
+#ifdef MCKPP_PK_STAMPS
+    tacc[23] += 1;
+#endif
     k = k0;
     asm volatile("" : "+v"(k));   // keeps the k-indexed grid-constant LDS reads inside the loop
     const bool active = si[I_ACT] != 0;
@@ -1091,6 +1101,12 @@ __global__ __launch_bounds__(512, 4) void k_column_pk(const mckpp_kparams *__res
     if (wv == mgr) M0();
     __syncthreads();
   }
+#ifdef MCKPP_PK_STAMPS
+  if (p.dbg && wv == mgr && lane == 0) {
+    for (int i = 0; i < 23; ++i) atomicAdd(p.dbg + i, tacc[i]);
+    atomicAdd(p.dbg + 31, tacc[23]);
+  }
+#endif
 #undef STAMP
 }
 
@@ -1123,12 +1139,12 @@ hipError_t mckpp_launch_column_kernel_pk(const mckpp_kparams &p, const mckpp_kpa
 {
   if (p.ncol <= 0) return hipSuccess;
   const int L = p.nzp1 + 2;
-  if (L > 512) return hipErrorInvalidValue;
+  if (L > 1024) return hipErrorInvalidValue;
   const bool ext = p.ext != 0;
   pk_geom g = pk_choose(L, ext, (size_t)160 * 1024);
   if (const char *e = getenv("MCKPP_PK")) {
     int nw = 0, b = 0;
-    if (sscanf(e, "%dx%d", &nw, &b) >= 1 && nw >= 1 && nw <= 8 && (64 * nw) / L >= 1) {
+    if (sscanf(e, "%dx%d", &nw, &b) >= 1 && nw >= 1 && nw <= 16 && (64 * nw) / L >= 1) {
       g.nw = nw;
       g.w = (64 * nw) / L;
       if (g.w > 16) g.w = 16;

@@ -66,31 +66,37 @@ __device__ __forceinline__ void serial_thomas_uts_n(int W, double *slots, int SS
       double *y = base + (R_YU + sys) * RS, *gm = base + (R_GM + sys) * RS;
       double *betm = base + R_BETM * RS, *rbm = base + R_RB * RS;
       int bad = 0;
-      double dm1 = d[(1) * KS], t1m1 = c_t1[(1) * CS];
-      double bet = 1. + t1m1 * dm1;   // cc(1)
-      double ynum = y[(1) * KS];             // y(1) = rhs(1)/bet, formed in the next level's step
-      // One level of the skewed sweep.  The serial wave shares its SIMD with four busy waves, so
-      // the sweep's time is its instruction count: the common case is one straight basic block
-      // (pivot chain bet -> 1/bet -> gam -> bet' interleaved with the solution chain, both on
-      // div_fast), and the two conditions that need other arithmetic - a zero pivot, or a tiny
-      // non-zero solution numerator that div_fast must not see - are detected at the end of the
-      // level before and sent through the slow copy of the step (IEEE sequences), practically never.
+      // The coefficients of tridcof share their products: with p(i) = tri(i,1) diff(i) and q(i) = tri(i,0) diff(i-1)
+      //   cl(i) = -p(i), cu(i) = -q(i), cc(i) = (1 + p(i)) + q(i)      (solvers.F90:28-40, same roundings: a
+      //   negation is exact), so a level forms p and q once; cu*x is -(q*x) exactly, hence cc - cu*gam = cc + q*gam.
+      double dm1 = d[(1) * KS];
+      double pm1 = c_t1[(1) * CS] * dm1;   // p(1)
+      double bet = 1. + pm1;               // cc(1)
+      double ynum = y[(1) * KS];           // y(1) = rhs(1)/bet, formed in the next level's step
+      // One level of the skewed sweep.  The serial wave shares its SIMD with busy waves and issues one
+      // fp64 instruction every ~6 cycles whether or not it depends on the previous one, so the sweep's time
+      // is its instruction count: the common case is one straight basic block (pivot chain bet -> 1/bet ->
+      // gam -> bet' interleaved with the solution chain, both on div_fast), and the two conditions that need
+      // other arithmetic - a zero pivot, or a tiny non-zero solution numerator that div_fast must not see -
+      // are detected at the end of the level before and sent through the slow copy of the step (IEEE
+      // sequences), practically never.
       unsigned long long rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum));   // wave mask, lives in SGPRs
       auto level = [&](int i, double di, double t0, double t1, double rhs, auto slow) {
         if (slow.value && bet == 0.) { bad = 1; bet = 1.E-12; }   // solvers.F90:140-151 would stop here
-        const double clm1 = -t1m1 * dm1;
-        const double cu = -t0 * dm1;
-        const double cc = 1. + t1 * di + t0 * dm1;
+        const double clm1 = -pm1;
+        const double q = t0 * dm1;          // -cu(i)
+        const double p = t1 * di;           // -cl(i)
+        const double cc = (1. + p) + q;
         const double rb = rcp_refine(bet);
         const double g = slow.value ? div_by_refined(clm1, bet, rb) : div_fast(clm1, bet, rb);
         const double yprev = slow.value ? div_by_refined(ynum, bet, rb) : div_fast(ynum, bet, rb);
         if (sys == 0) { betm[(i - 1) * KS] = bet; rbm[(i - 1) * KS] = rb; }
         y[(i - 1) * KS] = yprev;
         gm[(i) * KS] = g;
-        bet = cc - cu * g;
-        ynum = rhs - cu * yprev;
+        bet = cc + q * g;
+        ynum = rhs + q * yprev;
         rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum)) | __builtin_amdgcn_ballot_w64(bet == 0.);
-        dm1 = di; t1m1 = t1;
+        dm1 = di; pm1 = p;
       };
       auto step = [&](int i, double di, double t0, double t1, double rhs) {
         if (__builtin_expect(rare != 0ull, 0)) level(i, di, t0, t1, rhs, std::true_type{});
