@@ -178,7 +178,7 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
     return fail("mckpp_hip_init: iso_bot=%d outside 2..nzp1", c->iso_bot);
   const int nzp1 = c->nz + 1;
   const int lpl = (nzp1 + 2 + 63) / 64;
-  if (lpl > 3) return fail("mckpp_hip_init: nz=%d too deep (max 190 levels)", c->nz);
+  if (lpl > 8) return fail("mckpp_hip_init: nz=%d too deep (max 509 levels: a column takes nzp1+2 of the 512 lanes of a workgroup)", c->nz);
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail("mckpp_hip_init: device %d of %d", device, ndev);

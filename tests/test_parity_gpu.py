@@ -607,6 +607,11 @@ def test_default_kernel_selection(mk, kernel_env):
     kernel_env("v1")
     with pytest.raises(mk.MckppHipError, match="known: wg, pk"):
         mk.MckppHip(kc)
+    kernel_env(None)
+    kc = mk.KppConstFields(510)                      # a column takes nzp1+2 of the 512 lanes of a workgroup
+    mk.mckpp_physics_lookup(kc)
+    with pytest.raises(mk.MckppHipError, match="too deep"):
+        mk.MckppHip(kc)
 
 
 @pytest.mark.parametrize("variant", ["wg", "pk"])
@@ -856,13 +861,14 @@ def test_three_day_diurnal_run_bitexact(mk, nz, grid, nsteps):
 
 
 def test_seeded_sweep_of_shapes_and_forcings(mk, kernel_env):
-    """A seeded sweep over column depths (2 ... 189 levels, including every wave-count boundary),
+    """A seeded sweep over column depths (2 ... 509 levels, including every wave-count boundary),
     grids, time steps, Jerlov types, land masks and randomly perturbed forcing, three steps each on
     whatever kernel the library selects - and the same shape on the other cooperative kernel."""
     from oracle import orc
 
     rng = np.random.default_rng(20261003)
-    depths = [2, 3, 4, 5, 7, 12, 23, 31, 32, 33, 47, 59, 60, 61, 62, 63, 64, 65, 77, 96, 124, 125, 126, 127, 128, 160, 188, 189]
+    depths = [2, 3, 4, 5, 7, 12, 23, 31, 32, 33, 47, 59, 60, 61, 62, 63, 64, 65, 77, 96, 124, 125, 126, 127, 128, 160, 188, 189,
+              190, 255, 300, 509]
     for i, nz in enumerate(depths):
         grid = "stretched" if (i % 3 == 1 and nz >= 10) else "uniform"
         dto = [3600.0, 1200.0, 900.0][i % 3]
