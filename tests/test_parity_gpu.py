@@ -944,11 +944,11 @@ def test_full_size_soak_determinism_and_sample_parity(mk):
     _assert_bitexact(cm.compare(sub, ob, nz, cm.PROFILE_FIELDS + cm.SCALAR_FIELDS + ["hmixd0", "hmixd1"]), "soak sample")
 
 
-@pytest.mark.parametrize("nz,ncol,want", [(60, 20000, 5), (40, 20000, 2), (69, 20000, 2), (100, 20000, 2), (150, 20000, 2)])
+@pytest.mark.parametrize("nz,ncol,want", [(60, 20000, 5), (40, 20000, 2), (69, 20000, 2), (100, 20000, 1), (150, 20000, 2)])
 def test_tuned_residency_is_what_the_device_grants(mk, kernel_env, nz, ncol, want):
     """The cooperative kernels are tuned to a number of resident workgroups per CU (k_column_wg: 5 x 4
     columns at 56..61 levels, <= 96 VGPRs and <= 25 LDS granules of 1,280 B each; k_column_pk: 2 workgroups
-    of 7 or 8 waves at 128 VGPRs).  One more LDS row or a few more registers silently drops a workgroup per
+    of 7 or 8 waves at 128 VGPRs, or one of up to 16 waves where that keeps more columns in flight).  One more LDS row or a few more registers silently drops a workgroup per
     CU (-10 % or worse), so ask the runtime."""
     kernel_env(None)
     kc, k3 = cm.make_hip_case(ncol, nz)

@@ -1,13 +1,15 @@
+# CFGS="60:8x2 69:8x2 100:7x2 60:wg 100:auto": one bench line per entry; <levels>:<MCKPP_PK geometry | wg | auto>
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r02pk
 B="python bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 3"
-if [ -n "$PKTEST" ]; then timeout -k 10 900 python -m pytest tests/test_parity_gpu.py -x -q -m gpu -k "variant or tiny or trap or zero_pivot or uniform_grid or seeded or long_iter" 2>&1 | tail -1; fi
 for cfg in ${CFGS}; do
   nz=${cfg%%:*}; g=${cfg##*:}
   extra=""
-  if [ $nz = 150 ]; then extra="--ncol 50000"; fi
+  if [ $nz -ge 150 ]; then extra="--ncol 50000"; fi
   if [ $g = wg ]; then
-    timeout -k 10 200 $B --nz $nz > gpurun_out/r02pk/b_${nz}_$g.json 2>/dev/null
+    MCKPP_KERNEL=wg timeout -k 10 200 $B --nz $nz > gpurun_out/r02pk/b_${nz}_$g.json 2>/dev/null
+  elif [ $g = auto ]; then
+    MCKPP_KERNEL=pk timeout -k 10 200 $B --nz $nz $extra > gpurun_out/r02pk/b_${nz}_$g.json 2>/dev/null
   else
     MCKPP_KERNEL=pk MCKPP_PK=$g timeout -k 10 200 $B --nz $nz $extra > gpurun_out/r02pk/b_${nz}_$g.json 2>/dev/null
   fi
