@@ -81,6 +81,9 @@ hipError_t mckpp_launch_column_kernel_wg(const mckpp_kparams &p, const mckpp_kpa
 // packed-lane kernel (mckpp_kernels_pk.hip): columns dealt back to back over the workgroup's lanes
 hipError_t mckpp_launch_column_kernel_pk(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu,
                                          hipStream_t stream, mckpp_launch_info *info);
+// packed, stateless-lane kernel (mckpp_kernels_ps.hip): level phases loop over (slot, level) items
+hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu,
+                                         hipStream_t stream, mckpp_launch_info *info);
 hipError_t mckpp_launch_eos_batch(int64_t n, const double *s, const double *t, const double *p,
                                   double *alpha, double *beta, double *sig0, double *cp,
                                   hipStream_t stream);

@@ -1,0 +1,1205 @@
+// mckpp_kernels_ps.hip - packed, stateless-lane cooperative column kernel.
+//
+// k_column_ps (mckpp_kernels_pk.hip) gives every column nzp1+2 lanes for the whole step; its waves are
+// parked at barriers ~80 % of the time waiting for the manager wave's serial phases, and the number of columns
+// in flight on a CU is capped by the wave slots (16 waves at 128 VGPRs).  Here a level lane keeps NOTHING
+// between phases: the iterate (U,V,T,S of the under-relaxation) lives in two L2-resident scratch row sets in
+// HBM (diagnostic rows that are only written when a column finishes), every phase-crossing value in a row
+// of the slot's LDS block.  A level phase is then a loop over work items (slot, level) strided by the
+// workgroup's threads, so a workgroup serves as many slots as LDS holds, whatever its number of waves, and
+// no lane is left over at the end of a column.  Manager phases, LDS layout, arithmetic: as k_column_ps.
+#include "mckpp_sweeps.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace {
+
+using namespace mckpp_dev;
+
+enum { PS_EMPTY = 0, PS_ACTIVE = 1, PS_DONE = 2 };
+enum { F_NONE = 0, F_TRAP = 1, F_FINAL = 2 };
+
+// per-slot double record
+enum {
+  C_B0 = 0, C_B0SOL, C_USTAR, C_UFRAC, C_UCUBE, C_HEK, C_WU01, C_WU02, C_WX01, C_WX02, C_WXNT0, C_UREFNZ, C_VREFNZ,
+  C_RHO0CP0, C_RRC, X_RHO0, X_CP0, X_TALPHA0, X_SBETA0, X_RHOH2O, X_RHOB,
+  C_F, C_HMIXE, C_HMIXN, C_HBL, C_RHBL, C_STABLE, C_BFSFC, C_CASEA,
+  C_GAT1, C_DAT1 = C_GAT1 + 3, C_DKM1 = C_DAT1 + 3,
+  C_SREF = C_DKM1 + 3, C_SSURF, C_OCDEPTH, C_SFLUX1, C_SFLUX2, C_SFLUX3, C_SFLUX4, C_SFLUX5, C_SFLUX6,
+  C_T1X /* + parity: the level-1 temperature of the iterate, for the two EOS items */, C_COUNT = C_T1X + 2
+};
+// per-slot int record
+enum {
+  I_STATE = 0, I_ACT, I_COL, I_OLD, I_NEW, I_JER, I_INITFLAG, I_STATUS, I_NPASS, I_NPASS_TRY, I_ICONV, I_COMP, I_KMIXN,
+  I_KBL, I_NRESET, I_FIN, I_MAYBE, I_LOAD /* 1: new column, 2: restart the iteration (trap retry) */, I_JU,
+  I_KBLC, I_NVIOL, I_NU, I_NV, I_NF, I_BAD, I_LOCEAN, I_PAR /* scratch set holding the iterate */, I_COUNT
+};
+enum { R_RHO = R_COUNT, R_CP, R_X1, R_X2, R_COUNT_EXT };   // rho, cp, alphaDT, betaDS rows of the optional-physics build
+// Row aliases of this kernel (what a row holds between which phases):
+//   R_YU/R_YV/R_YS  previous solution until L1 has relaxed, then U, V, buoyancy of the iterate (L1..L6/L7)
+//   R_YT            previous temperature solution (the two EOS items read yT(1) in L1: nothing is written to it
+//                   there), hmin candidates L4..M3, right-hand side from L6
+//   R_GM/R_GT/R_GS  Rig, dbloc, Monin-Obukhov depth L2..L4; gam of the sweeps; rmsd terms in the trap
+//   R_DT/R_DS       Ritop, dVsq L2..L3, then diffusivities;  R_DM  LDD talpha L1..L2, then difm
+//   R_RB            LDD sbeta L1..L2, bulk Ri L3..L4, refined 1/bet from the U sweep; rmsd term in the trap
+//   R_BETM          T for LDD L1..L2, bet from the U sweep;  R_GH  LDD S L1..L2, then ghat
+enum { R_PV = R_YV, R_RAW = R_RB, R_H = R_YT, R_LA = R_DM, R_RITOP = R_DT, R_DVSQ = R_DS };
+
+// LDS layout.  A slot's rows are interleaved per level: element (row a, level i) sits at i*ROWS + a
+// doubles, so a level lane reaches all its rows and the rows of its neighbours through ONE base register
+// plus immediate offsets (the column depth, hence any row-major row length, is a run-time value).  ROWS is
+// odd (13 / 15): 32 consecutive levels fall on 32 distinct banks.  The grid constants are interleaved the
+// same way with a stride of 7.  Host and device agree on the sizes through these:
+enum { K_ZM = 0, K_HM, K_T0, K_T1, K_RDZ, K_DTOHK, K_STRIDE = 7 };
+__host__ __device__ inline int ps_rows(bool ext) { return ext ? (int)R_COUNT_EXT : (int)R_COUNT; }
+__host__ __device__ inline int ps_nl(int L) { return L + 2; }   // level indices 0..L+1
+__host__ __device__ inline int ps_ss(int L, bool ext)
+{
+  // lane (slot s, system m) of the serial sweeps touches s*SS + i*ROWS + m: with SS = 3 (mod 32 doubles)
+  // up to ten slots x three systems fall on distinct banks
+  int s = ps_rows(ext) * ps_nl(L);
+  while ((s & 31) != 3) ++s;
+  return s;
+}
+__host__ __device__ inline size_t ps_lds_bytes(int L, int W, bool ext)
+{
+  return (size_t)(K_STRIDE * ps_nl(L) + 2 + W * ps_ss(L, ext) + W * C_COUNT) * sizeof(double) +
+         (size_t)(W * I_COUNT + 4 + 8) * sizeof(int);
+}
+
+#ifndef MCKPP_PS_MGR_SIMD
+#define MCKPP_PS_MGR_SIMD -1
+#endif
+
+template <int KS>
+struct strided {   // x[i] of a level-interleaved row
+  double *b;
+  __device__ __forceinline__ double &operator[](int i) const { return b[i * KS]; }
+};
+
+// the manager wave's serial phases are what the other waves of the workgroup wait for
+#ifndef MCKPP_PS_PRIO   // measured: raising the manager wave's priority costs 3 % (its phases are latency-, not issue-bound)
+#define PRIO_HI()
+#define PRIO_LO()
+#else
+#define PRIO_HI() __builtin_amdgcn_s_setprio(3)
+#define PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#endif
+
+template <bool EXT>
+#ifndef MCKPP_PS_MINW
+#define MCKPP_PS_MINW 4
+#endif
+__global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_kparams *__restrict__ pp, const int ntime, const int L,
+                                                     const int W, const unsigned Lmagic)
+{
+  const mckpp_kparams &p = *pp;
+  extern __shared__ double lds[];
+  constexpr int ROWS = EXT ? (int)R_COUNT_EXT : (int)R_COUNT;
+  const int NL = ps_nl(L), SS = ps_ss(L, EXT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nz = p.nz, nzp1 = p.nzp1;
+  double *cst = lds;
+  const strided<K_STRIDE> c_zm{cst + K_ZM}, c_hm{cst + K_HM}, c_t0{cst + K_T0}, c_t1{cst + K_T1}, c_rdz{cst + K_RDZ},
+      c_dtohk{cst + K_DTOHK};
+  double *c_misc = lds + K_STRIDE * NL;
+  double *slots = c_misc + 2;
+  double *screc = slots + W * SS;
+  int *sirec = reinterpret_cast<int *>(screc + W * C_COUNT);
+  int *s_flags = sirec + W * I_COUNT;   // [0] some slot active, [1] some slot finishing
+
+  for (int i = tid; i < NL; i += blockDim.x) {
+    c_zm[i] = p.zm[i];
+    c_hm[i] = p.hm[i];
+    c_t0[i] = p.tri0[i];
+    c_t1[i] = p.tri1[i];
+    c_rdz[i] = rcp_refine(p.zm[i] - p.zm[i + 1]);
+    c_dtohk[i] = p.dto / p.hm[i];
+  }
+  if (tid == 0) { c_misc[0] = rcp_refine(p.hm[1]); c_misc[1] = rcp_refine(p.vonk); }
+  for (int i = tid; i < W * I_COUNT; i += blockDim.x) sirec[i] = 0;   // every slot PS_EMPTY
+  if (tid < 4) s_flags[tid] = 0;
+  // The manager is wave 0.  (Experiment kept behind MCKPP_PS_MGR_SIMD >= 0: electing the wave that sits on a
+  // given SIMD, so that the serial chains of all workgroups of a CU share one SIMD - measured 0.8-0.9x; one
+  // SIMD per workgroup chosen from blockIdx - 0.97x.  Raising the manager's s_setprio: 0.97x.)
+  int mgr = 0;
+#if MCKPP_PS_MGR_SIMD >= 0
+  {
+    int *s_simd = s_flags + 4;   // [8] SIMD id per wave
+    const int simd = (__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4) & 3);   // HW_REG_HW_ID bits 5:4
+    if (lane == 0) s_simd[wv] = simd;
+    __syncthreads();
+    const int nwv = blockDim.x >> 6;
+    mgr = -1;
+    for (int w = 0; w < nwv; ++w)
+      if (mgr < 0 && s_simd[w] == MCKPP_PS_MGR_SIMD) mgr = w;
+    if (mgr < 0) mgr = 0;
+    mgr = __builtin_amdgcn_readfirstlane(mgr);
+  }
+#endif
+
+  // ---- work items (slot, level) ------------------------------------------------
+  const int nthreads = blockDim.x, nitems = W * L;
+  __syncthreads();
+
+  const double lambda = 0.5;
+  const double epsln16 = 1.e-16, Ricr = 0.30, eps01 = 0.1, cekman = 0.7, cmonob = 1.0, epsln20 = 1.e-20;
+  const bool do_ocnint = p.mode == MCKPP_MODE_STEP || p.mode == MCKPP_MODE_PASS;
+  const bool flux_diag = p.mode == MCKPP_MODE_STEP || p.mode == MCKPP_MODE_INIT;   // wU, wX(1:nz) of ocnstep / initialize_ocean
+  // the iterate of the under-relaxation between passes: two sets of scratch rows (diagnostic rows that only
+  // a finishing column writes, element index = level-1), read from one set and written to the other
+  double *const xU[2] = {p.wU1, p.difm}, *const xV[2] = {p.wU2, p.difs}, *const xT[2] = {p.wX1, p.dift},
+                *const xS[2] = {p.wX2, p.ghat};
+
+// one level-parallel phase: every active (slot, level) item, strided by the workgroup's threads
+#define FOR_ITEMS                                                                         \
+  for (int it_ = tid; it_ < nitems; it_ += nthreads) {                                    \
+    const int slot = (int)__umulhi((unsigned)it_, Lmagic);                                \
+    const int k = it_ - slot * L + 1;                                                     \
+    int *const si = sirec + slot * I_COUNT;                                               \
+    if (!si[I_ACT]) continue;                                                             \
+    double *const my = slots + slot * SS;                                                 \
+    double *const sc = screc + slot * C_COUNT;                                            \
+    const int col = si[I_COL];                                                            \
+    const bool act = k <= nzp1, actz = k <= nz, virt1 = k == nzp1 + 1, virt2 = k == nzp1 + 2; \
+    const bool is1 = k == 1, isnz = k == nz, isnzp1 = k == nzp1;                          \
+    const int kr = act ? k : 1;                                                           \
+    const size_t ro = (size_t)col * p.ld;                                                 \
+    auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };             \
+    (void)sc; (void)actz; (void)virt1; (void)virt2; (void)is1; (void)isnz; (void)isnzp1; (void)kr; (void)ro;
+#define END_ITEMS }
+
+  // =========================== manager phases (wave 0) ===========================
+  // M0: slots whose column has finished pull the next one from the queue (refill of k_column_wg)
+  auto M0 = [&]() {
+    bool a = false;
+    if (lane < W) {
+      int *msi = sirec + lane * I_COUNT;
+      double *msc = screc + lane * C_COUNT;
+      int st = msi[I_STATE];
+      if (st == PS_ACTIVE && msi[I_FIN] == F_FINAL) st = PS_EMPTY;   // its outputs are stored (barrier before M0)
+      if (st == PS_EMPTY) {
+        const int c = atomicAdd(p.qhead, 1);
+        msi[I_FIN] = F_NONE;
+        if (c >= p.ncol) {
+          st = PS_DONE;
+          msi[I_ACT] = 0;
+        } else {
+          st = PS_ACTIVE;
+          const int *ci = p.ci + (size_t)c * MCKPP_CI;
+          const double *cs = p.cs + (size_t)c * MCKPP_CS;
+          int old = ci[CI_OLD], newi = ci[CI_NEW], status = 0;
+          if (old < 0 || old > 1) { old = newi; status |= 16; }
+          if (newi < 0 || newi > 1) { newi = old; status |= 16; }
+          msi[I_ACT] = 1; msi[I_COL] = c; msi[I_OLD] = old; msi[I_NEW] = newi; msi[I_JER] = ci[CI_JERLOV];
+          msi[I_INITFLAG] = (p.mode == MCKPP_MODE_INIT) ? 1 : ci[CI_INITFLAG];   // initialize_ocean.F90:59
+          msi[I_LOCEAN] = ci[CI_LOCEAN];
+          msi[I_STATUS] = status; msi[I_NPASS] = 0; msi[I_NPASS_TRY] = 0; msi[I_ICONV] = 0; msi[I_COMP] = 1;
+          msi[I_NRESET] = 0; msi[I_KMIXN] = 0; msi[I_KBL] = 0; msi[I_LOAD] = 1; msi[I_BAD] = 0;
+          msi[I_MAYBE] = (p.mode != MCKPP_MODE_STEP) ? 1 : 0;
+          msi[I_KBLC] = 0x7fffffff; msi[I_NVIOL] = 0; msi[I_NU] = 0; msi[I_NV] = 0; msi[I_NF] = 0; msi[I_PAR] = 0;
+          msc[C_F] = cs[CS_F]; msc[C_WXNT0] = 0.0; msc[C_HMIXE] = 0.0; msc[C_HMIXN] = 0.0;
+          msc[C_SREF] = cs[CS_SREF]; msc[C_SSURF] = cs[CS_SSURF]; msc[C_OCDEPTH] = cs[CS_OCDEPTH];
+          msc[C_SFLUX1] = cs[CS_SFLUX1]; msc[C_SFLUX2] = cs[CS_SFLUX2]; msc[C_SFLUX3] = cs[CS_SFLUX3];
+          msc[C_SFLUX4] = cs[CS_SFLUX4]; msc[C_SFLUX5] = cs[CS_SFLUX5]; msc[C_SFLUX6] = cs[CS_SFLUX6];
+        }
+        msi[I_STATE] = st;
+      }
+      a = st == PS_ACTIVE;
+    }
+    const unsigned long long m = __ballot(a);
+    if (lane == 0) { s_flags[0] = m != 0ull ? 1 : 0; s_flags[1] = 0; }
+  };
+
+  // M1: surface fluxes and friction velocity (verticalmixing_mod.F90:81-100), wXNT(0) (fluxes_mod.F90:110-116)
+  auto M1 = [&]() {
+    if (lane < W) {
+      int *msi = sirec + lane * I_COUNT;
+      double *msc = screc + lane * C_COUNT;
+      if (msi[I_ACT]) {
+        msi[I_LOAD] = 0;
+        msi[I_PAR] = msi[I_PAR] ^ 1;   // L1 has just written the other scratch set
+        const double rho0 = msc[X_RHO0], cp0 = msc[X_CP0], talpha0 = msc[X_TALPHA0], sbeta0 = msc[X_SBETA0];
+        const double rhoh2o = msc[X_RHOH2O], rhob = msc[X_RHOB];
+        const double sflux1 = msc[C_SFLUX1], sflux2 = msc[C_SFLUX2], sflux3 = msc[C_SFLUX3], sflux4 = msc[C_SFLUX4],
+                     sflux5 = msc[C_SFLUX5], sflux6 = msc[C_SFLUX6];
+        const double Ssurf = msc[C_SSURF];
+        const double r_rho0 = rcp_refine(rho0), rho0cp0 = rho0 * cp0, r_rc = rcp_refine(rho0cp0);
+        const double wU0_1 = div_fast(-sflux1, rho0, r_rho0);
+        const double wU0_2 = div_fast(-sflux2, rho0, r_rho0);
+        const double tau = __builtin_sqrt(sflux1 * sflux1 + sflux2 * sflux2) + 1.e-16;
+        const double ustar = __builtin_sqrt(div_fast(tau, rho0, r_rho0));
+        const double wX0_1 = div_fast(div_fast(-sflux4, rho0, r_rho0), cp0, rcp_refine(cp0));
+        const double wX0_2 = div_fast(Ssurf * sflux6, rhoh2o, rcp_refine(rhoh2o)) +
+                             div_fast((Ssurf - p.sice) * sflux5, rhob, rcp_refine(rhob));
+        const double B0 = -p.grav * (talpha0 * wX0_1 - sbeta0 * wX0_2);
+        const double B0sol = div_fast(p.grav * talpha0 * sflux3, rho0cp0, r_rc);
+        const wscale_u wu = wscale_prepare(ustar);
+        const double fa = __builtin_fabs(msc[C_F]) + epsln16;
+        msc[C_B0] = B0; msc[C_B0SOL] = B0sol; msc[C_USTAR] = ustar; msc[C_UFRAC] = wu.ufrac; msc[C_UCUBE] = wu.ucube;
+        msi[I_JU] = wu.ju;
+        msc[C_HEK] = div_fast(cekman * ustar, fa, rcp_refine(fa));   // Ekman depth scale, bldepth_mod.F90:158
+        msc[C_WU01] = wU0_1; msc[C_WU02] = wU0_2; msc[C_WX01] = wX0_1; msc[C_WX02] = wX0_2;
+        msc[C_RHO0CP0] = rho0cp0; msc[C_RRC] = r_rc;
+        if (ntime >= 1) msc[C_WXNT0] = div_fast(-sflux3 * p.swdk_tab[msi[I_JER] * p.ldc], rho0cp0, r_rc);
+      }
+    }
+  };
+
+  // M3: boundary-layer depth from the first level with hmin < -zm(k) (bldepth_mod.F90:161-201) and the
+  //     slot-uniform part of blmix (blmix_mod.F90:62-100, 136-149)
+  auto M3 = [&]() {
+    if (lane < W) {
+      int *msi = sirec + lane * I_COUNT;
+      double *msc = screc + lane * C_COUNT;
+      if (msi[I_ACT]) {
+        double *mrow = slots + lane * SS;
+        const int kc = msi[I_KBLC];
+        msi[I_KBLC] = 0x7fffffff;
+        int kbl = nz;
+        double hbl = -c_zm[nz];
+        if (kc <= nz) { kbl = kc; hbl = mrow[kc * ROWS + R_H]; }
+        msi[I_KBL] = kbl;
+        msc[C_HBL] = hbl;
+        const int jer = msi[I_JER];
+        const double B0 = msc[C_B0], B0sol = msc[C_B0SOL], ustar = msc[C_USTAR];
+        wscale_u wu;
+        wu.ju = msi[I_JU]; wu.ufrac = msc[C_UFRAC]; wu.ustar = ustar; wu.ucube = msc[C_UCUBE];
+        double bfsfc = swfrac_dev(-1.0, hbl, jer);
+        bfsfc = B0 + B0sol * (1. - bfsfc);
+        const double stable = 0.5 + dsign(0.5, bfsfc);
+        bfsfc = bfsfc + stable * epsln16;
+        const double caseA = 0.5 + dsign(0.5, -c_zm[kbl] - 0.5 * c_hm[kbl] - hbl);
+        double gat1[3], dat1[3];
+        const double r_hbl = rcp_refine(hbl);
+        {
+          double wm, ws;
+          double sigma = stable * 1.0 + (1. - stable) * eps01;
+          wscale_dev(p, wu, sigma, hbl, bfsfc, wm, ws);
+          int ifx = (int)(caseA + epsln20);
+          int kn = ifx * (kbl - 1) + (1 - ifx) * kbl;
+          double hmkn = c_hm[kn], hmkn1 = c_hm[kn + 1];
+          const double r_hmkn = rcp_refine(hmkn), r_hmkn1 = rcp_refine(hmkn1);
+          double delhat = 0.5 * hmkn - c_zm[kn] - hbl;
+          double R = 1.0 - div_fast(delhat, hmkn, r_hmkn);
+          const strided<ROWS> dd[3] = {{mrow + R_DM}, {mrow + R_DS}, {mrow + R_DT}};
+          double dp[3], dh[3];
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            double dvdzup = div_fast(dd[m][kn - 1] - dd[m][kn], hmkn, r_hmkn);
+            double dvdzdn = div_fast(dd[m][kn] - dd[m][kn + 1], hmkn1, r_hmkn1);
+            dp[m] = 0.5 * ((1. - R) * (dvdzup + __builtin_fabs(dvdzup)) + R * (dvdzdn + __builtin_fabs(dvdzdn)));
+            dh[m] = dd[m][kn] + dp[m] * delhat;
+          }
+          double u4 = ((ustar * ustar) * ustar) * ustar;
+          const double u4e = u4 + epsln20, wme = wm + epsln20, wse = ws + epsln20;
+          const double r_wme = rcp_refine(wme), r_wse = rcp_refine(wse);
+          double f1 = div_fast(stable * 5.0 * bfsfc, u4e, rcp_refine(u4e));
+          gat1[0] = div_fast(div_fast(dh[0], hbl, r_hbl), wme, r_wme);
+          dat1[0] = div_fast(-dp[0], wme, r_wme) + f1 * dh[0];
+          dat1[0] = dmin2(dat1[0], 0.);
+          gat1[1] = div_fast(div_fast(dh[1], hbl, r_hbl), wse, r_wse);
+          dat1[1] = div_fast(-dp[1], wse, r_wse) + f1 * dh[1];
+          dat1[1] = dmin2(dat1[1], 0.);
+          gat1[2] = div_fast(div_fast(dh[2], hbl, r_hbl), wse, r_wse);
+          dat1[2] = div_fast(-dp[2], wse, r_wse) + f1 * dh[2];
+          dat1[2] = dmin2(dat1[2], 0.);
+        }
+        {
+          double wm, ws;
+          double sig = div_fast(-c_zm[kbl - 1], hbl, r_hbl);
+          double sigma = stable * sig + (1. - stable) * dmin2(sig, eps01);
+          wscale_dev(p, wu, sigma, hbl, bfsfc, wm, ws);
+          double a1 = sig - 2.;
+          double a2 = 3. - 2. * sig;
+          double a3 = sig - 1.;
+          double Gm = a1 + a2 * gat1[0] + a3 * dat1[0];
+          double Gs = a1 + a2 * gat1[1] + a3 * dat1[1];
+          double Gt = a1 + a2 * gat1[2] + a3 * dat1[2];
+          msc[C_DKM1 + 0] = hbl * wm * sig * (1. + sig * Gm);
+          msc[C_DKM1 + 1] = hbl * ws * sig * (1. + sig * Gs);
+          msc[C_DKM1 + 2] = hbl * ws * sig * (1. + sig * Gt);
+        }
+        msc[C_RHBL] = r_hbl; msc[C_STABLE] = stable; msc[C_BFSFC] = bfsfc; msc[C_CASEA] = caseA;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { msc[C_GAT1 + m] = gat1[m]; msc[C_DAT1 + m] = dat1[m]; }
+      }
+    }
+  };
+
+  // G: ocnstep control after a pass (ocnstep_mod.F90:122-192), one lane per slot
+  auto G = [&]() {
+    bool f_any = false;
+    if (lane < W) {
+      int *msi = sirec + lane * I_COUNT;
+      double *msc = screc + lane * C_COUNT;
+      if (msi[I_ACT]) {
+        int fin = F_NONE;
+        int status = msi[I_STATUS], npass_try = msi[I_NPASS_TRY], iconv = msi[I_ICONV];
+        if (p.mode != MCKPP_MODE_INIT && msi[I_BAD]) status |= 1;
+        msi[I_BAD] = 0;
+        msi[I_NPASS] = msi[I_NPASS] + 1;
+        if (p.mode != MCKPP_MODE_STEP) {
+          fin = F_FINAL;
+        } else {
+          ++npass_try;
+          const double hbl = msc[C_HBL];
+          if (npass_try <= 3) {   // compulsory passes
+            msc[C_HMIXE] = hbl;
+          } else {
+            const double hmixn = hbl, hmixe = msc[C_HMIXE];
+            const int kmixn = msi[I_KBL];
+            msc[C_HMIXN] = hmixn;
+            msi[I_KMIXN] = kmixn;
+            double tol = p.hmixtolfrac * c_hm[kmixn];
+            if (kmixn == nzp1) tol = p.hmixtolfrac * c_hm[nz];
+            if (__builtin_fabs(hmixn - hmixe) > tol) iconv = 0;
+            else iconv = iconv + 1;
+            bool go_on = false;
+            if (iconv < 3) {
+              if (npass_try < p.itermax) { msc[C_HMIXE] = hmixn; go_on = true; }
+              else if (hmixn > hmixe) { msc[C_HMIXE] = hmixn; go_on = true; }
+            }
+            if (!go_on) {
+              if (npass_try > (p.itermax + 1)) status |= 2;
+              fin = F_TRAP;
+              msi[I_NVIOL] = 0;
+            }
+          }
+          msi[I_MAYBE] = (npass_try >= 3 && (iconv >= 2 || npass_try + 1 >= p.itermax)) ? 1 : 0;
+        }
+        msi[I_STATUS] = status; msi[I_NPASS_TRY] = npass_try; msi[I_ICONV] = iconv;
+        msi[I_FIN] = fin;
+        f_any = fin != F_NONE;
+      }
+    }
+    const unsigned long long m = __ballot(f_any);
+    if (lane == 0) s_flags[1] = m != 0ull ? 1 : 0;
+  };
+
+  // ---- optional terms of the T and S right-hand sides (ocnint_mod.F90:97-215), level k of item (my, si, col):
+  // relaxation / flux corrections / prescribed advection (rhsmod, solvers.F90:176-335, salinity only)
+  auto ext_rhs = [&](double *my, const int *si, int col, int k, int kmixe, double To_k, double So_k, double &rhsT,
+                     double &rhsS) {
+    const double dto = p.dto;
+    const double *xs = p.xs + (size_t)col * MCKPP_XS;
+    const double rhok = my[k * ROWS + R_RHO], cpk = my[k * ROWS + R_CP];
+    const size_t oin = (size_t)col * p.ld + (k - 1);
+    if (k == 1) {
+      if (p.L_RELAX_SST && !p.L_FCORR_WITHZ && !p.L_FCORR) {   // :97-114
+        const double relax_sst = xs[XS_RELAX_SST], SST0 = xs[XS_SST0];
+        double fc = 0.0;
+        if (relax_sst > 1.e-10) {
+          if (!p.L_RELAX_CALCONLY) rhsT = rhsT + dto * relax_sst * (SST0 - To_k) * p.dm[kmixe] / c_hm[1];
+          fc = relax_sst * (SST0 - To_k) * p.dm[kmixe] * rhok * cpk;
+        }
+        p.cs[(size_t)col * MCKPP_CS + CS_FCORR] = fc;
+      }
+      if (p.L_FCORR && !p.L_RELAX_SST && !p.L_FCORR_WITHZ)     // :121-125
+        rhsT = rhsT + dto * xs[XS_FCORR_TWOD] / (rhok * cpk * c_hm[1]);
+    }
+    double tinc = 0.;                                           // :133-160
+    if (p.L_FCORR_WITHZ && !p.L_FCORR) tinc = dto * p.fcorr_withz[oin] / (rhok * cpk);
+    if (p.L_RELAX_OCNT) tinc = tinc + dto * xs[XS_RELAX_OCNT] * (p.ocnT_clim[oin] - To_k);
+    rhsT = rhsT + tinc;
+    const double ocnTcorr = tinc * rhok * cpk / dto;
+    // prescribed advection of salinity, rhsmod with jsclr = 2 (:179-184)
+    const int *ai = p.adv_i + (size_t)col * (p.maxmodeadv + 1);
+    const double *ad = p.adv_d + (size_t)col * (p.maxmodeadv + 1);
+    const int nmode = ai[0];
+    const int nzi = nz, km = kmixe;
+    for (int im = 0; im < nmode; ++im) {
+      const int mode = ai[1 + im];
+      if (mode <= 0) continue;
+      const double fact = dto * ad[im] * 0.033;
+      if (mode == 1) {
+        if (k == 1) rhsS = rhsS + fact / c_hm[1];
+      } else if (mode == 2) {
+        const double delta = p.hsum[km - 1];
+        if (k <= km - 1) rhsS = rhsS + fact / delta;
+      } else if (mode == 3) {
+        const double delta = p.hsum[nzi];
+        if (k <= nzi) rhsS = rhsS + fact / delta;
+      } else if (mode == 4) {
+        const int nzend = nzi - 1;
+        int n1 = 0;
+        do { n1 = n1 + 1; } while (c_zm[n1] >= -100. && n1 < nzp1);
+        double delta = 0.0;
+        for (int n = n1; n <= nzend; ++n) delta = delta + c_hm[n];
+        if (k >= n1 && k <= nzend) rhsS = rhsS + fact / delta;
+      } else if (mode == 5) {
+        if (k == nzi) rhsS = rhsS + fact / c_hm[nzi];
+      } else if (mode == 6 || mode == 7) {
+        int n1, n2 = 0;
+        double depth, dmax, delta = 0.0;
+        if (mode == 6) { n1 = 1; depth = c_hm[1]; dmax = p.dm[km] - 0.5 * (c_hm[km] + c_hm[km - 1]); }
+        else { n1 = km - 1; depth = p.dm[km] - 0.5 * c_hm[km]; dmax = 100.; }
+        for (int n = n1; n <= nzi; ++n) {
+          n2 = n;
+          delta = delta + c_hm[n];
+          depth = depth + c_hm[n + 1];
+          if (depth >= dmax) break;
+        }
+        if (k >= n1 && k <= n2) rhsS = rhsS + fact / delta;
+      }
+    }
+    double sinc = 0.;                                           // :187-213
+    if (p.L_SFCORR_WITHZ && !p.L_SFCORR) sinc = dto * p.sfcorr_withz[oin];
+    if (p.L_RELAX_SAL) sinc = sinc + dto * xs[XS_RELAX_SAL] * (p.sal_clim[oin] - So_k);
+    rhsS = rhsS + sinc;
+    // tinc_fcorr of the latest pass is what check_profile adds to (overrides.F90:87-88): always stored
+    const size_t o = (size_t)col * p.ld + k;
+    p.tinc_fcorr[o] = tinc;
+    if (si[I_MAYBE]) { p.ocnTcorr[o] = ocnTcorr; p.sinc_fcorr[o] = sinc; p.scorr[o] = sinc / dto; }
+  };
+
+  // =========================== persistent pass loop ===========================
+#ifdef MCKPP_PS_STAMPS   // profiling build: per-segment cycle sums kept in registers by the manager wave
+  unsigned long long tacc[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) tacc[i] = 0;
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#define STAMP(i)                                              \
+  do {                                                        \
+    unsigned long long t_ = __builtin_amdgcn_s_memtime();     \
+    tacc[i] += t_ - tlast;                                    \
+    tlast = t_;                                               \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+  if (wv == mgr) M0();
+  __syncthreads();
+  for (;;) {
+    if (!s_flags[0]) break;
+    STAMP(22);
+#ifdef MCKPP_PS_STAMPS
+    tacc[23] += 1;
+#endif
+
+    // ---- L1: (new column / retry: ocnstep_mod.F90:91-112 extrapolation) under-relaxation, equation of state
+    FOR_ITEMS
+      const int ldf = si[I_LOAD], par = si[I_PAR];
+      const size_t o = ro + (kr - 1);
+      double U = 0, V = 0, T = 0, S = 0;
+      if (p.mode == MCKPP_MODE_STEP) {
+        double yu, yv, yt, ys;
+        if (ldf != 0) {   // the relaxation memory equals the new iterate (Ux = U, ocnstep_mod.F90:105,110)
+          const int old = si[I_OLD], newi = si[I_NEW];
+          const double uo = act ? p.Us[old][o] : 0.0, un = act ? p.Us[newi][o] : 0.0;
+          const double vo = act ? p.Vs[old][o] : 0.0, vn = act ? p.Vs[newi][o] : 0.0;
+          const double to = p.Ts[old][o], tn = p.Ts[newi][o];
+          const double so = act ? p.Ss[old][o] : 0.0, sn = act ? p.Ss[newi][o] : 0.0;
+          U = 2. * un - uo;
+          V = 2. * vn - vo;
+          T = 2. * tn - to;
+          S = 2. * sn - so;
+          yu = U; yv = V; yt = T; ys = S;
+        } else {
+          U = act ? xU[par][o] : 0.0; V = act ? xV[par][o] : 0.0; S = act ? xS[par][o] : 0.0;
+          T = act ? xT[par][o] : sc[C_T1X + par];   // scratch rows are read back by the thread that wrote them only
+          yu = row(R_YU)[k]; yv = row(R_YV)[k]; yt = row(R_YT)[kr]; ys = row(R_YS)[k];
+        }
+        // under-relaxation, ocnstep_mod.F90:123-132 / :142-151 (an EOS item follows level 1's temperature)
+        T = lambda * T + (1 - lambda) * yt;
+        if (act) {
+          U = lambda * U + (1 - lambda) * yu;
+          V = lambda * V + (1 - lambda) * yv;
+          S = lambda * S + (1 - lambda) * ys;
+          xU[par ^ 1][o] = U; xV[par ^ 1][o] = V; xT[par ^ 1][o] = T; xS[par ^ 1][o] = S;
+          if (is1) sc[C_T1X + (par ^ 1)] = T;
+        }
+      } else {
+        U = act ? p.U[o] : 0.0; V = act ? p.V[o] : 0.0; T = p.T[o]; S = act ? p.S[o] : 0.0;
+      }
+      const double Sref = sc[C_SREF];
+      const double zm1 = c_zm[1];
+      const double zmk = c_zm[k];
+      double Sin = S + Sref, Pin = -zmk;
+      const double Tin = T;
+      if (virt1) { Sin = 0.0; Pin = -zm1; }
+      if (virt2) { Sin = p.sice; Pin = -zm1; }
+      double s0, talpha, sbeta;
+      abk80_dev(Sin, Tin, Pin, talpha, sbeta, s0);
+      const double rho = 1000. + s0;
+      const double cp = cpsw_dev(Sin, Tin, Pin);
+      const double buoy = div_fast(-p.grav * s0, 1000., 1. / 1000.);
+      if (is1) { sc[X_RHO0] = rho; sc[X_CP0] = cp; sc[X_TALPHA0] = talpha; sc[X_SBETA0] = sbeta; }
+      if (virt1) sc[X_RHOH2O] = rho;
+      if (virt2) sc[X_RHOB] = rho;
+      if (act) { row(R_YU)[k] = U; row(R_PV)[k] = V; row(R_YS)[k] = buoy; }
+      if (p.diag && si[I_MAYBE]) {   // what the last vmix leaves behind (types_transfer.F90:199-327)
+        const size_t od = ro + k;
+        if (act) { p.rho[od] = rho; p.cp[od] = cp; p.buoy[od] = buoy; p.talpha[od] = talpha; p.sbeta[od] = sbeta; }
+        if (is1) { p.rho[od - 1] = rho; p.cp[od - 1] = cp; p.talpha[od - 1] = talpha; p.sbeta[od - 1] = sbeta; }
+      }
+      if constexpr (EXT) {
+        if (act) { row(R_RHO)[k] = rho; row(R_CP)[k] = cp; }
+        if (p.LDD && act) {   // neighbours for alphaDT, betaDS
+          row(R_LA)[k] = talpha; row(R_RB)[k] = sbeta; row(R_GH)[k] = S; row(R_BETM)[k] = T;
+        }
+      }
+    END_ITEMS
+    STAMP(0);
+    __syncthreads();
+    STAMP(1);
+
+    // ---- M1 | L2: surface fluxes (wave 0) | reference-level loop, Ri pieces (verticalmixing_mod.F90:111-137)
+    if (wv == mgr) M1();
+    FOR_ITEMS
+      const strided<ROWS> aU = row(R_YU), aV = row(R_PV), aB = row(R_YS);
+      const double U = act ? aU[k] : 0.0, V = act ? aV[k] : 0.0, buoy = aB[k];
+      const double zmk = c_zm[k];
+      const double zm1 = c_zm[1];
+      const double U1 = aU[1], V1 = aV[1], Bu1 = aB[1];
+      const double zref = eps01 * zmk, rzref = rcp_refine(zref);
+      double wz = dmax2(zm1, zref);
+      double ur = div_fast_guarded(U1 * wz, zref, rzref), vr = div_fast_guarded(V1 * wz, zref, rzref),
+             br = div_fast(Bu1 * wz, zref, rzref);
+      bool live = actz;
+      double zk = zm1, Uk = U1, Vk = V1, Bk = Bu1;
+      for (int kl = 1; kl <= nz; ++kl) {
+        live = live && !(zref >= zk);
+        if (!__any(live)) break;
+        const double zk1 = c_zm[kl + 1], Uk1 = aU[kl + 1], Vk1 = aV[kl + 1], Bk1 = aB[kl + 1];
+        if (live) {
+          const double dzk = zk - zk1, rdzk = c_rdz[kl];
+          double wz2 = dmin2(zk - zk1, zk - zref);
+          double del = div_fast(0.5 * wz2, dzk, rdzk);
+          ur = ur - div_fast_guarded(wz2 * (Uk + del * (Uk1 - Uk)), zref, rzref);
+          vr = vr - div_fast_guarded(wz2 * (Vk + del * (Vk1 - Vk)), zref, rzref);
+          br = br - div_fast(wz2 * (Bk + del * (Bk1 - Bk)), zref, rzref);
+        }
+        zk = zk1; Uk = Uk1; Vk = Vk1; Bk = Bk1;
+      }
+      if constexpr (EXT) {
+        if (p.LDD && act) {   // verticalmixing_mod.F90:103-108
+          const double talpha = row(R_LA)[k], sbeta = row(R_RB)[k], T = row(R_BETM)[k], S = row(R_GH)[k];
+          row(R_X1)[k] = 0.5 * (talpha + row(R_LA)[k + 1]) * (T - row(R_BETM)[k + 1]);
+          row(R_X2)[k] = 0.5 * (sbeta + row(R_RB)[k + 1]) * (S - row(R_GH)[k + 1]);
+        }
+      }
+      const double bk1 = aB[k + 1], uk1 = aU[k + 1], vk1 = aV[k + 1];
+      const double Ritop = (zref - zmk) * (br - buoy);
+      const double dbloc = buoy - bk1;
+      const double dVsq = (ur - U) * (ur - U) + (vr - V) * (vr - V);
+      const double shsq = (U - uk1) * (U - uk1) + (V - vk1) * (V - vk1);
+      if (p.mode != MCKPP_MODE_STEP && isnz) { sc[C_UREFNZ] = ur; sc[C_VREFNZ] = vr; }
+      const double zdiff = zmk - c_zm[k + 1];
+      const double shs = shsq + 1.e-16;
+      const double Rig = div_fast(dbloc * zdiff, shs, rcp_refine(shs));
+      if (actz) { row(R_R)[k] = Rig; row(R_DB)[k] = dbloc; row(R_RITOP)[k] = Ritop; row(R_DVSQ)[k] = dVsq; }
+      if (is1) row(R_R)[0] = 0.0;
+      if (isnzp1) row(R_R)[k] = 0.0;
+      if (p.diag && si[I_MAYBE]) {
+        const size_t od = ro + k;
+        if (actz) { p.Rig[od] = Rig; p.dbloc[od] = dbloc; p.Shsq[od] = shsq; }
+      }
+    END_ITEMS
+    STAMP(2);
+    __syncthreads();
+    STAMP(3);
+
+    // ---- L3: rimix + z121 (rimix_mod.F90:13-106, z121_mod.F90:7-45), ddmix, interior diffusivity rows;
+    //          bldepth, level-parallel part (bldepth_mod.F90:105-147)
+    FOR_ITEMS
+      if (!act) continue;
+      const strided<ROWS> aR = row(R_R), aDb = row(R_DB);
+      const double zmk = c_zm[k], zdiff = zmk - c_zm[k + 1];
+      const double Rig = aR[k], dbloc = aDb[k], Ritop = row(R_RITOP)[k], dVsq = row(R_DVSQ)[k];
+      const double Riinfty = 0.8;
+      double vm1 = aR[k - 1], vp1 = aR[k + 1];
+      double wm1 = (k - 1 >= 1 && !((vm1 < 0.0) || (vm1 > Riinfty))) ? 1.0 : 0.0;
+      double wp1 = (k + 1 <= nz && !((vp1 < 0.0) || (vp1 > Riinfty))) ? 1.0 : 0.0;
+      double sm = wm1 * vm1 + 2. * Rig + wp1 * vp1;
+      double wait = wm1 + 2.0 + wp1;
+      sm = div_fast(sm, wait, wait == 3.0 ? 1. / 3. : (wait == 2.0 ? 0.5 : 0.25));
+      double Rigg = dmax2(sm, 0.0);
+      double ratio = dmin2(div_fast(Rigg, Riinfty, 1. / Riinfty), 1.0);
+      double fri = (1.0 - ratio * ratio);
+      fri = fri * fri * fri;
+      double dm_i = (0.0001 + fri * 0.005);
+      double ds_i = (0.00001 + fri * 0.005);
+      double dt_i = ds_i;   // dift = difs, rimix_mod.F90:95-97
+      if constexpr (EXT) {
+        if (p.LDD) {   // ddmix_mod.F90:12-52
+          const double Rrho0 = 1.9, dsfmax = 1.0e-4;
+          const double aDT = row(R_X1)[k], bDS = row(R_X2)[k];
+          if ((aDT > bDS) && (bDS > 0.)) {
+            double Rrho = dmin2(aDT / bDS, Rrho0);
+            double rr = ((Rrho - 1) / (Rrho0 - 1));
+            double diffdd = 1.0 - rr * rr;
+            diffdd = dsfmax * diffdd * diffdd * diffdd;
+            dt_i = dt_i + diffdd * 0.8 / Rrho;
+            ds_i = ds_i + diffdd;
+          } else if ((aDT < 0.0) && (bDS < 0.0) && (aDT < bDS)) {
+            double Rrho = aDT / bDS;
+            double diffdd = 1.5e-6 * 9.0 * 0.101 * mckpp_exp(4.6 * mckpp_exp(-0.54 * (1 / Rrho - 1)));
+            double prandtl = 0.15 * Rrho;
+            if (Rrho > 0.5) prandtl = (1.85 - 0.85 / Rrho) * Rrho;
+            dt_i = dt_i + diffdd;
+            ds_i = ds_i + prandtl * diffdd;
+          }
+        }
+      }
+      const double B0 = sc[C_B0], B0sol = sc[C_B0SOL], ustar = sc[C_USTAR];
+      wscale_u wu;
+      wu.ju = si[I_JU]; wu.ufrac = sc[C_UFRAC]; wu.ustar = ustar; wu.ucube = sc[C_UCUBE];
+      const double zm_kmp1 = c_zm[nzp1];
+      double swf = p.swfrac_tab[si[I_JER] * p.ldc + k];
+      double bf = B0 + B0sol * (1. - swf);
+      double st = 0.5 + dsign(0.5, bf + epsln16);
+      double sg = st * 1. + (1. - st) * eps01;
+      double wm, ws;
+      wscale_dev(p, wu, sg, -zmk, bf, wm, ws);
+      double dbm1 = aDb[k - 1];
+      double bvsq = 0.5 * (div_fast(dbm1, c_zm[k - 1] - zmk, c_rdz[k - 1]) + div_fast(dbloc, zdiff, c_rdz[k]));
+      double Vtsq = -zmk * ws * __builtin_sqrt(__builtin_fabs(bvsq)) * p.Vtc;
+      const double rawden = dVsq + Vtsq + epsln16, bfa = __builtin_fabs(bf) + epsln16;
+      double raw = div_fast(Ritop, rawden, rcp_refine(rawden));
+      double dmo = div_fast(div_fast(cmonob * ustar * ustar * ustar, p.vonk, c_misc[1]), bfa, rcp_refine(bfa));
+      dmo = st * dmo - (1. - st) * zm_kmp1;
+      // interior diffusivities (after the reads of Ritop / dVsq, which share their rows)
+      if (actz) { row(R_DM)[k] = dm_i; row(R_DS)[k] = ds_i; row(R_DT)[k] = dt_i; }
+      if (isnz) { row(R_DM)[k + 1] = dm_i; row(R_DS)[k + 1] = ds_i; row(R_DT)[k + 1] = dt_i; }   // kppmix_mod.F90:82-84
+      if (is1) { row(R_DM)[0] = 0.0; row(R_DS)[0] = 0.0; row(R_DT)[0] = 0.0; }
+      if (k >= 2 && actz) { row(R_RAW)[k] = raw; row(R_DMO)[k] = dmo; }
+      if (is1) { row(R_RAW)[1] = 0.0; row(R_DMO)[1] = -zm_kmp1; }
+    END_ITEMS
+    STAMP(4);
+    __syncthreads();
+    STAMP(5);
+
+    // ---- M2: Rib(ku) = MAX(Rib(ku), Rib(ka)+epsln), bldepth_mod.F90:137
+    if (wv == mgr) { PRIO_HI(); serial_scan_rib_n(W, R_RAW, slots, SS, 1, ROWS, nz, sirec + I_ACT, I_COUNT, lane); PRIO_LO(); }
+    STAMP(6);
+    __syncthreads();
+    STAMP(7);
+
+    // ---- L4: first level with hmin < -zm(k) (bldepth_mod.F90:139-180): every hit level posts its hmin,
+    //          the shallowest one wins through an LDS minimum
+    FOR_ITEMS
+      const strided<ROWS> aRaw = row(R_RAW), aDmo = row(R_DMO);
+      const double zmk = c_zm[k];
+      const double ocdepth = sc[C_OCDEPTH];
+      const double zm_kmp1 = c_zm[nzp1];
+      const double hek = sc[C_HEK];
+      const double B0 = sc[C_B0], B0sol = sc[C_B0SOL];
+      double swf = p.swfrac_tab[si[I_JER] * p.ldc + k];
+      double bf = B0 + B0sol * (1. - swf);
+      double stab = 0.5 + dsign(0.5, bf + epsln16);
+      double Rka = aRaw[k - 1], Rku = aRaw[k], dmoa = aDmo[k - 1], dmou = aDmo[k];
+      double zkm1 = c_zm[k - 1];
+      double hri = -zkm1 + (zkm1 - zmk) * (Ricr - Rka) / (Rku - Rka);
+      double hmonob;
+      if (dmou <= (-zmk)) {
+        hmonob = (dmou - dmoa) / (zkm1 - zmk);
+        hmonob = (dmou + hmonob * zmk) / (1. - hmonob);
+      } else {
+        hmonob = -zm_kmp1;
+      }
+      double hekman = stab * hek - (1. - stab) * zm_kmp1;
+      double hmin = dmin2(dmin2(dmin2(hri, hmonob), hekman), -ocdepth);
+      bool hit = (k >= 2) && actz && (hmin < -zmk);
+      if (hit && !si[I_INITFLAG] && (hmin < -zkm1)) {
+        double hmin2 = dmin2(dmin2(hri, hmonob), -ocdepth);
+        if (hmin2 < -zmk) hmin = hmin2;
+      }
+      if (hit) row(R_H)[k] = hmin;
+      // only a hit whose shallower neighbour (same wave, same column since k >= 2) did not hit can be the first
+      const unsigned long long m = __ballot(hit);
+      const bool prev = lane > 0 && ((m >> (lane - 1)) & 1ull);
+      if (hit && !prev) atomicMin(&si[I_KBLC], k);
+    END_ITEMS
+    STAMP(8);
+    __syncthreads();
+    STAMP(9);
+
+    // ---- M3: hbl, kbl, slot-uniform part of blmix
+    if (wv == mgr) { PRIO_HI(); M3(); PRIO_LO(); }
+    STAMP(10);
+    __syncthreads();
+    STAMP(11);
+
+    // ---- L5: blmix shape functions, enhance, combine (blmix_mod.F90:110-133, enhance_mod.F90:10-51,
+    //          kppmix_mod.F90:103-111, verticalmixing_mod.F90:151-159) -> final diffusivity rows
+    FOR_ITEMS
+      if (!act) continue;
+      const int kbl = si[I_KBL];
+      const double zmk = c_zm[k];
+      const double dm_i = row(R_DM)[k], ds_i = row(R_DS)[k], dt_l = row(R_DT)[k];   // interior values of L3
+      double difm = dm_i, difs = ds_i, dift = dt_l, ghat = 0.;
+      if (k < kbl) {
+        const double hbl = sc[C_HBL], r_hbl = sc[C_RHBL], stable = sc[C_STABLE], bfsfc = sc[C_BFSFC];
+        wscale_u wu;
+        wu.ju = si[I_JU]; wu.ufrac = sc[C_UFRAC]; wu.ustar = sc[C_USTAR]; wu.ucube = sc[C_UCUBE];
+        const double hk = c_hm[k];
+        double wm, ws;
+        double sig = div_fast(-zmk + 0.5 * hk, hbl, r_hbl);
+        double sigma = stable * sig + (1. - stable) * dmin2(sig, eps01);
+        wscale_dev(p, wu, sigma, hbl, bfsfc, wm, ws);
+        double a1 = sig - 2.;
+        double a2 = 3. - 2. * sig;
+        double a3 = sig - 1.;
+        double Gm = a1 + a2 * sc[C_GAT1 + 0] + a3 * sc[C_DAT1 + 0];
+        double Gs = a1 + a2 * sc[C_GAT1 + 1] + a3 * sc[C_DAT1 + 1];
+        double Gt = a1 + a2 * sc[C_GAT1 + 2] + a3 * sc[C_DAT1 + 2];
+        double b0 = hbl * wm * sig * (1. + sig * Gm);
+        double b1 = hbl * ws * sig * (1. + sig * Gs);
+        double b2 = hbl * ws * sig * (1. + sig * Gt);
+        const double ghd = ws * hbl + epsln20;
+        double gh = div_fast((1. - stable) * p.cg, ghd, rcp_refine(ghd));
+        if (k == kbl - 1 && k <= nz - 1) {
+          const double caseA = sc[C_CASEA];
+          double delta = div_fast(hbl + zmk, zmk - c_zm[k + 1], c_rdz[k]);
+          double omd = 1. - delta;
+          double dkmp5 = caseA * dm_i + (1. - caseA) * b0;
+          double dstar = (omd * omd) * sc[C_DKM1 + 0] + (delta * delta) * dkmp5;
+          b0 = omd * dm_i + delta * dstar;
+          dkmp5 = caseA * ds_i + (1. - caseA) * b1;
+          dstar = (omd * omd) * sc[C_DKM1 + 1] + (delta * delta) * dkmp5;
+          b1 = omd * ds_i + delta * dstar;
+          dkmp5 = caseA * dt_l + (1. - caseA) * b2;
+          dstar = (omd * omd) * sc[C_DKM1 + 2] + (delta * delta) * dkmp5;
+          b2 = omd * dt_l + delta * dstar;
+          gh = (1. - caseA) * gh;
+        }
+        difm = b0; difs = b1; dift = b2; ghat = gh;
+      }
+      if (k >= nz) { difm = 0.0001; difs = 0.00001; dift = 0.00001; ghat = 0.0; }
+      row(R_DM)[k] = difm; row(R_DS)[k] = difs; row(R_DT)[k] = dift; row(R_GH)[k] = ghat;
+    END_ITEMS
+    STAMP(12);
+    __syncthreads();
+    STAMP(13);
+
+    // ---- L6: right-hand sides of U, T, S (ocnint_mod.F90:51-58, tridrhs solvers.F90:53-107)
+    if (do_ocnint) {
+      FOR_ITEMS
+        if (!act) continue;
+        const strided<ROWS> aDt = row(R_DT), aDs = row(R_DS), aGh = row(R_GH);
+        const double f = sc[C_F];
+        const size_t o = ro + (k - 1);
+        const double Uo = p.U[o], Vo = p.V[o], To = p.T[o], So = p.S[o];
+        const double dto = p.dto, tri1_nz = c_t1[nz];
+        const double wX0_1 = sc[C_WX01], wX0_2 = sc[C_WX02];
+        const strided<ROWS> yU = row(R_YU), yT = row(R_YT), yS = row(R_YS);
+        if (actz) {
+          const double V = row(R_PV)[k];
+          const double difm = row(R_DM)[k], difs = aDs[k], dift = aDt[k], ghat = aGh[k];
+          const int jer = si[I_JER];
+          const double rho0cp0 = sc[C_RHO0CP0], r_rc = sc[C_RRC], sflux3 = sc[C_SFLUX3];
+          const double dt_m1 = aDt[k - 1], ds_m1 = aDs[k - 1];
+          const double gh_m1 = (k >= 2) ? aGh[k - 1] : 0.0;
+          double wxnt = 0.0, wxnt_m1 = 0.0;   // wXNT(k,1), wXNT(k-1,1), fluxes_mod.F90:110-116
+          if (ntime >= 1) {
+            wxnt = div_fast(-sflux3 * p.swdk_tab[jer * p.ldc + k], rho0cp0, r_rc);
+            wxnt_m1 = div_fast(-sflux3 * p.swdk_tab[jer * p.ldc + k - 1], rho0cp0, r_rc);
+          }
+          double rhsU;
+          if (k == 1) rhsU = Uo + dto * (f * .5 * (Vo + V) - div_fast(sc[C_WU01], c_hm[1], c_misc[0]));
+          else rhsU = Uo + dto * f * .5 * (Vo + V);
+          if (k == nz) rhsU = rhsU + tri1_nz * difm * p.U[ro + (nzp1 - 1)];
+          double rhsT;
+          const double dtohk = c_dtohk[k];
+          if (k == 1) rhsT = To + dtohk * (wX0_1 * dift * ghat - wX0_1 * 1.0 + wxnt - sc[C_WXNT0]);
+          else rhsT = To + dtohk * (wX0_1 * (dift * ghat - dt_m1 * gh_m1) + wxnt - wxnt_m1);
+          if (k == nz && nz > 1) rhsT = rhsT + p.T[ro + (nzp1 - 1)] * tri1_nz * dift;
+          double rhsS;
+          if (k == 1) rhsS = So + dtohk * (wX0_2 * difs * ghat - wX0_2 * 1.0 + 0.0 - 0.0);
+          else rhsS = So + dtohk * (wX0_2 * (difs * ghat - ds_m1 * gh_m1) + 0.0 - 0.0);
+          if (k == nz && nz > 1) rhsS = rhsS + p.S[ro + (nzp1 - 1)] * tri1_nz * difs;
+          if constexpr (EXT) ext_rhs(my, si, col, k, si[I_KBL], To, So, rhsT, rhsS);
+          yU[k] = rhsU; yT[k] = rhsT; yS[k] = rhsS;
+        }
+        if (isnzp1) {
+          yU[k] = Uo; yT[k] = To; yS[k] = So;   // solvers.F90:159
+          if constexpr (EXT) { double t = 0.0, s2 = 0.0; ext_rhs(my, si, col, k, si[I_KBL], To, So, t, s2); }   // ocnint_mod.F90:153-160, 207-213
+        }
+      END_ITEMS
+    }
+    STAMP(14);
+    __syncthreads();
+    STAMP(15);
+
+    // ---- M4: Thomas factorise + sweep for U, T, S (solvers.F90:14-44, 112-161)
+    if (wv == mgr && do_ocnint) {
+      PRIO_HI();
+      serial_thomas_uts_n(W, slots, SS, 1, ROWS, K_STRIDE, nz, cst + K_T0, cst + K_T1, sirec + I_ACT, I_COUNT,
+                          sirec + I_BAD, I_COUNT, lane);
+      PRIO_LO();
+    }
+    STAMP(16);
+    __syncthreads();
+    STAMP(17);
+
+    // ---- L7: V right-hand side with the new U (ocnint_mod.F90:62-69)
+    if (do_ocnint) {
+      FOR_ITEMS
+        if (!act) continue;
+        const size_t o = ro + (k - 1);
+        const double Uo = p.U[o], Vo = p.V[o];
+        const double dto = p.dto, f = sc[C_F];
+        const strided<ROWS> yU = row(R_YU), yV = row(R_YV);
+        if (actz) {
+          const double un = yU[k];
+          double rhsV;
+          if (k == 1) rhsV = Vo - dto * (f * .5 * (Uo + un) + div_fast(sc[C_WU02], c_hm[1], c_misc[0]));
+          else rhsV = Vo - dto * f * .5 * (Uo + un);
+          if (k == nz) rhsV = rhsV + c_t1[nz] * row(R_DM)[k] * p.V[ro + (nzp1 - 1)];
+          yV[k] = rhsV;
+        } else {
+          yV[k] = Vo;
+        }
+      END_ITEMS
+    }
+    STAMP(18);
+    __syncthreads();
+    STAMP(19);
+
+    // ---- M5: Thomas sweep for V on the stored momentum factorisation; ocnstep control
+    if (wv == mgr) {
+      PRIO_HI();
+      if (do_ocnint) serial_thomas_v_n(W, slots, SS, 1, ROWS, K_STRIDE, nz, cst + K_T0, sirec + I_ACT, I_COUNT, lane);
+      G();
+      PRIO_LO();
+    }
+    STAMP(20);
+    __syncthreads();
+    STAMP(21);
+    if (!s_flags[1]) continue;
+
+    // =========================== finish round ===========================
+    // instability trap (ocnstep_mod.F90:200-236), then retry or outputs + check_profile.  The profiles of a
+    // finishing slot are what the last ocnint returned: they stay in the slot's solution rows (R_YU, R_YV,
+    // R_YT, R_YS) and every sub-phase works on them in place.  INIT / VMIX have no solution: U,V,T,S are the
+    // column's own rows in HBM.
+    FOR_ITEMS
+      if (si[I_FIN] != F_TRAP) continue;   // :200-207
+      const double U = row(R_YU)[k], V = row(R_YV)[k], T = row(R_YT)[k], tk1 = row(R_YT)[k + 1];
+      const bool v = actz && (__builtin_fabs(U) >= 10 || __builtin_fabs(V) >= 10 || __builtin_fabs(T - tk1) >= 10);
+      if (v) atomicAdd(&si[I_NVIOL], 1);
+    END_ITEMS
+    __syncthreads();
+    FOR_ITEMS
+      if (!(si[I_FIN] == F_TRAP && si[I_NVIOL] == 0 && act)) continue;   // :208-219
+      const size_t o = ro + (k - 1);
+      const double U = row(R_YU)[k], V = row(R_YV)[k], T = row(R_YT)[k], S = row(R_YS)[k];
+      const double Uo = p.U[o], Vo = p.V[o], To = p.T[o], So = p.S[o];
+      const double hk = c_hm[k];
+      row(R_GM)[k] = (U - Uo) * (U - Uo) * hk / p.dm_nz;
+      row(R_GT)[k] = (V - Vo) * (V - Vo) * hk / p.dm_nz;
+      row(R_GS)[k] = (T - To) * (T - To) * hk / p.dm_nz;
+      row(R_RB)[k] = (S - So) * (S - So) * hk / p.dm_nz;
+    END_ITEMS
+    __syncthreads();
+    if (wv == mgr) {   // trap decision, one lane per (slot, profile) for the rmsd sums, then one per slot
+      bool over = false;
+      if (lane < 4 * W) {
+        const int ms = lane >> 2, mq = lane & 3;
+        const int *msi = sirec + ms * I_COUNT;
+        if (msi[I_ACT] && msi[I_FIN] == F_TRAP && msi[I_NVIOL] == 0) {
+          const strided<ROWS> t{slots + ms * SS + (mq == 3 ? (int)R_RB : (int)R_GM + mq)};
+          double sum = 0.;
+          for (int q = 1; q <= nzp1; ++q) sum = sum + t[q];
+          sum = __builtin_sqrt(sum);
+          over = sum >= 1.0;
+        }
+      }
+      const unsigned long long mo = __ballot(over);
+      if (lane < W) {
+        int *msi = sirec + lane * I_COUNT;
+        double *msc = screc + lane * C_COUNT;
+        if (msi[I_ACT] && msi[I_FIN] == F_TRAP) {
+          int comp_flag = 0, status = msi[I_STATUS], nreset = msi[I_NRESET];
+          double f = msc[C_F];
+          const int nviol = msi[I_NVIOL];
+          if (nviol > 0) {
+            comp_flag = 1;
+            for (int i = 0; i < nviol; ++i) f = f * 1.01;
+          } else {
+            const int nover = __popcll((mo >> (4 * lane)) & 0xFull);
+            if (nover > 0) {
+              comp_flag = 1;
+              for (int i = 0; i < nover; ++i) f = f * 1.01;
+            }
+          }
+          if (comp_flag) { status |= 4; msc[C_F] = f; }
+          nreset = nreset + 1;
+          if (nreset > 10) status |= 8;
+          msi[I_COMP] = comp_flag; msi[I_STATUS] = status; msi[I_NRESET] = nreset;
+          if (comp_flag && nreset <= 10) {   // retry, ocnstep_mod.F90:89
+            msi[I_FIN] = F_NONE; msi[I_LOAD] = 2; msi[I_NPASS_TRY] = 0; msi[I_ICONV] = 0; msi[I_MAYBE] = 0;
+          } else {
+            msi[I_FIN] = F_FINAL;
+            msi[I_NU] = 0; msi[I_NV] = 0; msi[I_NF] = 0;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- outputs.  Diagnostic fluxes (ocnstep_mod.F90:242-256 / initialize_ocean.F90:66-81) from the final
+    // profiles and their k+1 neighbours; STEP: level-1 references, then (optional physics) current damping.
+    FOR_ITEMS
+      if (si[I_FIN] != F_FINAL) continue;
+      const bool fstep = p.mode == MCKPP_MODE_STEP;
+      const bool sol = do_ocnint;   // profiles in the solution rows
+      const size_t o = ro + (k - 1);
+      double U = 0, V = 0, T = 0, S = 0, uk1 = 0, vk1 = 0, tk1 = 0, sk1 = 0;
+      if (act) {
+        if (sol) { U = row(R_YU)[k]; V = row(R_YV)[k]; T = row(R_YT)[k]; S = row(R_YS)[k]; }
+        else { U = p.U[o]; V = p.V[o]; T = p.T[o]; S = p.S[o]; }
+      }
+      if (actz && p.diag && flux_diag) {
+        if (sol) { uk1 = row(R_YU)[k + 1]; vk1 = row(R_YV)[k + 1]; tk1 = row(R_YT)[k + 1]; sk1 = row(R_YS)[k + 1]; }
+        else { uk1 = p.U[o + 1]; vk1 = p.V[o + 1]; tk1 = p.T[o + 1]; sk1 = p.S[o + 1]; }
+      }
+      if (p.diag) {
+        const double wX0_1 = sc[C_WX01], wX0_2 = sc[C_WX02];
+        const double rho0cp0 = sc[C_RHO0CP0], sflux3 = sc[C_SFLUX3];
+        const size_t od = ro + k;
+        // the difm, difs, dift, ghat, wU, wX rows of HBM double as the iterate's scratch sets: a finishing
+        // column's diagnostics are written only now that no pass reads them any more
+        if (act) {
+          const double dfm = row(R_DM)[k], dfs = row(R_DS)[k], dft = row(R_DT)[k], gh = row(R_GH)[k];
+          p.difm[od] = dfm; p.difs[od] = dfs; p.dift[od] = dft;
+          if (actz) {
+            p.ghat[od] = gh;
+            p.wXNT1[od] = (ntime >= 1) ? -sflux3 * p.swdk_tab[si[I_JER] * p.ldc + k] / rho0cp0 : 0.0;
+            if (flux_diag) {
+              const double talpha = p.talpha[od], sbeta = p.sbeta[od];   // of the last vmix (L1 of this pass)
+              double deltaz = 0.5 * (c_hm[k] + c_hm[k + 1]);
+              double wX1 = -dfs * ((T - tk1) / deltaz - gh * wX0_1);
+              double wX2 = -dfs * ((S - sk1) / deltaz - gh * wX0_2);
+              if (p.LDD) wX1 = -dft * ((T - tk1) / deltaz - gh * wX0_1);
+              p.wX1[od] = wX1; p.wX2[od] = wX2;
+              p.wX3[od] = p.grav * (talpha * wX1 - sbeta * wX2);
+              p.wU1[od] = -dfm * (U - uk1) / deltaz;
+              p.wU2[od] = -dfm * (V - vk1) / deltaz;
+            }
+          }
+        }
+        if (is1) {   // index-0 entries
+          p.difm[ro] = 0.0; p.difs[ro] = 0.0; p.dift[ro] = 0.0;
+          p.wU1[ro] = sc[C_WU01]; p.wU2[ro] = sc[C_WU02];
+          p.wX1[ro] = wX0_1; p.wX2[ro] = wX0_2; p.wX3[ro] = -sc[C_B0];
+          p.wXNT1[ro] = sc[C_WXNT0];
+        }
+      }
+      if (fstep && is1) {   // level-1 references, before any override touches the profiles
+        double *cs = p.cs + (size_t)col * MCKPP_CS;
+        cs[CS_UREF] = U; cs[CS_VREF] = V; cs[CS_TREF] = T;
+        cs[CS_SSURF] = p.L_SSref ? cs[CS_SSREF] : S + sc[C_SREF];
+      }
+      if constexpr (EXT) {
+        if (fstep && p.L_DAMP_CURR && act) {   // ocnstep_mod.F90:317-340
+          const double rr = (double)p.dt_uvdamp * (86400. / p.dto);
+          double a = 0.99 * __builtin_fabs(U), b = (U * U) / rr;
+          if (b < a) atomicAdd(&si[I_NU], 1);
+          row(R_YU)[k] = U - dsign(dmin2(a, b), U);
+          a = 0.99 * __builtin_fabs(V); b = (V * V) / rr;
+          if (b < a) atomicAdd(&si[I_NV], 1);
+          row(R_YV)[k] = V - dsign(dmin2(a, b), V);
+        }
+      }
+    END_ITEMS
+    // wX(0..nz), wU rows hold final values now, but the scratch sets alias them: a slot that is NOT finishing
+    // must not have been disturbed - it was not (only its own column's rows are touched by a slot).
+    if constexpr (EXT) __syncthreads();
+    // ---- STEP: new time level, check_profile (overrides.F90:42-125); the optional parts count over all
+    // levels of the column: LDS counters between workgroup barriers (EXT build).
+    FOR_ITEMS
+      if (!(si[I_FIN] == F_FINAL && p.mode == MCKPP_MODE_STEP)) continue;
+      const size_t o = ro + (k - 1);
+      const int newi = 1 - si[I_NEW];   // old = new; new = 1 - old
+      double U = 0, V = 0, T = 0, S = 0;
+      if (act) { U = row(R_YU)[k]; V = row(R_YV)[k]; T = row(R_YT)[k]; S = row(R_YS)[k]; }
+      if (act) { p.Us[newi][o] = U; p.Vs[newi][o] = V; p.Ts[newi][o] = T; p.Ss[newi][o] = S; }
+      if (si[I_COMP] && act) {   // overrides.F90:57-78
+        if (EXT && p.clim_present) { T = p.ocnT_clim[o]; S = p.sal_clim[o]; row(R_YT)[k] = T; row(R_YS)[k] = S; }
+        U = p.U_init[o]; V = p.V_init[o];
+        row(R_YU)[k] = U; row(R_YV)[k] = V;
+      }
+      if constexpr (EXT) {
+        if (si[I_LOCEAN] && p.L_NO_FREEZE && act) {   // :85-94
+          double xt = p.tinc_fcorr[ro + k];
+          if (T < -1.8) { xt = xt + (-1.8 - T); T = -1.8; row(R_YT)[k] = T; atomicAdd(&si[I_NF], 1); }
+          p.tinc_fcorr[ro + k] = xt;
+        }
+      }
+    END_ITEMS
+    if constexpr (EXT) {
+      __syncthreads();
+      // isotherm check (:102-120): |T(k) - T(k-1)| dz and dz into the gam rows, summed by every item of the slot
+      FOR_ITEMS
+        if (!(si[I_FIN] == F_FINAL && p.mode == MCKPP_MODE_STEP && si[I_LOCEAN] && p.L_NO_ISOTHERM)) continue;
+        if (k >= 2 && act) {
+          const double dz = c_zm[k] - c_zm[k - 1];
+          row(R_GM)[k] = __builtin_fabs((row(R_YT)[k] - row(R_YT)[k - 1])) * dz;
+          row(R_GT)[k] = dz;
+        }
+      END_ITEMS
+      __syncthreads();
+    }
+    FOR_ITEMS
+      if (si[I_FIN] != F_FINAL) continue;
+      double *cs = p.cs + (size_t)col * MCKPP_CS;
+      int *ci = p.ci + (size_t)col * MCKPP_CI;
+      const size_t o = ro + (k - 1);
+      if (p.mode == MCKPP_MODE_STEP) {
+        double reset_out = (double)si[I_NRESET];
+        if (si[I_COMP]) reset_out = 999.;
+        bool iso_reset = false;
+        if constexpr (EXT) {
+          if (si[I_LOCEAN] && p.L_NO_ISOTHERM) {
+            const strided<ROWS> tD = row(R_GM), tZ = row(R_GT);
+            double dtdz_total = 0., dz_total = 0.;
+            for (int q = 2; q <= p.iso_bot; ++q) {
+              dtdz_total = dtdz_total + tD[q];
+              dz_total = dz_total + tZ[q];
+            }
+            dtdz_total = dtdz_total / dz_total;
+            if (__builtin_fabs(dtdz_total) < p.iso_thresh) {
+              iso_reset = true;
+              reset_out = (-1.) * reset_out;
+            }
+          } else {
+            reset_out = 0.0;   // :121-123
+          }
+        } else {
+          reset_out = 0.0;     // :121-123 (no isotherm check in the default physics)
+        }
+        if (act) {
+          double U = row(R_YU)[k], V = row(R_YV)[k], T = row(R_YT)[k], S = row(R_YS)[k];
+          if (EXT && iso_reset) { T = p.ocnT_clim[o]; S = p.sal_clim[o]; }
+          p.U[o] = U; p.V[o] = V; p.T[o] = T; p.S[o] = S;
+        }
+        if (is1) {
+          const int old = si[I_NEW], newi = 1 - old;
+          double dampu = 0.0, dampv = 0.0;
+          if constexpr (EXT) {
+            if (p.L_DAMP_CURR) {
+              const double inc = 1.0 / (double)nzp1;
+              const int nu = si[I_NU], nv = si[I_NV];
+              for (int i = 0; i < nu; ++i) dampu = dampu + inc;
+              for (int i = 0; i < nv; ++i) dampv = dampv + inc;
+            }
+            double freeze = cs[CS_FREEZE];
+            if (si[I_LOCEAN] && p.L_NO_FREEZE) {
+              const double inc = 1.0 / (double)nzp1;
+              const int nf = si[I_NF];
+              for (int i = 0; i < nf; ++i) freeze = freeze + inc;
+            }
+            cs[CS_FREEZE] = freeze;
+          }
+          const double hmixn = sc[C_HMIXN];
+          cs[CS_HMIX] = hmixn;
+          cs[CS_KMIX] = (double)si[I_KMIXN];
+          cs[newi ? CS_HMIXD1 : CS_HMIXD0] = hmixn;
+          cs[CS_RESET] = reset_out;
+          cs[CS_DAMPU] = dampu; cs[CS_DAMPV] = dampv;
+          ci[CI_OLD] = old; ci[CI_NEW] = newi;
+          ci[CI_STATUS] = si[I_STATUS]; ci[CI_NPASS] = si[I_NPASS];
+        }
+      } else if (p.mode == MCKPP_MODE_INIT) {
+        if (act) {
+          const double U = p.U[o], V = p.V[o], T = p.T[o], S = p.S[o];
+          p.Us[0][o] = U; p.Us[1][o] = U; p.Vs[0][o] = V; p.Vs[1][o] = V;
+          p.Ts[0][o] = T; p.Ts[1][o] = T; p.Ss[0][o] = S; p.Ss[1][o] = S;
+        }
+        if (is1) {
+          const double hbl = sc[C_HBL];
+          cs[CS_HMIX] = hbl;
+          cs[CS_KMIX] = (double)si[I_KBL];
+          cs[CS_TREF] = p.T[o];
+          cs[CS_UREF] = sc[C_UREFNZ]; cs[CS_VREF] = sc[C_VREFNZ];
+          cs[CS_HMIXD0] = hbl; cs[CS_HMIXD1] = hbl;
+          ci[CI_OLD] = 0; ci[CI_NEW] = 1; ci[CI_INITFLAG] = 0;
+          ci[CI_STATUS] = si[I_STATUS]; ci[CI_NPASS] = si[I_NPASS];
+        }
+      } else {
+        if (p.mode == MCKPP_MODE_PASS && act) {
+          p.U[o] = row(R_YU)[k]; p.V[o] = row(R_YV)[k]; p.T[o] = row(R_YT)[k]; p.S[o] = row(R_YS)[k];
+        }
+        if (is1) {
+          cs[CS_HMIX] = sc[C_HBL];
+          cs[CS_KMIX] = (double)si[I_KBL];
+          cs[CS_UREF] = sc[C_UREFNZ]; cs[CS_VREF] = sc[C_VREFNZ];
+          ci[CI_STATUS] = si[I_STATUS]; ci[CI_NPASS] = si[I_NPASS];
+        }
+      }
+    END_ITEMS
+    __syncthreads();   // every read of the finished slots' records is done: hand them to the queue
+    if (wv == mgr) M0();
+    __syncthreads();
+  }
+#ifdef MCKPP_PS_STAMPS
+  if (p.dbg && wv == mgr && lane == 0) {
+    for (int i = 0; i < 23; ++i) atomicAdd(p.dbg + i, tacc[i]);
+    atomicAdd(p.dbg + 31, tacc[23]);
+  }
+#endif
+#undef STAMP
+#undef FOR_ITEMS
+#undef END_ITEMS
+}
+
+struct ps_geom { int nw, w, per_cu; };
+
+// Slots per workgroup / waves / workgroups per CU: what keeps most columns in flight on a CU - two workgroups of
+// 8 waves or one of 16 (128 VGPRs: 16 waves per CU), each with as many slots as its share of the LDS holds
+// (<= 16: four manager lanes per slot in the trap) - and no more waves than the items need.
+ps_geom ps_choose(int L, bool ext, size_t cu_lds_bytes)
+{
+  auto granules = [&](int w_) { return (ps_lds_bytes(L, w_, ext) + 1279) / 1280 * 1280; };
+  int w2 = 16, w1 = 16;
+  while (w2 > 1 && 2 * granules(w2) > cu_lds_bytes) --w2;
+  while (w1 > 1 && granules(w1) > cu_lds_bytes) --w1;
+  ps_geom g;
+  if (w1 > 2 * w2) g = {16, w1, 1};
+  else g = {8, w2, 2};
+  const int need = (g.w * L + 63) / 64;
+  if (need < g.nw) g.nw = need;
+  if (g.per_cu * g.nw < 16 && g.per_cu == 2 && 16 / g.nw > 2) {   // small columns: more, smaller workgroups
+    g.per_cu = 16 / g.nw;
+    while (g.per_cu > 2 && (size_t)g.per_cu * granules(g.w) > cu_lds_bytes) --g.per_cu;
+  }
+  return g;
+}
+
+}  // namespace
+
+// MCKPP_PS=<slots>x<waves>x<workgroups per CU> overrides the geometry (experiments).
+hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu, hipStream_t stream,
+                                         mckpp_launch_info *info)
+{
+  if (p.ncol <= 0) return hipSuccess;
+  const int L = p.nzp1 + 2;
+  if (L > 1024) return hipErrorInvalidValue;
+  const bool ext = p.ext != 0;
+  ps_geom g = ps_choose(L, ext, (size_t)160 * 1024);
+  if (const char *e = getenv("MCKPP_PS")) {
+    int w = 0, nw = 0, b = 0;
+    if (sscanf(e, "%dx%dx%d", &w, &nw, &b) == 3 && w >= 1 && w <= 16 && nw >= 1 && nw <= 16 && b >= 1) g = {nw, w, b};
+  }
+  const size_t lds = ps_lds_bytes(L, g.w, ext);
+  if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
+  const void *fn = ext ? reinterpret_cast<const void *>(k_column_ps<true>) : reinterpret_cast<const void *>(k_column_ps<false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  int nblocks = num_cu * g.per_cu;
+  const int groups = (p.ncol + g.w - 1) / g.w;
+  if (nblocks > groups) nblocks = groups;
+  if (nblocks < 1) nblocks = 1;
+  if (info) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * g.nw, lds) != hipSuccess) nb = 0;
+    *info = {nblocks, 64 * g.nw, nb, lds};
+  }
+  const unsigned Lmagic = (unsigned)(0x100000000ull / (unsigned long long)L) + 1u;   // it / L == umulhi(it, Lmagic) for it < 2^20
+  if (ext) hipLaunchKernelGGL(k_column_ps<true>, dim3((unsigned)nblocks), dim3(64 * g.nw), lds, stream, dp, p.ntime, L, g.w, Lmagic);
+  else hipLaunchKernelGGL(k_column_ps<false>, dim3((unsigned)nblocks), dim3(64 * g.nw), lds, stream, dp, p.ntime, L, g.w, Lmagic);
+  return hipGetLastError();
+}

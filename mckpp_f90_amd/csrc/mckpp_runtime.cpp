@@ -212,7 +212,8 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   if (const char *kv = getenv("MCKPP_KERNEL")) {
     if (strcmp(kv, "wg") == 0) h->kernel_variant = 2;
     else if (strcmp(kv, "pk") == 0) h->kernel_variant = 4;
-    else return fail("mckpp_hip_init: MCKPP_KERNEL=%s (known: wg, pk)", kv);
+    else if (strcmp(kv, "ps") == 0) h->kernel_variant = 5;
+    else return fail("mckpp_hip_init: MCKPP_KERNEL=%s (known: wg, pk, ps)", kv);
   }
   if (h->kernel_variant == 2 && nzp1 + 2 > 64) {
     return fail("mckpp_hip_init: MCKPP_KERNEL=wg carries columns of up to 61 levels (nz=%d)", c->nz);
@@ -656,7 +657,9 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode, const forced_r
                                  forced->flsn, forced->el, h->stream));
     }
     HIPCHK(hipMemsetAsync(h->d_qhead, 0, sizeof(int), h->stream));
-    if (h->kernel_variant == 4) {
+    if (h->kernel_variant == 5) {
+      HIPCHK(mckpp_launch_column_kernel_ps(p, h->d_params, h->num_cu, h->stream, &h->last_launch));
+    } else if (h->kernel_variant == 4) {
       HIPCHK(mckpp_launch_column_kernel_pk(p, h->d_params, h->num_cu, h->stream, &h->last_launch));
     } else {
       HIPCHK(mckpp_launch_column_kernel_wg(p, h->d_params, h->num_cu, h->stream));
@@ -749,6 +752,7 @@ const char *mckpp_hip_kernel_name(mckpp_hip_handle h)
 {
   if (!h) return "none";
   if (h->kernel_variant == 2) return h->ext ? "k_column_wg<1,EXT>" : "k_column_wg<1>";
+  if (h->kernel_variant == 5) return h->ext ? "k_column_ps<EXT>" : "k_column_ps";
   return h->ext ? "k_column_pk<EXT>" : "k_column_pk";
 }
 

@@ -605,7 +605,7 @@ def test_default_kernel_selection(mk, kernel_env):
     with pytest.raises(mk.MckppHipError, match="61 levels"):
         mk.MckppHip(kc)
     kernel_env("v1")
-    with pytest.raises(mk.MckppHipError, match="known: wg, pk"):
+    with pytest.raises(mk.MckppHipError, match="known: wg, pk, ps"):
         mk.MckppHip(kc)
     kernel_env(None)
     kc = mk.KppConstFields(510)                      # a column takes nzp1+2 of the 512 lanes of a workgroup
@@ -614,7 +614,7 @@ def test_default_kernel_selection(mk, kernel_env):
         mk.MckppHip(kc)
 
 
-@pytest.mark.parametrize("variant", ["wg", "pk"])
+@pytest.mark.parametrize("variant", ["wg", "pk", "ps"])
 @pytest.mark.parametrize("nz,ncol,nsteps,grid", [(40, 70, 2, "uniform"), (61, 67, 2, "uniform"), (62, 67, 2, "uniform"),
                                                  (69, 131, 2, "stretched"), (125, 35, 2, "uniform"),
                                                  (126, 35, 2, "uniform"), (150, 41, 2, "uniform")])
@@ -625,13 +625,14 @@ def test_every_kernel_variant_bitexact(mk, kernel_env, variant, nz, ncol, nsteps
         pytest.skip("k_column_wg holds columns of up to 61 levels")
     kernel_env(variant)
     out, k3, ob, kc, oc = _run_both(mk, ncol, nz, nsteps, grid=grid, land_every=5, jerlov_mix=True)
-    want = {"wg": "k_column_wg<", "pk": "k_column_pk"}[variant]
+    want = {"wg": "k_column_wg<", "pk": "k_column_pk", "ps": "k_column_ps"}[variant]
     assert kc._hip_ctx.kernel_name.startswith(want), kc._hip_ctx.kernel_name
     for tag, res in out:
         _assert_bitexact(res, f"{variant} nz={nz} {tag}")
 
 
-@pytest.mark.parametrize("variant,nz", [("wg", 40), ("wg", 60), ("pk", 40), ("pk", 60), ("pk", 69), ("pk", 100), ("pk", 150)])
+@pytest.mark.parametrize("variant,nz", [("wg", 40), ("wg", 60), ("pk", 40), ("pk", 60), ("pk", 69), ("pk", 100), ("pk", 150),
+                                        ("ps", 40), ("ps", 60), ("ps", 69), ("ps", 100), ("ps", 150)])
 def test_instability_trap_every_variant(mk, kernel_env, variant, nz):
     """The retry round (violation counts and rmsd sums over lanes of several waves in k_column_pk)."""
     from oracle import orc
@@ -672,7 +673,7 @@ def test_config2_pass_every_variant(mk, kernel_env):
 
     fields = ["U", "V", "T", "S", "hmix", "kmix", "uref", "vref", "rho", "cp", "buoy", "difm", "difs", "dift",
               "ghat", "Rig", "dbloc", "Shsq", "wXNT1"]
-    for variant, nz in [("wg", 60), ("pk", 40), ("pk", 60), ("pk", 69), ("pk", 100), ("pk", 150)]:
+    for variant, nz in [("wg", 60), ("pk", 40), ("pk", 60), ("pk", 69), ("pk", 100), ("pk", 150), ("ps", 40), ("ps", 60), ("ps", 100)]:
         kernel_env(variant)
         ncol = 300
         oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1)
@@ -681,7 +682,7 @@ def test_config2_pass_every_variant(mk, kernel_env):
         ob["sflux"] = sf
         cm.set_forcing_3d(k3, sf)
         ctx = mk.MckppHip(kc)
-        assert ctx.kernel_name.startswith("k_column_wg<" if variant == "wg" else "k_column_pk")
+        assert ctx.kernel_name.startswith({"wg": "k_column_wg<", "pk": "k_column_pk", "ps": "k_column_ps"}[variant])
         ctx.upload(k3)
         ctx.vmix_pass(1)
         ctx.download(k3)
@@ -690,7 +691,7 @@ def test_config2_pass_every_variant(mk, kernel_env):
         ctx.close()
 
 
-@pytest.mark.parametrize("variant,nz", [("wg", 40), ("wg", 60), ("pk", 40), ("pk", 60), ("pk", 69), ("pk", 100)])
+@pytest.mark.parametrize("variant,nz", [("wg", 40), ("wg", 60), ("pk", 40), ("pk", 60), ("pk", 69), ("pk", 100), ("ps", 40), ("ps", 60), ("ps", 69), ("ps", 100)])
 def test_tiny_and_denormal_velocities_take_the_ieee_paths(mk, kernel_env, variant, nz):
     """The kernels drop the v_div_scale rescaling where operand ranges are known and guard the
     quotients whose numerators can be tiny non-zero numbers (velocities diffused down a deep column):
@@ -962,7 +963,7 @@ def test_tuned_residency_is_what_the_device_grants(mk, kernel_env, nz, ncol, wan
     ctx.close()
 
 
-@pytest.mark.parametrize("variant,nz", [("wg", 60), ("pk", 60), ("pk", 100)])
+@pytest.mark.parametrize("variant,nz", [("wg", 60), ("pk", 60), ("pk", 100), ("ps", 60), ("ps", 100)])
 def test_zero_pivot_on_device(mk, kernel_env, variant, nz):
     """The reference STOPs when the Thomas pivot vanishes (src/mckpp_physics_solvers.F90:140-151); the
     device sets MCKPP_ST_ZERO_PIVOT, continues with bet = 1e-12 and lets the instability trap deal with
@@ -984,7 +985,7 @@ def test_zero_pivot_on_device(mk, kernel_env, variant, nz):
         oc.tri0[level] = 0.0
         oc.tri1[level] = -1.0e4
         ctx = mk.mckpp_initialize_ocean_model(k3, kc)
-        assert ctx.kernel_name.startswith("k_column_wg" if variant == "wg" else "k_column_pk")
+        assert ctx.kernel_name.startswith({"wg": "k_column_wg", "pk": "k_column_pk", "ps": "k_column_ps"}[variant])
         orc.init_ocean(oc, ob, 0)
         sf = cm.synth.forcing(ncol, "bench")
         ob["sflux"] = sf
@@ -1033,7 +1034,7 @@ def test_long_iteration_status_on_device(mk, kernel_env, variant, nz):
     assert seen > 0, "no column exceeded itermax+1 passes"
 
 
-@pytest.mark.parametrize("variant,nz", [("wg", 60), ("pk", 40), ("pk", 60), ("pk", 69), ("pk", 100)])
+@pytest.mark.parametrize("variant,nz", [("wg", 60), ("pk", 40), ("pk", 60), ("pk", 69), ("pk", 100), ("ps", 40), ("ps", 60), ("ps", 100)])
 def test_verticalmixing_alone(mk, kernel_env, variant, nz):
     """mckpp_hip_vmix_only = mckpp_physics_verticalmixing (src/mckpp_physics_verticalmixing_mod.F90:14) by
     itself, the third routine of the reference's call surface: after two model steps, one more vmix on the
