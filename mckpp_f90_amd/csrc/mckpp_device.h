@@ -66,6 +66,9 @@ struct mckpp_kparams {
   // diagnostics (all or none)
   double *rho, *cp, *buoy, *talpha, *sbeta, *difm, *difs, *dift, *ghat;
   double *wU1, *wU2, *wX1, *wX2, *wX3, *wXNT1, *Rig, *dbloc, *Shsq;
+  // k_column_ps: the iterate's scratch rows, one block per (workgroup, slot) (mckpp_ps_scratch_doubles)
+  double *scratch;
+  size_t scratch_doubles;
 };
 
 // what the last cooperative-kernel launch looked like (for the residency check of the tests)
@@ -84,6 +87,7 @@ hipError_t mckpp_launch_column_kernel_pk(const mckpp_kparams &p, const mckpp_kpa
 // packed, stateless-lane kernel (mckpp_kernels_ps.hip): level phases loop over (slot, level) items
 hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu,
                                          hipStream_t stream, mckpp_launch_info *info);
+size_t mckpp_ps_scratch_doubles(int nzp1, int ext, int num_cu);   // what p.scratch must hold for that launch
 hipError_t mckpp_launch_eos_batch(int64_t n, const double *s, const double *t, const double *p,
                                   double *alpha, double *beta, double *sig0, double *cp,
                                   hipStream_t stream);

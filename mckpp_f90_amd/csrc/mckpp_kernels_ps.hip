@@ -1,13 +1,14 @@
 // mckpp_kernels_ps.hip - packed, stateless-lane cooperative column kernel.
 //
-// k_column_ps (mckpp_kernels_pk.hip) gives every column nzp1+2 lanes for the whole step; its waves are
+// k_column_pk (mckpp_kernels_pk.hip) gives every column nzp1+2 lanes for the whole step; its waves are
 // parked at barriers ~80 % of the time waiting for the manager wave's serial phases, and the number of columns
-// in flight on a CU is capped by the wave slots (16 waves at 128 VGPRs).  Here a level lane keeps NOTHING
-// between phases: the iterate (U,V,T,S of the under-relaxation) lives in two L2-resident scratch row sets in
-// HBM (diagnostic rows that are only written when a column finishes), every phase-crossing value in a row
-// of the slot's LDS block.  A level phase is then a loop over work items (slot, level) strided by the
-// workgroup's threads, so a workgroup serves as many slots as LDS holds, whatever its number of waves, and
-// no lane is left over at the end of a column.  Manager phases, LDS layout, arithmetic: as k_column_ps.
+// in flight on a CU is capped by the wave slots (16 waves at 128 VGPRs) and by 13 LDS rows per column.
+// Here a level lane keeps NOTHING between phases: the iterate (U,V,T,S of the under-relaxation) lives in a
+// small cache-resident scratch block per (workgroup, slot), every other phase-crossing value in one of NINE
+// rows of the slot's LDS block (each row is reused three to five times in a pass, see the table below).  A
+// level phase is a loop over work items (slot, level) strided by the workgroup's threads, so a workgroup
+// serves as many slots as LDS holds, whatever its number of waves: the manager wave's serial phases cost the
+// same for 15 slots as for 8.  Manager phases, LDS layout, arithmetic: as k_column_pk.
 #include "mckpp_sweeps.h"
 
 #include <cstdio>
@@ -33,26 +34,30 @@ enum {
 enum {
   I_STATE = 0, I_ACT, I_COL, I_OLD, I_NEW, I_JER, I_INITFLAG, I_STATUS, I_NPASS, I_NPASS_TRY, I_ICONV, I_COMP, I_KMIXN,
   I_KBL, I_NRESET, I_FIN, I_MAYBE, I_LOAD /* 1: new column, 2: restart the iteration (trap retry) */, I_JU,
-  I_KBLC, I_NVIOL, I_NU, I_NV, I_NF, I_BAD, I_LOCEAN, I_PAR /* scratch set holding the iterate */, I_COUNT
+  I_KBLC, I_NVIOL, I_NOVER, I_NU, I_NV, I_NF, I_BAD, I_LOCEAN, I_PAR /* which C_T1X holds the iterate's level-1 temperature */, I_COUNT
 };
-enum { R_RHO = R_COUNT, R_CP, R_X1, R_X2, R_COUNT_EXT };   // rho, cp, alphaDT, betaDS rows of the optional-physics build
-// Row aliases of this kernel (what a row holds between which phases):
-//   R_YU/R_YV/R_YS  previous solution until L1 has relaxed, then U, V, buoyancy of the iterate (L1..L6/L7)
-//   R_YT            previous temperature solution (the two EOS items read yT(1) in L1: nothing is written to it
-//                   there), hmin candidates L4..M3, right-hand side from L6
-//   R_GM/R_GT/R_GS  Rig, dbloc, Monin-Obukhov depth L2..L4; gam of the sweeps; rmsd terms in the trap
-//   R_DT/R_DS       Ritop, dVsq L2..L3, then diffusivities;  R_DM  LDD talpha L1..L2, then difm
-//   R_RB            LDD sbeta L1..L2, bulk Ri L3..L4, refined 1/bet from the U sweep; rmsd term in the trap
-//   R_BETM          T for LDD L1..L2, bet from the U sweep;  R_GH  LDD S L1..L2, then ghat
-enum { R_PV = R_YV, R_RAW = R_RB, R_H = R_YT, R_LA = R_DM, R_RITOP = R_DT, R_DVSQ = R_DS };
-
+// LDS rows of a slot and what each holds between which phases of a pass:
+//   Q_DM   (LDD talpha L1..L2)  difm: interior L3, final L5 .. M5 (V sweep, U system's diffusivity)
+//   Q_DT   Ritop L2..L3; dift L3/L5 .. M4, where the T system's gam overwrites it level by level
+//   Q_DS   dVsq L2..L3;  difs likewise, then the S system's gam
+//   Q_YU   previous U solution .. L1; U of the iterate L1..L2; Monin-Obukhov depth L3..L4; rhs L6; solution M4
+//   Q_YT   previous T solution .. L1; dbloc L2..L3; rhs L6; solution M4
+//   Q_YS   previous S solution .. L1; buoyancy L1..L2; hmin candidates L4..M3; rhs L6; solution M4
+//   Q_YV   previous V solution .. L1; V of the iterate L1..L2; bulk Ri L3..L4 (scan M2); ghat L5..L6;
+//          rhs L7; solution M5
+//   Q_GM   Rig L2..L3; gam of the momentum system M4..M5
+//   Q_BET  (LDD T L1..L2) pivots of the momentum system M4..M5
+// In the instability trap Q_DM, Q_DT, Q_DS, Q_GM carry the four rmsd terms, in the isotherm check Q_DM, Q_DT.
+// Optional-physics build: rho, cp (L1..L6), alphaDT, betaDS (L2..L3), LDD sbeta and S (L1..L2).
+enum { Q_DM = 0, Q_DT, Q_DS, Q_YU, Q_YT, Q_YS, Q_YV, Q_GM, Q_BET, Q_COUNT,
+       Q_RHO = Q_COUNT, Q_CP, Q_X1, Q_X2, Q_S1, Q_S2, Q_COUNT_EXT };
 // LDS layout.  A slot's rows are interleaved per level: element (row a, level i) sits at i*ROWS + a
 // doubles, so a level lane reaches all its rows and the rows of its neighbours through ONE base register
 // plus immediate offsets (the column depth, hence any row-major row length, is a run-time value).  ROWS is
-// odd (13 / 15): 32 consecutive levels fall on 32 distinct banks.  The grid constants are interleaved the
+// odd (9 / 15): 32 consecutive levels fall on 32 distinct banks.  The grid constants are interleaved the
 // same way with a stride of 7.  Host and device agree on the sizes through these:
 enum { K_ZM = 0, K_HM, K_T0, K_T1, K_RDZ, K_DTOHK, K_STRIDE = 7 };
-__host__ __device__ inline int ps_rows(bool ext) { return ext ? (int)R_COUNT_EXT : (int)R_COUNT; }
+__host__ __device__ inline int ps_rows(bool ext) { return ext ? (int)Q_COUNT_EXT : (int)Q_COUNT; }
 __host__ __device__ inline int ps_nl(int L) { return L + 2; }   // level indices 0..L+1
 __host__ __device__ inline int ps_ss(int L, bool ext)
 {
@@ -62,10 +67,149 @@ __host__ __device__ inline int ps_ss(int L, bool ext)
   while ((s & 31) != 3) ++s;
   return s;
 }
+__host__ __device__ inline int ps_scratch_ld(int nzp1) { return (nzp1 + 7) & ~7; }   // row length of the iterate's scratch
 __host__ __device__ inline size_t ps_lds_bytes(int L, int W, bool ext)
 {
   return (size_t)(K_STRIDE * ps_nl(L) + 2 + W * ps_ss(L, ext) + W * C_COUNT) * sizeof(double) +
          (size_t)(W * I_COUNT + 4 + 8) * sizeof(int);
+}
+
+
+// ---- the manager wave's Thomas sweeps on this kernel's rows (arithmetic: serial_thomas_uts_n / _v_n of
+// mckpp_sweeps.h, solvers.F90:14-44, 112-161).  lane = (slot, system U|T|S).  The T and S systems store their
+// gam over the diffusivity row they have just consumed (level i's diffusivity is in a register before gam(i)
+// is written); the momentum system keeps difm, gam and its pivots for the V sweep.
+__device__ __forceinline__ void ps_thomas_uts(int W, double *slots, int SS, int KS, int CS, int nz, const double *c_t0,
+                                              const double *c_t1, const int *sact, int sact_stride, int *sbad,
+                                              int sbad_stride, int lane)
+{
+  if (lane < 3 * W) {
+    const int sl = lane / 3, sys = lane - 3 * sl;
+    if (sact[sl * sact_stride]) {
+      double *base = slots + sl * SS;
+      const double *d = base + (Q_DM + sys);
+      double *y = base + (Q_YU + sys), *gm = base + (sys == 0 ? (int)Q_GM : (int)Q_DM + sys);
+      double *betm = base + Q_BET;
+      int bad = 0;
+      double dm1 = d[(1) * KS];
+      double pm1 = c_t1[(1) * CS] * dm1;   // p(1)
+      double bet = 1. + pm1;               // cc(1)
+      double ynum = y[(1) * KS];           // y(1) = rhs(1)/bet, formed in the next level's step
+      unsigned long long rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum));   // wave mask, lives in SGPRs
+      auto level = [&](int i, double di, double t0, double t1, double rhs, auto slow) {
+        if (slow.value && bet == 0.) { bad = 1; bet = 1.E-12; }   // solvers.F90:140-151 would stop here
+        const double clm1 = -pm1;
+        const double q = t0 * dm1;          // -cu(i)
+        const double p = t1 * di;           // -cl(i)
+        const double cc = (1. + p) + q;
+        const double rb = rcp_refine(bet);
+        const double g = slow.value ? div_by_refined(clm1, bet, rb) : div_fast(clm1, bet, rb);
+        const double yprev = slow.value ? div_by_refined(ynum, bet, rb) : div_fast(ynum, bet, rb);
+        if (sys == 0) betm[(i - 1) * KS] = bet;
+        y[(i - 1) * KS] = yprev;
+        gm[(i) * KS] = g;
+        bet = cc + q * g;
+        ynum = rhs + q * yprev;
+        rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum)) | __builtin_amdgcn_ballot_w64(bet == 0.);
+        dm1 = di; pm1 = p;
+      };
+      auto step = [&](int i, double di, double t0, double t1, double rhs) {
+        if (__builtin_expect(rare != 0ull, 0)) level(i, di, t0, t1, rhs, std::true_type{});
+        else level(i, di, t0, t1, rhs, std::false_type{});
+      };
+      {   // two levels per trip; each half's operands are fetched while the other half runs
+        int i = 2;
+        double a_d = d[(2) * KS], a_t0 = c_t0[(2) * CS], a_t1 = c_t1[(2) * CS], a_r = y[(2) * KS];
+        for (; i + 1 <= nz; i += 2) {
+          const double b_d = d[(i + 1) * KS], b_t0 = c_t0[(i + 1) * CS], b_t1 = c_t1[(i + 1) * CS], b_r = y[(i + 1) * KS];
+          step(i, a_d, a_t0, a_t1, a_r);
+          if (i + 2 <= nz) { a_d = d[(i + 2) * KS]; a_t0 = c_t0[(i + 2) * CS]; a_t1 = c_t1[(i + 2) * CS]; a_r = y[(i + 2) * KS]; }
+          step(i + 1, b_d, b_t0, b_t1, b_r);
+        }
+        if (i <= nz) step(i, a_d, a_t0, a_t1, a_r);
+      }
+      if (bet == 0.) { bad = 1; bet = 1.E-12; }
+      double yy = div_by_refined(ynum, bet, rcp_refine(bet));
+      y[(nz) * KS] = yy;
+      if (sys == 0) betm[(nz) * KS] = bet;
+      int i = nz - 1;   // back substitution, operands fetched four levels ahead
+      for (; i >= 4; i -= 4) {
+        const double y0 = y[(i) * KS], y1 = y[(i - 1) * KS], y2 = y[(i - 2) * KS], y3 = y[(i - 3) * KS];
+        const double g0 = gm[(i + 1) * KS], g1 = gm[(i) * KS], g2 = gm[(i - 1) * KS], g3 = gm[(i - 2) * KS];
+        yy = y0 - g0 * yy; const double r0 = yy;
+        yy = y1 - g1 * yy; const double r1 = yy;
+        yy = y2 - g2 * yy; const double r2 = yy;
+        yy = y3 - g3 * yy;
+        y[(i) * KS] = r0; y[(i - 1) * KS] = r1; y[(i - 2) * KS] = r2; y[(i - 3) * KS] = yy;
+      }
+      for (; i >= 1; --i) {
+        yy = y[(i) * KS] - gm[(i + 1) * KS] * yy;
+        y[(i) * KS] = yy;
+      }
+      if (bad) sbad[sl * sbad_stride] = 1;
+    }
+  }
+}
+
+// V on the stored momentum factorisation (pivots, gam); lane = slot.  The refined reciprocal of a pivot is
+// formed again from the pivot (the same value the U sweep used: rcp_refine is a function of its argument),
+// off the dependent chain, when the level's operands are fetched.
+__device__ __forceinline__ void ps_thomas_v(int W, double *slots, int SS, int KS, int CS, int nz, const double *c_t0,
+                                            const int *sact, int sact_stride, int lane)
+{
+  if (lane < W && sact[lane * sact_stride]) {
+    double *base = slots + lane * SS;
+    const double *d = base + Q_DM, *gm = base + Q_GM, *betm = base + Q_BET;
+    double *y = base + Q_YV;
+    const double b1 = betm[(1) * KS];
+    double yy = div_by_refined(y[(1) * KS], b1, rcp_refine(b1));
+    y[(1) * KS] = yy;
+    double dm1 = d[(1) * KS];
+    double nprev = 0.0, bprev = 1.0;
+    unsigned long long rare = 0ull;   // wave mask of lanes whose last numerator was tiny
+    auto vstep = [&](int i, double rhs, double t0, double b, double r, double di) {
+      if (__builtin_expect(rare != 0ull, 0)) {
+        if (tiny_nonzero(nprev)) { yy = nprev / bprev; y[(i - 1) * KS] = yy; }
+      }
+      const double cu = -t0 * dm1;
+      const double n = rhs - cu * yy;
+      yy = div_fast(n, b, r);
+      rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(n));
+      y[(i) * KS] = yy;
+      nprev = n; bprev = b;
+      dm1 = di;
+    };
+    {
+      int i = 2;
+      double a_rhs = y[(2) * KS], a_t0 = c_t0[(2) * CS], a_b = betm[(2) * KS], a_d = d[(2) * KS];
+      double a_r = rcp_refine(a_b);
+      for (; i + 1 <= nz; i += 2) {
+        const double b_rhs = y[(i + 1) * KS], b_t0 = c_t0[(i + 1) * CS], b_b = betm[(i + 1) * KS], b_d = d[(i + 1) * KS];
+        const double b_r = rcp_refine(b_b);
+        vstep(i, a_rhs, a_t0, a_b, a_r, a_d);
+        if (i + 2 <= nz) { a_rhs = y[(i + 2) * KS]; a_t0 = c_t0[(i + 2) * CS]; a_b = betm[(i + 2) * KS]; a_d = d[(i + 2) * KS]; a_r = rcp_refine(a_b); }
+        vstep(i + 1, b_rhs, b_t0, b_b, b_r, b_d);
+      }
+      if (i <= nz) vstep(i, a_rhs, a_t0, a_b, a_r, a_d);
+    }
+    if (__builtin_expect(rare != 0ull, 0)) {
+      if (tiny_nonzero(nprev)) { yy = nprev / bprev; y[(nz) * KS] = yy; }
+    }
+    int i = nz - 1;
+    for (; i >= 4; i -= 4) {
+      const double y0 = y[(i) * KS], y1 = y[(i - 1) * KS], y2 = y[(i - 2) * KS], y3 = y[(i - 3) * KS];
+      const double g0 = gm[(i + 1) * KS], g1 = gm[(i) * KS], g2 = gm[(i - 1) * KS], g3 = gm[(i - 2) * KS];
+      yy = y0 - g0 * yy; const double r0 = yy;
+      yy = y1 - g1 * yy; const double r1 = yy;
+      yy = y2 - g2 * yy; const double r2 = yy;
+      yy = y3 - g3 * yy;
+      y[(i) * KS] = r0; y[(i - 1) * KS] = r1; y[(i - 2) * KS] = r2; y[(i - 3) * KS] = yy;
+    }
+    for (; i >= 1; --i) {
+      yy = y[(i) * KS] - gm[(i + 1) * KS] * yy;
+      y[(i) * KS] = yy;
+    }
+  }
 }
 
 #ifndef MCKPP_PS_MGR_SIMD
@@ -96,7 +240,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 {
   const mckpp_kparams &p = *pp;
   extern __shared__ double lds[];
-  constexpr int ROWS = EXT ? (int)R_COUNT_EXT : (int)R_COUNT;
+  constexpr int ROWS = EXT ? (int)Q_COUNT_EXT : (int)Q_COUNT;
   const int NL = ps_nl(L), SS = ps_ss(L, EXT);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -148,10 +292,11 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   const double epsln16 = 1.e-16, Ricr = 0.30, eps01 = 0.1, cekman = 0.7, cmonob = 1.0, epsln20 = 1.e-20;
   const bool do_ocnint = p.mode == MCKPP_MODE_STEP || p.mode == MCKPP_MODE_PASS;
   const bool flux_diag = p.mode == MCKPP_MODE_STEP || p.mode == MCKPP_MODE_INIT;   // wU, wX(1:nz) of ocnstep / initialize_ocean
-  // the iterate of the under-relaxation between passes: two sets of scratch rows (diagnostic rows that only
-  // a finishing column writes, element index = level-1), read from one set and written to the other
-  double *const xU[2] = {p.wU1, p.difm}, *const xV[2] = {p.wU2, p.difs}, *const xT[2] = {p.wX1, p.dift},
-                *const xS[2] = {p.wX2, p.ghat};
+  // the iterate of the under-relaxation between passes: four scratch rows per (workgroup, slot), element
+  // index = level-1, each element read and rewritten in place by the one item that owns it.  The block is
+  // reused by every column the slot serves, so it stays in L2.
+  const int LS = ps_scratch_ld(nzp1);
+  double *const scr0 = p.scratch + (size_t)blockIdx.x * (size_t)W * (size_t)(4 * LS);
 
 // one level-parallel phase: every active (slot, level) item, strided by the workgroup's threads
 #define FOR_ITEMS                                                                         \
@@ -167,8 +312,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     const bool is1 = k == 1, isnz = k == nz, isnzp1 = k == nzp1;                          \
     const int kr = act ? k : 1;                                                           \
     const size_t ro = (size_t)col * p.ld;                                                 \
+    double *const xs_ = scr0 + (size_t)slot * (size_t)(4 * LS) + (kr - 1);   /* iterate U, V, T, S of this item */ \
     auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };             \
-    (void)sc; (void)actz; (void)virt1; (void)virt2; (void)is1; (void)isnz; (void)isnzp1; (void)kr; (void)ro;
+    (void)sc; (void)actz; (void)virt1; (void)virt2; (void)is1; (void)isnz; (void)isnzp1; (void)kr; (void)ro; (void)xs_;
 #define END_ITEMS }
 
   // =========================== manager phases (wave 0) ===========================
@@ -220,7 +366,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       double *msc = screc + lane * C_COUNT;
       if (msi[I_ACT]) {
         msi[I_LOAD] = 0;
-        msi[I_PAR] = msi[I_PAR] ^ 1;   // L1 has just written the other scratch set
+        msi[I_PAR] = msi[I_PAR] ^ 1;   // L1 has just written the other copy of the iterate's level-1 temperature
         const double rho0 = msc[X_RHO0], cp0 = msc[X_CP0], talpha0 = msc[X_TALPHA0], sbeta0 = msc[X_SBETA0];
         const double rhoh2o = msc[X_RHOH2O], rhob = msc[X_RHOB];
         const double sflux1 = msc[C_SFLUX1], sflux2 = msc[C_SFLUX2], sflux3 = msc[C_SFLUX3], sflux4 = msc[C_SFLUX4],
@@ -260,7 +406,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         msi[I_KBLC] = 0x7fffffff;
         int kbl = nz;
         double hbl = -c_zm[nz];
-        if (kc <= nz) { kbl = kc; hbl = mrow[kc * ROWS + R_H]; }
+        if (kc <= nz) { kbl = kc; hbl = mrow[kc * ROWS + Q_YS]; }
         msi[I_KBL] = kbl;
         msc[C_HBL] = hbl;
         const int jer = msi[I_JER];
@@ -284,7 +430,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           const double r_hmkn = rcp_refine(hmkn), r_hmkn1 = rcp_refine(hmkn1);
           double delhat = 0.5 * hmkn - c_zm[kn] - hbl;
           double R = 1.0 - div_fast(delhat, hmkn, r_hmkn);
-          const strided<ROWS> dd[3] = {{mrow + R_DM}, {mrow + R_DS}, {mrow + R_DT}};
+          const strided<ROWS> dd[3] = {{mrow + Q_DM}, {mrow + Q_DS}, {mrow + Q_DT}};
           double dp[3], dh[3];
 #pragma unroll
           for (int m = 0; m < 3; ++m) {
@@ -385,7 +531,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
                      double &rhsS) {
     const double dto = p.dto;
     const double *xs = p.xs + (size_t)col * MCKPP_XS;
-    const double rhok = my[k * ROWS + R_RHO], cpk = my[k * ROWS + R_CP];
+    const double rhok = my[k * ROWS + Q_RHO], cpk = my[k * ROWS + Q_CP];
     const size_t oin = (size_t)col * p.ld + (k - 1);
     if (k == 1) {
       if (p.L_RELAX_SST && !p.L_FCORR_WITHZ && !p.L_FCORR) {   // :97-114
@@ -498,9 +644,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           S = 2. * sn - so;
           yu = U; yv = V; yt = T; ys = S;
         } else {
-          U = act ? xU[par][o] : 0.0; V = act ? xV[par][o] : 0.0; S = act ? xS[par][o] : 0.0;
-          T = act ? xT[par][o] : sc[C_T1X + par];   // scratch rows are read back by the thread that wrote them only
-          yu = row(R_YU)[k]; yv = row(R_YV)[k]; yt = row(R_YT)[kr]; ys = row(R_YS)[k];
+          U = act ? xs_[0] : 0.0; V = act ? xs_[LS] : 0.0; S = act ? xs_[3 * LS] : 0.0;
+          T = act ? xs_[2 * LS] : sc[C_T1X + par];   // the two EOS items follow level 1, whose item rewrites it now
+          yu = row(Q_YU)[k]; yv = row(Q_YV)[k]; yt = row(Q_YT)[kr]; ys = row(Q_YS)[k];
         }
         // under-relaxation, ocnstep_mod.F90:123-132 / :142-151 (an EOS item follows level 1's temperature)
         T = lambda * T + (1 - lambda) * yt;
@@ -508,7 +654,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           U = lambda * U + (1 - lambda) * yu;
           V = lambda * V + (1 - lambda) * yv;
           S = lambda * S + (1 - lambda) * ys;
-          xU[par ^ 1][o] = U; xV[par ^ 1][o] = V; xT[par ^ 1][o] = T; xS[par ^ 1][o] = S;
+          xs_[0] = U; xs_[LS] = V; xs_[2 * LS] = T; xs_[3 * LS] = S;
           if (is1) sc[C_T1X + (par ^ 1)] = T;
         }
       } else {
@@ -529,16 +675,16 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       if (is1) { sc[X_RHO0] = rho; sc[X_CP0] = cp; sc[X_TALPHA0] = talpha; sc[X_SBETA0] = sbeta; }
       if (virt1) sc[X_RHOH2O] = rho;
       if (virt2) sc[X_RHOB] = rho;
-      if (act) { row(R_YU)[k] = U; row(R_PV)[k] = V; row(R_YS)[k] = buoy; }
+      if (act) { row(Q_YU)[k] = U; row(Q_YV)[k] = V; row(Q_YS)[k] = buoy; }
       if (p.diag && si[I_MAYBE]) {   // what the last vmix leaves behind (types_transfer.F90:199-327)
         const size_t od = ro + k;
         if (act) { p.rho[od] = rho; p.cp[od] = cp; p.buoy[od] = buoy; p.talpha[od] = talpha; p.sbeta[od] = sbeta; }
         if (is1) { p.rho[od - 1] = rho; p.cp[od - 1] = cp; p.talpha[od - 1] = talpha; p.sbeta[od - 1] = sbeta; }
       }
       if constexpr (EXT) {
-        if (act) { row(R_RHO)[k] = rho; row(R_CP)[k] = cp; }
+        if (act) { row(Q_RHO)[k] = rho; row(Q_CP)[k] = cp; }
         if (p.LDD && act) {   // neighbours for alphaDT, betaDS
-          row(R_LA)[k] = talpha; row(R_RB)[k] = sbeta; row(R_GH)[k] = S; row(R_BETM)[k] = T;
+          row(Q_DM)[k] = talpha; row(Q_S1)[k] = sbeta; row(Q_S2)[k] = S; row(Q_BET)[k] = T;
         }
       }
     END_ITEMS
@@ -549,7 +695,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     // ---- M1 | L2: surface fluxes (wave 0) | reference-level loop, Ri pieces (verticalmixing_mod.F90:111-137)
     if (wv == mgr) M1();
     FOR_ITEMS
-      const strided<ROWS> aU = row(R_YU), aV = row(R_PV), aB = row(R_YS);
+      const strided<ROWS> aU = row(Q_YU), aV = row(Q_YV), aB = row(Q_YS);
       const double U = act ? aU[k] : 0.0, V = act ? aV[k] : 0.0, buoy = aB[k];
       const double zmk = c_zm[k];
       const double zm1 = c_zm[1];
@@ -576,9 +722,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       }
       if constexpr (EXT) {
         if (p.LDD && act) {   // verticalmixing_mod.F90:103-108
-          const double talpha = row(R_LA)[k], sbeta = row(R_RB)[k], T = row(R_BETM)[k], S = row(R_GH)[k];
-          row(R_X1)[k] = 0.5 * (talpha + row(R_LA)[k + 1]) * (T - row(R_BETM)[k + 1]);
-          row(R_X2)[k] = 0.5 * (sbeta + row(R_RB)[k + 1]) * (S - row(R_GH)[k + 1]);
+          const double talpha = row(Q_DM)[k], sbeta = row(Q_S1)[k], T = row(Q_BET)[k], S = row(Q_S2)[k];
+          row(Q_X1)[k] = 0.5 * (talpha + row(Q_DM)[k + 1]) * (T - row(Q_BET)[k + 1]);
+          row(Q_X2)[k] = 0.5 * (sbeta + row(Q_S1)[k + 1]) * (S - row(Q_S2)[k + 1]);
         }
       }
       const double bk1 = aB[k + 1], uk1 = aU[k + 1], vk1 = aV[k + 1];
@@ -590,9 +736,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       const double zdiff = zmk - c_zm[k + 1];
       const double shs = shsq + 1.e-16;
       const double Rig = div_fast(dbloc * zdiff, shs, rcp_refine(shs));
-      if (actz) { row(R_R)[k] = Rig; row(R_DB)[k] = dbloc; row(R_RITOP)[k] = Ritop; row(R_DVSQ)[k] = dVsq; }
-      if (is1) row(R_R)[0] = 0.0;
-      if (isnzp1) row(R_R)[k] = 0.0;
+      if (actz) { row(Q_GM)[k] = Rig; row(Q_YT)[k] = dbloc; row(Q_DT)[k] = Ritop; row(Q_DS)[k] = dVsq; }
+      if (is1) row(Q_GM)[0] = 0.0;
+      if (isnzp1) row(Q_GM)[k] = 0.0;
       if (p.diag && si[I_MAYBE]) {
         const size_t od = ro + k;
         if (actz) { p.Rig[od] = Rig; p.dbloc[od] = dbloc; p.Shsq[od] = shsq; }
@@ -606,9 +752,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     //          bldepth, level-parallel part (bldepth_mod.F90:105-147)
     FOR_ITEMS
       if (!act) continue;
-      const strided<ROWS> aR = row(R_R), aDb = row(R_DB);
+      const strided<ROWS> aR = row(Q_GM), aDb = row(Q_YT);
       const double zmk = c_zm[k], zdiff = zmk - c_zm[k + 1];
-      const double Rig = aR[k], dbloc = aDb[k], Ritop = row(R_RITOP)[k], dVsq = row(R_DVSQ)[k];
+      const double Rig = aR[k], dbloc = aDb[k], Ritop = row(Q_DT)[k], dVsq = row(Q_DS)[k];
       const double Riinfty = 0.8;
       double vm1 = aR[k - 1], vp1 = aR[k + 1];
       double wm1 = (k - 1 >= 1 && !((vm1 < 0.0) || (vm1 > Riinfty))) ? 1.0 : 0.0;
@@ -626,7 +772,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       if constexpr (EXT) {
         if (p.LDD) {   // ddmix_mod.F90:12-52
           const double Rrho0 = 1.9, dsfmax = 1.0e-4;
-          const double aDT = row(R_X1)[k], bDS = row(R_X2)[k];
+          const double aDT = row(Q_X1)[k], bDS = row(Q_X2)[k];
           if ((aDT > bDS) && (bDS > 0.)) {
             double Rrho = dmin2(aDT / bDS, Rrho0);
             double rr = ((Rrho - 1) / (Rrho0 - 1));
@@ -662,18 +808,18 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       double dmo = div_fast(div_fast(cmonob * ustar * ustar * ustar, p.vonk, c_misc[1]), bfa, rcp_refine(bfa));
       dmo = st * dmo - (1. - st) * zm_kmp1;
       // interior diffusivities (after the reads of Ritop / dVsq, which share their rows)
-      if (actz) { row(R_DM)[k] = dm_i; row(R_DS)[k] = ds_i; row(R_DT)[k] = dt_i; }
-      if (isnz) { row(R_DM)[k + 1] = dm_i; row(R_DS)[k + 1] = ds_i; row(R_DT)[k + 1] = dt_i; }   // kppmix_mod.F90:82-84
-      if (is1) { row(R_DM)[0] = 0.0; row(R_DS)[0] = 0.0; row(R_DT)[0] = 0.0; }
-      if (k >= 2 && actz) { row(R_RAW)[k] = raw; row(R_DMO)[k] = dmo; }
-      if (is1) { row(R_RAW)[1] = 0.0; row(R_DMO)[1] = -zm_kmp1; }
+      if (actz) { row(Q_DM)[k] = dm_i; row(Q_DS)[k] = ds_i; row(Q_DT)[k] = dt_i; }
+      if (isnz) { row(Q_DM)[k + 1] = dm_i; row(Q_DS)[k + 1] = ds_i; row(Q_DT)[k + 1] = dt_i; }   // kppmix_mod.F90:82-84
+      if (is1) { row(Q_DM)[0] = 0.0; row(Q_DS)[0] = 0.0; row(Q_DT)[0] = 0.0; }
+      if (k >= 2 && actz) { row(Q_YV)[k] = raw; row(Q_YU)[k] = dmo; }
+      if (is1) { row(Q_YV)[1] = 0.0; row(Q_YU)[1] = -zm_kmp1; }
     END_ITEMS
     STAMP(4);
     __syncthreads();
     STAMP(5);
 
     // ---- M2: Rib(ku) = MAX(Rib(ku), Rib(ka)+epsln), bldepth_mod.F90:137
-    if (wv == mgr) { PRIO_HI(); serial_scan_rib_n(W, R_RAW, slots, SS, 1, ROWS, nz, sirec + I_ACT, I_COUNT, lane); PRIO_LO(); }
+    if (wv == mgr) { PRIO_HI(); serial_scan_rib_n(W, Q_YV, slots, SS, 1, ROWS, nz, sirec + I_ACT, I_COUNT, lane); PRIO_LO(); }
     STAMP(6);
     __syncthreads();
     STAMP(7);
@@ -681,7 +827,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     // ---- L4: first level with hmin < -zm(k) (bldepth_mod.F90:139-180): every hit level posts its hmin,
     //          the shallowest one wins through an LDS minimum
     FOR_ITEMS
-      const strided<ROWS> aRaw = row(R_RAW), aDmo = row(R_DMO);
+      const strided<ROWS> aRaw = row(Q_YV), aDmo = row(Q_YU);
       const double zmk = c_zm[k];
       const double ocdepth = sc[C_OCDEPTH];
       const double zm_kmp1 = c_zm[nzp1];
@@ -707,7 +853,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         double hmin2 = dmin2(dmin2(hri, hmonob), -ocdepth);
         if (hmin2 < -zmk) hmin = hmin2;
       }
-      if (hit) row(R_H)[k] = hmin;
+      if (hit) row(Q_YS)[k] = hmin;
       // only a hit whose shallower neighbour (same wave, same column since k >= 2) did not hit can be the first
       const unsigned long long m = __ballot(hit);
       const bool prev = lane > 0 && ((m >> (lane - 1)) & 1ull);
@@ -729,7 +875,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       if (!act) continue;
       const int kbl = si[I_KBL];
       const double zmk = c_zm[k];
-      const double dm_i = row(R_DM)[k], ds_i = row(R_DS)[k], dt_l = row(R_DT)[k];   // interior values of L3
+      const double dm_i = row(Q_DM)[k], ds_i = row(Q_DS)[k], dt_l = row(Q_DT)[k];   // interior values of L3
       double difm = dm_i, difs = ds_i, dift = dt_l, ghat = 0.;
       if (k < kbl) {
         const double hbl = sc[C_HBL], r_hbl = sc[C_RHBL], stable = sc[C_STABLE], bfsfc = sc[C_BFSFC];
@@ -769,7 +915,12 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         difm = b0; difs = b1; dift = b2; ghat = gh;
       }
       if (k >= nz) { difm = 0.0001; difs = 0.00001; dift = 0.00001; ghat = 0.0; }
-      row(R_DM)[k] = difm; row(R_DS)[k] = difs; row(R_DT)[k] = dift; row(R_GH)[k] = ghat;
+      row(Q_DM)[k] = difm; row(Q_DS)[k] = difs; row(Q_DT)[k] = dift; row(Q_YV)[k] = ghat;
+      if (p.diag && si[I_MAYBE]) {   // the sweeps reuse these rows: what the last vmix leaves behind goes out now
+        const size_t od = ro + k;
+        p.difm[od] = difm; p.difs[od] = difs; p.dift[od] = dift;
+        if (actz) p.ghat[od] = ghat;
+      }
     END_ITEMS
     STAMP(12);
     __syncthreads();
@@ -779,16 +930,16 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     if (do_ocnint) {
       FOR_ITEMS
         if (!act) continue;
-        const strided<ROWS> aDt = row(R_DT), aDs = row(R_DS), aGh = row(R_GH);
+        const strided<ROWS> aDt = row(Q_DT), aDs = row(Q_DS), aGh = row(Q_YV);
         const double f = sc[C_F];
         const size_t o = ro + (k - 1);
         const double Uo = p.U[o], Vo = p.V[o], To = p.T[o], So = p.S[o];
         const double dto = p.dto, tri1_nz = c_t1[nz];
         const double wX0_1 = sc[C_WX01], wX0_2 = sc[C_WX02];
-        const strided<ROWS> yU = row(R_YU), yT = row(R_YT), yS = row(R_YS);
+        const strided<ROWS> yU = row(Q_YU), yT = row(Q_YT), yS = row(Q_YS);
         if (actz) {
-          const double V = row(R_PV)[k];
-          const double difm = row(R_DM)[k], difs = aDs[k], dift = aDt[k], ghat = aGh[k];
+          const double V = xs_[LS];   // of the iterate (its row holds ghat by now)
+          const double difm = row(Q_DM)[k], difs = aDs[k], dift = aDt[k], ghat = aGh[k];
           const int jer = si[I_JER];
           const double rho0cp0 = sc[C_RHO0CP0], r_rc = sc[C_RRC], sflux3 = sc[C_SFLUX3];
           const double dt_m1 = aDt[k - 1], ds_m1 = aDs[k - 1];
@@ -827,8 +978,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     // ---- M4: Thomas factorise + sweep for U, T, S (solvers.F90:14-44, 112-161)
     if (wv == mgr && do_ocnint) {
       PRIO_HI();
-      serial_thomas_uts_n(W, slots, SS, 1, ROWS, K_STRIDE, nz, cst + K_T0, cst + K_T1, sirec + I_ACT, I_COUNT,
-                          sirec + I_BAD, I_COUNT, lane);
+      ps_thomas_uts(W, slots, SS, ROWS, K_STRIDE, nz, cst + K_T0, cst + K_T1, sirec + I_ACT, I_COUNT, sirec + I_BAD,
+                    I_COUNT, lane);
       PRIO_LO();
     }
     STAMP(16);
@@ -842,13 +993,13 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         const size_t o = ro + (k - 1);
         const double Uo = p.U[o], Vo = p.V[o];
         const double dto = p.dto, f = sc[C_F];
-        const strided<ROWS> yU = row(R_YU), yV = row(R_YV);
+        const strided<ROWS> yU = row(Q_YU), yV = row(Q_YV);
         if (actz) {
           const double un = yU[k];
           double rhsV;
           if (k == 1) rhsV = Vo - dto * (f * .5 * (Uo + un) + div_fast(sc[C_WU02], c_hm[1], c_misc[0]));
           else rhsV = Vo - dto * f * .5 * (Uo + un);
-          if (k == nz) rhsV = rhsV + c_t1[nz] * row(R_DM)[k] * p.V[ro + (nzp1 - 1)];
+          if (k == nz) rhsV = rhsV + c_t1[nz] * row(Q_DM)[k] * p.V[ro + (nzp1 - 1)];
           yV[k] = rhsV;
         } else {
           yV[k] = Vo;
@@ -862,7 +1013,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     // ---- M5: Thomas sweep for V on the stored momentum factorisation; ocnstep control
     if (wv == mgr) {
       PRIO_HI();
-      if (do_ocnint) serial_thomas_v_n(W, slots, SS, 1, ROWS, K_STRIDE, nz, cst + K_T0, sirec + I_ACT, I_COUNT, lane);
+      if (do_ocnint) ps_thomas_v(W, slots, SS, ROWS, K_STRIDE, nz, cst + K_T0, sirec + I_ACT, I_COUNT, lane);
       G();
       PRIO_LO();
     }
@@ -873,12 +1024,12 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 
     // =========================== finish round ===========================
     // instability trap (ocnstep_mod.F90:200-236), then retry or outputs + check_profile.  The profiles of a
-    // finishing slot are what the last ocnint returned: they stay in the slot's solution rows (R_YU, R_YV,
-    // R_YT, R_YS) and every sub-phase works on them in place.  INIT / VMIX have no solution: U,V,T,S are the
+    // finishing slot are what the last ocnint returned: they stay in the slot's solution rows (Q_YU, Q_YV,
+    // Q_YT, Q_YS) and every sub-phase works on them in place.  INIT / VMIX have no solution: U,V,T,S are the
     // column's own rows in HBM.
     FOR_ITEMS
       if (si[I_FIN] != F_TRAP) continue;   // :200-207
-      const double U = row(R_YU)[k], V = row(R_YV)[k], T = row(R_YT)[k], tk1 = row(R_YT)[k + 1];
+      const double U = row(Q_YU)[k], V = row(Q_YV)[k], T = row(Q_YT)[k], tk1 = row(Q_YT)[k + 1];
       const bool v = actz && (__builtin_fabs(U) >= 10 || __builtin_fabs(V) >= 10 || __builtin_fabs(T - tk1) >= 10);
       if (v) atomicAdd(&si[I_NVIOL], 1);
     END_ITEMS
@@ -886,29 +1037,28 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     FOR_ITEMS
       if (!(si[I_FIN] == F_TRAP && si[I_NVIOL] == 0 && act)) continue;   // :208-219
       const size_t o = ro + (k - 1);
-      const double U = row(R_YU)[k], V = row(R_YV)[k], T = row(R_YT)[k], S = row(R_YS)[k];
+      const double U = row(Q_YU)[k], V = row(Q_YV)[k], T = row(Q_YT)[k], S = row(Q_YS)[k];
       const double Uo = p.U[o], Vo = p.V[o], To = p.T[o], So = p.S[o];
       const double hk = c_hm[k];
-      row(R_GM)[k] = (U - Uo) * (U - Uo) * hk / p.dm_nz;
-      row(R_GT)[k] = (V - Vo) * (V - Vo) * hk / p.dm_nz;
-      row(R_GS)[k] = (T - To) * (T - To) * hk / p.dm_nz;
-      row(R_RB)[k] = (S - So) * (S - So) * hk / p.dm_nz;
+      row(Q_DM)[k] = (U - Uo) * (U - Uo) * hk / p.dm_nz;
+      row(Q_DT)[k] = (V - Vo) * (V - Vo) * hk / p.dm_nz;
+      row(Q_DS)[k] = (T - To) * (T - To) * hk / p.dm_nz;
+      row(Q_GM)[k] = (S - So) * (S - So) * hk / p.dm_nz;
     END_ITEMS
     __syncthreads();
     if (wv == mgr) {   // trap decision, one lane per (slot, profile) for the rmsd sums, then one per slot
-      bool over = false;
-      if (lane < 4 * W) {
-        const int ms = lane >> 2, mq = lane & 3;
-        const int *msi = sirec + ms * I_COUNT;
+      if (lane < W) sirec[lane * I_COUNT + I_NOVER] = 0;
+      for (int l = lane; l < 4 * W; l += 64) {
+        const int ms = l >> 2, mq = l & 3;
+        int *msi = sirec + ms * I_COUNT;
         if (msi[I_ACT] && msi[I_FIN] == F_TRAP && msi[I_NVIOL] == 0) {
-          const strided<ROWS> t{slots + ms * SS + (mq == 3 ? (int)R_RB : (int)R_GM + mq)};
+          const strided<ROWS> t{slots + ms * SS + (mq == 3 ? (int)Q_GM : (int)Q_DM + mq)};
           double sum = 0.;
           for (int q = 1; q <= nzp1; ++q) sum = sum + t[q];
           sum = __builtin_sqrt(sum);
-          over = sum >= 1.0;
+          if (sum >= 1.0) atomicAdd(&msi[I_NOVER], 1);
         }
       }
-      const unsigned long long mo = __ballot(over);
       if (lane < W) {
         int *msi = sirec + lane * I_COUNT;
         double *msc = screc + lane * C_COUNT;
@@ -920,7 +1070,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
             comp_flag = 1;
             for (int i = 0; i < nviol; ++i) f = f * 1.01;
           } else {
-            const int nover = __popcll((mo >> (4 * lane)) & 0xFull);
+            const int nover = msi[I_NOVER];
             if (nover > 0) {
               comp_flag = 1;
               for (int i = 0; i < nover; ++i) f = f * 1.01;
@@ -949,24 +1099,20 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       const size_t o = ro + (k - 1);
       double U = 0, V = 0, T = 0, S = 0, uk1 = 0, vk1 = 0, tk1 = 0, sk1 = 0;
       if (act) {
-        if (sol) { U = row(R_YU)[k]; V = row(R_YV)[k]; T = row(R_YT)[k]; S = row(R_YS)[k]; }
+        if (sol) { U = row(Q_YU)[k]; V = row(Q_YV)[k]; T = row(Q_YT)[k]; S = row(Q_YS)[k]; }
         else { U = p.U[o]; V = p.V[o]; T = p.T[o]; S = p.S[o]; }
       }
       if (actz && p.diag && flux_diag) {
-        if (sol) { uk1 = row(R_YU)[k + 1]; vk1 = row(R_YV)[k + 1]; tk1 = row(R_YT)[k + 1]; sk1 = row(R_YS)[k + 1]; }
+        if (sol) { uk1 = row(Q_YU)[k + 1]; vk1 = row(Q_YV)[k + 1]; tk1 = row(Q_YT)[k + 1]; sk1 = row(Q_YS)[k + 1]; }
         else { uk1 = p.U[o + 1]; vk1 = p.V[o + 1]; tk1 = p.T[o + 1]; sk1 = p.S[o + 1]; }
       }
       if (p.diag) {
         const double wX0_1 = sc[C_WX01], wX0_2 = sc[C_WX02];
         const double rho0cp0 = sc[C_RHO0CP0], sflux3 = sc[C_SFLUX3];
         const size_t od = ro + k;
-        // the difm, difs, dift, ghat, wU, wX rows of HBM double as the iterate's scratch sets: a finishing
-        // column's diagnostics are written only now that no pass reads them any more
-        if (act) {
-          const double dfm = row(R_DM)[k], dfs = row(R_DS)[k], dft = row(R_DT)[k], gh = row(R_GH)[k];
-          p.difm[od] = dfm; p.difs[od] = dfs; p.dift[od] = dft;
+        {
           if (actz) {
-            p.ghat[od] = gh;
+            const double dfm = p.difm[od], dfs = p.difs[od], dft = p.dift[od], gh = p.ghat[od];   // stored by L5 of this pass
             p.wXNT1[od] = (ntime >= 1) ? -sflux3 * p.swdk_tab[si[I_JER] * p.ldc + k] / rho0cp0 : 0.0;
             if (flux_diag) {
               const double talpha = p.talpha[od], sbeta = p.sbeta[od];   // of the last vmix (L1 of this pass)
@@ -998,16 +1144,14 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           const double rr = (double)p.dt_uvdamp * (86400. / p.dto);
           double a = 0.99 * __builtin_fabs(U), b = (U * U) / rr;
           if (b < a) atomicAdd(&si[I_NU], 1);
-          row(R_YU)[k] = U - dsign(dmin2(a, b), U);
+          row(Q_YU)[k] = U - dsign(dmin2(a, b), U);
           a = 0.99 * __builtin_fabs(V); b = (V * V) / rr;
           if (b < a) atomicAdd(&si[I_NV], 1);
-          row(R_YV)[k] = V - dsign(dmin2(a, b), V);
+          row(Q_YV)[k] = V - dsign(dmin2(a, b), V);
         }
       }
     END_ITEMS
-    // wX(0..nz), wU rows hold final values now, but the scratch sets alias them: a slot that is NOT finishing
-    // must not have been disturbed - it was not (only its own column's rows are touched by a slot).
-    if constexpr (EXT) __syncthreads();
+    __syncthreads();   // the k+1 neighbours above are read from the rows that check_profile rewrites below
     // ---- STEP: new time level, check_profile (overrides.F90:42-125); the optional parts count over all
     // levels of the column: LDS counters between workgroup barriers (EXT build).
     FOR_ITEMS
@@ -1015,17 +1159,17 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       const size_t o = ro + (k - 1);
       const int newi = 1 - si[I_NEW];   // old = new; new = 1 - old
       double U = 0, V = 0, T = 0, S = 0;
-      if (act) { U = row(R_YU)[k]; V = row(R_YV)[k]; T = row(R_YT)[k]; S = row(R_YS)[k]; }
+      if (act) { U = row(Q_YU)[k]; V = row(Q_YV)[k]; T = row(Q_YT)[k]; S = row(Q_YS)[k]; }
       if (act) { p.Us[newi][o] = U; p.Vs[newi][o] = V; p.Ts[newi][o] = T; p.Ss[newi][o] = S; }
       if (si[I_COMP] && act) {   // overrides.F90:57-78
-        if (EXT && p.clim_present) { T = p.ocnT_clim[o]; S = p.sal_clim[o]; row(R_YT)[k] = T; row(R_YS)[k] = S; }
+        if (EXT && p.clim_present) { T = p.ocnT_clim[o]; S = p.sal_clim[o]; row(Q_YT)[k] = T; row(Q_YS)[k] = S; }
         U = p.U_init[o]; V = p.V_init[o];
-        row(R_YU)[k] = U; row(R_YV)[k] = V;
+        row(Q_YU)[k] = U; row(Q_YV)[k] = V;
       }
       if constexpr (EXT) {
         if (si[I_LOCEAN] && p.L_NO_FREEZE && act) {   // :85-94
           double xt = p.tinc_fcorr[ro + k];
-          if (T < -1.8) { xt = xt + (-1.8 - T); T = -1.8; row(R_YT)[k] = T; atomicAdd(&si[I_NF], 1); }
+          if (T < -1.8) { xt = xt + (-1.8 - T); T = -1.8; row(Q_YT)[k] = T; atomicAdd(&si[I_NF], 1); }
           p.tinc_fcorr[ro + k] = xt;
         }
       }
@@ -1037,8 +1181,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         if (!(si[I_FIN] == F_FINAL && p.mode == MCKPP_MODE_STEP && si[I_LOCEAN] && p.L_NO_ISOTHERM)) continue;
         if (k >= 2 && act) {
           const double dz = c_zm[k] - c_zm[k - 1];
-          row(R_GM)[k] = __builtin_fabs((row(R_YT)[k] - row(R_YT)[k - 1])) * dz;
-          row(R_GT)[k] = dz;
+          row(Q_DM)[k] = __builtin_fabs((row(Q_YT)[k] - row(Q_YT)[k - 1])) * dz;
+          row(Q_DT)[k] = dz;
         }
       END_ITEMS
       __syncthreads();
@@ -1054,7 +1198,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         bool iso_reset = false;
         if constexpr (EXT) {
           if (si[I_LOCEAN] && p.L_NO_ISOTHERM) {
-            const strided<ROWS> tD = row(R_GM), tZ = row(R_GT);
+            const strided<ROWS> tD = row(Q_DM), tZ = row(Q_DT);
             double dtdz_total = 0., dz_total = 0.;
             for (int q = 2; q <= p.iso_bot; ++q) {
               dtdz_total = dtdz_total + tD[q];
@@ -1072,7 +1216,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           reset_out = 0.0;     // :121-123 (no isotherm check in the default physics)
         }
         if (act) {
-          double U = row(R_YU)[k], V = row(R_YV)[k], T = row(R_YT)[k], S = row(R_YS)[k];
+          double U = row(Q_YU)[k], V = row(Q_YV)[k], T = row(Q_YT)[k], S = row(Q_YS)[k];
           if (EXT && iso_reset) { T = p.ocnT_clim[o]; S = p.sal_clim[o]; }
           p.U[o] = U; p.V[o] = V; p.T[o] = T; p.S[o] = S;
         }
@@ -1121,7 +1265,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         }
       } else {
         if (p.mode == MCKPP_MODE_PASS && act) {
-          p.U[o] = row(R_YU)[k]; p.V[o] = row(R_YV)[k]; p.T[o] = row(R_YT)[k]; p.S[o] = row(R_YS)[k];
+          p.U[o] = row(Q_YU)[k]; p.V[o] = row(Q_YV)[k]; p.T[o] = row(Q_YT)[k]; p.S[o] = row(Q_YS)[k];
         }
         if (is1) {
           cs[CS_HMIX] = sc[C_HBL];
@@ -1148,30 +1292,50 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 
 struct ps_geom { int nw, w, per_cu; };
 
-// Slots per workgroup / waves / workgroups per CU: what keeps most columns in flight on a CU - two workgroups of
-// 8 waves or one of 16 (128 VGPRs: 16 waves per CU), each with as many slots as its share of the LDS holds
-// (<= 16: four manager lanes per slot in the trap) - and no more waves than the items need.
+// Slots per workgroup / waves / workgroups per CU.  A pass of a workgroup is its manager wave's serial phases
+// (independent of the number of slots, ~0.9 k cycles per level) plus its level phases (~25 k cycles per trip of the
+// item loop, 40 k when one 16-wave workgroup has the CU to itself and nothing overlaps its barriers) plus ~12 k of
+// barriers and finish rounds; 128 VGPRs allow 16 waves per CU.  The rate is slots in flight / pass time: take the
+// geometry that maximises it under the LDS each workgroup's slots need.  <= 21 slots: three manager lanes per slot.
 ps_geom ps_choose(int L, bool ext, size_t cu_lds_bytes)
 {
   auto granules = [&](int w_) { return (ps_lds_bytes(L, w_, ext) + 1279) / 1280 * 1280; };
-  int w2 = 16, w1 = 16;
-  while (w2 > 1 && 2 * granules(w2) > cu_lds_bytes) --w2;
-  while (w1 > 1 && granules(w1) > cu_lds_bytes) --w1;
-  ps_geom g;
-  if (w1 > 2 * w2) g = {16, w1, 1};
-  else g = {8, w2, 2};
-  const int need = (g.w * L + 63) / 64;
-  if (need < g.nw) g.nw = need;
-  if (g.per_cu * g.nw < 16 && g.per_cu == 2 && 16 / g.nw > 2) {   // small columns: more, smaller workgroups
-    g.per_cu = 16 / g.nw;
-    while (g.per_cu > 2 && (size_t)g.per_cu * granules(g.w) > cu_lds_bytes) --g.per_cu;
+  ps_geom best = {1, 1, 1};
+  double best_rate = 0.0;
+  for (int per_cu = 1; per_cu <= 4; per_cu *= 2) {
+    const int nw = 16 / per_cu, threads = 64 * nw;
+    const double trip = per_cu == 1 ? 40.e3 : 25.e3;
+    for (int w = 1; w <= 21; ++w) {
+      if ((size_t)per_cu * granules(w) > cu_lds_bytes) break;
+      const int trips = (w * L + threads - 1) / threads;
+      const double pass = 0.9e3 * L + trip * trips + 12.e3;
+      const double rate = per_cu * w / pass;
+      if (rate > best_rate * 1.0001) { best_rate = rate; best = {nw, w, per_cu}; }
+    }
+  }
+  const int need = (best.w * L + 63) / 64;
+  if (need < best.nw) best.nw = need;
+  return best;
+}
+
+ps_geom ps_geometry(int L, bool ext)   // MCKPP_PS=<slots>x<waves>x<workgroups per CU> overrides the choice (experiments)
+{
+  ps_geom g = ps_choose(L, ext, (size_t)160 * 1024);
+  if (const char *e = getenv("MCKPP_PS")) {
+    int w = 0, nw = 0, b = 0;
+    if (sscanf(e, "%dx%dx%d", &w, &nw, &b) == 3 && w >= 1 && w <= 21 && nw >= 1 && nw <= 16 && b >= 1) g = {nw, w, b};
   }
   return g;
 }
 
 }  // namespace
 
-// MCKPP_PS=<slots>x<waves>x<workgroups per CU> overrides the geometry (experiments).
+size_t mckpp_ps_scratch_doubles(int nzp1, int ext, int num_cu)
+{
+  const ps_geom g = ps_geometry(nzp1 + 2, ext != 0);
+  return (size_t)num_cu * g.per_cu * g.w * 4 * ps_scratch_ld(nzp1);
+}
+
 hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu, hipStream_t stream,
                                          mckpp_launch_info *info)
 {
@@ -1179,11 +1343,8 @@ hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kpa
   const int L = p.nzp1 + 2;
   if (L > 1024) return hipErrorInvalidValue;
   const bool ext = p.ext != 0;
-  ps_geom g = ps_choose(L, ext, (size_t)160 * 1024);
-  if (const char *e = getenv("MCKPP_PS")) {
-    int w = 0, nw = 0, b = 0;
-    if (sscanf(e, "%dx%dx%d", &w, &nw, &b) == 3 && w >= 1 && w <= 16 && nw >= 1 && nw <= 16 && b >= 1) g = {nw, w, b};
-  }
+  const ps_geom g = ps_geometry(L, ext);
+  if (!p.scratch || p.scratch_doubles < mckpp_ps_scratch_doubles(p.nzp1, p.ext, num_cu)) return hipErrorInvalidValue;
   const size_t lds = ps_lds_bytes(L, g.w, ext);
   if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
   const void *fn = ext ? reinterpret_cast<const void *>(k_column_ps<true>) : reinterpret_cast<const void *>(k_column_ps<false>);
@@ -1197,6 +1358,16 @@ hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kpa
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * g.nw, lds) != hipSuccess) nb = 0;
     *info = {nblocks, 64 * g.nw, nb, lds};
+  }
+  if (getenv("MCKPP_PS_VERBOSE")) {
+    static bool said = false;
+    if (!said) {
+      said = true;
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * g.nw, lds) != hipSuccess) nb = -1;
+      fprintf(stderr, "[mckpp ps] L=%d: %d slots x %d waves x %d workgroups per CU, %zu B of LDS each, %d fit on a CU, %d workgroups\n",
+              L, g.w, g.nw, g.per_cu, lds, nb, nblocks);
+    }
   }
   const unsigned Lmagic = (unsigned)(0x100000000ull / (unsigned long long)L) + 1u;   // it / L == umulhi(it, Lmagic) for it < 2^20
   if (ext) hipLaunchKernelGGL(k_column_ps<true>, dim3((unsigned)nblocks), dim3(64 * g.nw), lds, stream, dp, p.ntime, L, g.w, Lmagic);

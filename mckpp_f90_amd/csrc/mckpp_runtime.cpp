@@ -87,6 +87,8 @@ struct mckpp_hip_ctx {
   int *d_qhead = nullptr;
   unsigned long long *d_dbg = nullptr;
   mckpp_kparams *d_params = nullptr;   // device copy of the kernel parameter block
+  double *d_scratch = nullptr;         // k_column_ps: scratch rows of the iterate, per (workgroup, slot)
+  size_t scratch_doubles = 0;
   int num_cu = 256;
   double *d_series = nullptr;   // [nrec][8][ncol] forcing records (mckpp_hip_set_flux_series)
   int series_rec0 = 0, series_nrec = 0;
@@ -221,6 +223,11 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipMalloc(&h->d_qhead, sizeof(int)));
   HIPCHK(hipMalloc(&h->d_params, sizeof(mckpp_kparams)));
+  if (h->kernel_variant == 5) {
+    h->scratch_doubles = mckpp_ps_scratch_doubles(nzp1, h->ext ? 1 : 0, h->num_cu);
+    HIPCHK(hipMalloc(&h->d_scratch, h->scratch_doubles * sizeof(double)));
+    HIPCHK(hipMemset(h->d_scratch, 0, h->scratch_doubles * sizeof(double)));
+  }
   if (getenv("MCKPP_STAMP")) {
     HIPCHK(hipMalloc(&h->d_dbg, 32 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(h->d_dbg, 0, 32 * sizeof(unsigned long long)));
@@ -318,7 +325,7 @@ int mckpp_hip_finalize(mckpp_hip_handle h)
   if (h->stream) hipStreamSynchronize(h->stream);
   free_state(h);
   hipFree(h->d_zm); hipFree(h->d_hm); hipFree(h->d_tri0); hipFree(h->d_tri1);
-  hipFree(h->d_swfrac_tab); hipFree(h->d_swdk_tab); hipFree(h->d_wtab); hipFree(h->d_qhead); hipFree(h->d_params); hipFree(h->d_dm); hipFree(h->d_hsum);
+  hipFree(h->d_swfrac_tab); hipFree(h->d_swdk_tab); hipFree(h->d_wtab); hipFree(h->d_qhead); hipFree(h->d_params); hipFree(h->d_scratch); hipFree(h->d_dm); hipFree(h->d_hsum);
   if (h->d_dbg) hipFree(h->d_dbg);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
@@ -629,6 +636,7 @@ static void fill_params(mckpp_hip_ctx *h, mckpp_kparams &p, int ntime, int mode)
   p.wU1 = h->d_diag[D_WU1]; p.wU2 = h->d_diag[D_WU2];
   p.wX1 = h->d_diag[D_WX1]; p.wX2 = h->d_diag[D_WX2]; p.wX3 = h->d_diag[D_WX3]; p.wXNT1 = h->d_diag[D_WXNT1];
   p.Rig = h->d_diag[D_RIG]; p.dbloc = h->d_diag[D_DBLOC]; p.Shsq = h->d_diag[D_SHSQ];
+  p.scratch = h->d_scratch; p.scratch_doubles = h->scratch_doubles;
 }
 
 struct forced_run { int ndtocn, l_rest; double flsn, el; };
@@ -729,11 +737,11 @@ int mckpp_hip_synchronize(mckpp_hip_handle h)
     unsigned long long t[32];
     HIPCHK(hipMemcpy(t, h->d_dbg, sizeof t, hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(h->d_dbg, 0, sizeof t));
-    if (h->kernel_variant == 4) {
+    if (h->kernel_variant == 4 || h->kernel_variant == 5) {
       if (t[31]) {
         const char *nm[23] = {"L1", "w", "M1L2", "w", "L3", "w", "M2", "w", "L4", "w", "M3", "w", "L5", "w", "L6", "w",
                               "M4", "w", "L7", "w", "M5", "w", "finish"};
-        fprintf(stderr, "[mckpp stamps pk] wave-passes %llu; cycles per wave-pass:", t[31]);
+        fprintf(stderr, "[mckpp stamps %s] wave-passes %llu; cycles per wave-pass:", h->kernel_variant == 4 ? "pk" : "ps", t[31]);
         double tot = 0;
         for (int i = 0; i < 23; ++i) { fprintf(stderr, " %s=%.0f", nm[i], (double)t[i] / (double)t[31]); tot += (double)t[i]; }
         fprintf(stderr, " total=%.0f\n", tot / (double)t[31]);
