@@ -92,7 +92,7 @@ struct mckpp_hip_ctx {
   int num_cu = 256;
   double *d_series = nullptr;   // [nrec][8][ncol] forcing records (mckpp_hip_set_flux_series)
   int series_rec0 = 0, series_nrec = 0;
-  int kernel_variant = 4;   // 2: k_column_wg (one wavefront per column), 4: k_column_pk (packed lanes)
+  int kernel_variant = 5;   // 2: k_column_wg (one wavefront per column), 4: k_column_pk (packed lanes), 5: k_column_ps (packed, stateless lanes)
   mckpp_launch_info last_launch{};   // geometry of this context's most recent cooperative launch
   double *d_stage = nullptr;
   size_t stage_elems = 0;
@@ -204,13 +204,10 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   h->ext = c->LDD || c->L_RELAX_SST || c->L_FCORR || c->L_FCORR_WITHZ || c->L_SFCORR || c->L_SFCORR_WITHZ ||
            c->L_RELAX_SAL || c->L_RELAX_OCNT || c->L_NO_FREEZE || c->L_NO_ISOTHERM || c->L_DAMP_CURR ||
            c->clim_present || c->L_ADVECT;
-  // Kernel choice.  k_column_pk (packed lanes) everywhere except where a column fills a wavefront almost
-  // exactly (59..64 lanes = 56..61 levels): there k_column_wg keeps the column's scalars in SGPRs and
-  // is ~6 % faster (measured, 1e5 columns).  MCKPP_KERNEL=v1|wg|mw|pk overrides (experiments, tests).
-  {
-    const int lanes = nzp1 + 2;
-    h->kernel_variant = (lanes >= 59 && lanes <= 64) ? 2 : 4;
-  }
+  // Kernel choice: k_column_ps (packed, stateless level lanes) at every depth - measured against the other two
+  // on 1e5 columns: +12 % over k_column_wg at 60 levels, +13..40 % over k_column_pk at 40..150.
+  // MCKPP_KERNEL=wg|pk|ps overrides (experiments, tests).
+  h->kernel_variant = 5;
   if (const char *kv = getenv("MCKPP_KERNEL")) {
     if (strcmp(kv, "wg") == 0) h->kernel_variant = 2;
     else if (strcmp(kv, "pk") == 0) h->kernel_variant = 4;

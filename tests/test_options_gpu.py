@@ -266,7 +266,7 @@ def test_options_on_deep_columns(mk, monkeypatch, nz, variant):
 
 def test_optional_physics_kernel_selection(mk, monkeypatch):
     monkeypatch.delenv("MCKPP_KERNEL", raising=False)
-    for nz, want in [(40, "k_column_pk<EXT>"), (60, "k_column_wg<1,EXT>"), (69, "k_column_pk<EXT>"), (150, "k_column_pk<EXT>")]:
+    for nz, want in [(40, "k_column_ps<EXT>"), (60, "k_column_ps<EXT>"), (69, "k_column_ps<EXT>"), (150, "k_column_ps<EXT>")]:
         kc = mk.KppConstFields(nz)
         kc.L_DAMP_CURR = 1
         mk.mckpp_physics_lookup(kc)

@@ -571,10 +571,10 @@ def test_config4_100_levels_slice(mk):
 
 
 # ---- kernel variants -------------------------------------------------------------------------
-# The library holds two implementations of the column step: k_column_pk (packed lanes: a column takes
-# nzp1+2 lanes wherever they fall in the workgroup; every depth) and k_column_wg (one wavefront per
-# column, up to 61 levels; the default where a column fills a wavefront almost exactly).
-# MCKPP_KERNEL=wg|pk selects one at init; both must reproduce the oracle's bits on every shape they accept.
+# The library holds three implementations of the column step: k_column_ps (the default: level phases loop
+# over (slot, level) items, nine LDS rows per column), k_column_pk (packed lanes: a column takes nzp1+2 lanes
+# wherever they fall in the workgroup) and k_column_wg (one wavefront per column, up to 61 levels).
+# MCKPP_KERNEL=wg|pk|ps selects one at init; all must reproduce the oracle's bits on every shape they accept.
 
 @pytest.fixture
 def kernel_env(monkeypatch):
@@ -588,8 +588,7 @@ def kernel_env(monkeypatch):
 
 def test_default_kernel_selection(mk, kernel_env):
     kernel_env(None)
-    for nz, want in [(40, "k_column_pk"), (55, "k_column_pk"), (56, "k_column_wg<1>"), (61, "k_column_wg<1>"),
-                     (62, "k_column_pk"), (69, "k_column_pk"), (100, "k_column_pk"), (150, "k_column_pk")]:
+    for nz, want in [(10, "k_column_ps"), (40, "k_column_ps"), (60, "k_column_ps"), (69, "k_column_ps"), (150, "k_column_ps")]:
         kc = mk.KppConstFields(nz)
         mk.mckpp_physics_lookup(kc)
         ctx = mk.MckppHip(kc)
@@ -599,7 +598,7 @@ def test_default_kernel_selection(mk, kernel_env):
     kc.LDD = True
     mk.mckpp_physics_lookup(kc)
     ctx = mk.MckppHip(kc)
-    assert ctx.kernel_name == "k_column_pk<EXT>"     # optional-physics build
+    assert ctx.kernel_name == "k_column_ps<EXT>"     # optional-physics build
     ctx.close()
     kernel_env("wg")                                 # the one-wavefront kernel refuses columns it cannot hold
     with pytest.raises(mk.MckppHipError, match="61 levels"):
@@ -945,12 +944,11 @@ def test_full_size_soak_determinism_and_sample_parity(mk):
     _assert_bitexact(cm.compare(sub, ob, nz, cm.PROFILE_FIELDS + cm.SCALAR_FIELDS + ["hmixd0", "hmixd1"]), "soak sample")
 
 
-@pytest.mark.parametrize("nz,ncol,want", [(60, 20000, 5), (40, 20000, 2), (69, 20000, 2), (100, 20000, 1), (150, 20000, 2)])
+@pytest.mark.parametrize("nz,ncol,want", [(60, 20000, 2), (40, 20000, 2), (69, 20000, 2), (100, 20000, 2), (150, 20000, 2)])
 def test_tuned_residency_is_what_the_device_grants(mk, kernel_env, nz, ncol, want):
-    """The cooperative kernels are tuned to a number of resident workgroups per CU (k_column_wg: 5 x 4
-    columns at 56..61 levels, <= 96 VGPRs and <= 25 LDS granules of 1,280 B each; k_column_pk: 2 workgroups
-    of 7 or 8 waves at 128 VGPRs, or one of up to 16 waves where that keeps more columns in flight).  One more LDS row or a few more registers silently drops a workgroup per
-    CU (-10 % or worse), so ask the runtime."""
+    """The cooperative kernel is tuned to a number of resident workgroups per CU (k_column_ps: two workgroups
+    of 8 waves at <= 128 VGPRs, each with as many slots as half the CU's LDS holds).  One more LDS row or a few
+    more registers silently drops a workgroup per CU (-40 %), so ask the runtime."""
     kernel_env(None)
     kc, k3 = cm.make_hip_case(ncol, nz)
     ctx = mk.MckppHip(kc)
