@@ -58,13 +58,14 @@ enum { Q_DM = 0, Q_DT, Q_DS, Q_YU, Q_YT, Q_YS, Q_YV, Q_GM, Q_BET, Q_COUNT,
 // same way with a stride of 7.  Host and device agree on the sizes through these:
 enum { K_ZM = 0, K_HM, K_T0, K_T1, K_RDZ, K_DTOHK, K_STRIDE = 7 };
 __host__ __device__ inline int ps_rows(bool ext) { return ext ? (int)Q_COUNT_EXT : (int)Q_COUNT; }
-__host__ __device__ inline int ps_nl(int L) { return L + 2; }   // level indices 0..L+1
+__host__ __device__ inline int ps_nl(int L) { return L; }   // level indices 0..nzp1+1 (L = nzp1+2 items per column)
 __host__ __device__ inline int ps_ss(int L, bool ext)
 {
-  // lane (slot s, system m) of the serial sweeps touches s*SS + i*ROWS + m: with SS = 3 (mod 32 doubles)
-  // up to ten slots x three systems fall on distinct banks
+  // lane (slot s, system m) of the serial sweeps touches s*SS + i*ROWS + m: an odd SS that is not +-1 (mod 32
+  // doubles) spreads the 3W lanes over the banks about evenly (LDS is the scarce resource here: no more padding)
   int s = ps_rows(ext) * ps_nl(L);
-  while ((s & 31) != 3) ++s;
+  if (!(s & 1)) ++s;
+  while ((s & 31) == 1 || (s & 31) == 31) s += 2;
   return s;
 }
 __host__ __device__ inline int ps_scratch_ld(int nzp1) { return (nzp1 + 7) & ~7; }   // row length of the iterate's scratch
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         } else {
           U = act ? xs_[0] : 0.0; V = act ? xs_[LS] : 0.0; S = act ? xs_[3 * LS] : 0.0;
           T = act ? xs_[2 * LS] : sc[C_T1X + par];   // the two EOS items follow level 1, whose item rewrites it now
-          yu = row(Q_YU)[k]; yv = row(Q_YV)[k]; yt = row(Q_YT)[kr]; ys = row(Q_YS)[k];
+          yu = row(Q_YU)[kr]; yv = row(Q_YV)[kr]; yt = row(Q_YT)[kr]; ys = row(Q_YS)[kr];
         }
         // under-relaxation, ocnstep_mod.F90:123-132 / :142-151 (an EOS item follows level 1's temperature)
         T = lambda * T + (1 - lambda) * yt;
@@ -662,7 +663,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       }
       const double Sref = sc[C_SREF];
       const double zm1 = c_zm[1];
-      const double zmk = c_zm[k];
+      const double zmk = c_zm[kr];
       double Sin = S + Sref, Pin = -zmk;
       const double Tin = T;
       if (virt1) { Sin = 0.0; Pin = -zm1; }
@@ -695,6 +696,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     // ---- M1 | L2: surface fluxes (wave 0) | reference-level loop, Ri pieces (verticalmixing_mod.F90:111-137)
     if (wv == mgr) M1();
     FOR_ITEMS
+      if (!act) continue;   // the two equation-of-state items exist for L1 only
       const strided<ROWS> aU = row(Q_YU), aV = row(Q_YV), aB = row(Q_YS);
       const double U = act ? aU[k] : 0.0, V = act ? aV[k] : 0.0, buoy = aB[k];
       const double zmk = c_zm[k];
@@ -827,6 +829,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     // ---- L4: first level with hmin < -zm(k) (bldepth_mod.F90:139-180): every hit level posts its hmin,
     //          the shallowest one wins through an LDS minimum
     FOR_ITEMS
+      if (!act) continue;   // the two equation-of-state items exist for L1 only
       const strided<ROWS> aRaw = row(Q_YV), aDmo = row(Q_YU);
       const double zmk = c_zm[k];
       const double ocdepth = sc[C_OCDEPTH];
@@ -1028,6 +1031,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     // Q_YT, Q_YS) and every sub-phase works on them in place.  INIT / VMIX have no solution: U,V,T,S are the
     // column's own rows in HBM.
     FOR_ITEMS
+      if (!act) continue;   // the two equation-of-state items exist for L1 only
       if (si[I_FIN] != F_TRAP) continue;   // :200-207
       const double U = row(Q_YU)[k], V = row(Q_YV)[k], T = row(Q_YT)[k], tk1 = row(Q_YT)[k + 1];
       const bool v = actz && (__builtin_fabs(U) >= 10 || __builtin_fabs(V) >= 10 || __builtin_fabs(T - tk1) >= 10);
@@ -1035,6 +1039,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     END_ITEMS
     __syncthreads();
     FOR_ITEMS
+      if (!act) continue;   // the two equation-of-state items exist for L1 only
       if (!(si[I_FIN] == F_TRAP && si[I_NVIOL] == 0 && act)) continue;   // :208-219
       const size_t o = ro + (k - 1);
       const double U = row(Q_YU)[k], V = row(Q_YV)[k], T = row(Q_YT)[k], S = row(Q_YS)[k];
@@ -1093,6 +1098,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     // ---- outputs.  Diagnostic fluxes (ocnstep_mod.F90:242-256 / initialize_ocean.F90:66-81) from the final
     // profiles and their k+1 neighbours; STEP: level-1 references, then (optional physics) current damping.
     FOR_ITEMS
+      if (!act) continue;   // the two equation-of-state items exist for L1 only
       if (si[I_FIN] != F_FINAL) continue;
       const bool fstep = p.mode == MCKPP_MODE_STEP;
       const bool sol = do_ocnint;   // profiles in the solution rows
@@ -1155,6 +1161,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     // ---- STEP: new time level, check_profile (overrides.F90:42-125); the optional parts count over all
     // levels of the column: LDS counters between workgroup barriers (EXT build).
     FOR_ITEMS
+      if (!act) continue;   // the two equation-of-state items exist for L1 only
       if (!(si[I_FIN] == F_FINAL && p.mode == MCKPP_MODE_STEP)) continue;
       const size_t o = ro + (k - 1);
       const int newi = 1 - si[I_NEW];   // old = new; new = 1 - old
@@ -1178,6 +1185,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       __syncthreads();
       // isotherm check (:102-120): |T(k) - T(k-1)| dz and dz into the gam rows, summed by every item of the slot
       FOR_ITEMS
+        if (!act) continue;   // the two equation-of-state items exist for L1 only
         if (!(si[I_FIN] == F_FINAL && p.mode == MCKPP_MODE_STEP && si[I_LOCEAN] && p.L_NO_ISOTHERM)) continue;
         if (k >= 2 && act) {
           const double dz = c_zm[k] - c_zm[k - 1];
@@ -1188,6 +1196,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       __syncthreads();
     }
     FOR_ITEMS
+      if (!act) continue;   // the two equation-of-state items exist for L1 only
       if (si[I_FIN] != F_FINAL) continue;
       double *cs = p.cs + (size_t)col * MCKPP_CS;
       int *ci = p.ci + (size_t)col * MCKPP_CI;
@@ -1293,10 +1302,12 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 struct ps_geom { int nw, w, per_cu; };
 
 // Slots per workgroup / waves / workgroups per CU.  A pass of a workgroup is its manager wave's serial phases
-// (independent of the number of slots, ~0.9 k cycles per level) plus its level phases (~25 k cycles per trip of the
-// item loop, 40 k when one 16-wave workgroup has the CU to itself and nothing overlaps its barriers) plus ~12 k of
-// barriers and finish rounds; 128 VGPRs allow 16 waves per CU.  The rate is slots in flight / pass time: take the
-// geometry that maximises it under the LDS each workgroup's slots need.  <= 21 slots: three manager lanes per slot.
+// (independent of the number of slots: 0.8-1 k cycles per level) plus its level phases (23-26 k cycles per trip
+// of the item loop) plus barrier waits and finish rounds; 128 VGPRs allow 16 waves per CU.  The rate is slots in
+// flight / pass time: take the geometry that maximises it under the LDS each workgroup's slots need.  The
+// constants are fits to the per-phase cycle counts of profiles/r02/stamps.txt (one 16-wave workgroup: nothing
+// overlaps its barriers; four 4-wave workgroups: four manager waves share the CU with few level waves).
+// <= 21 slots: three manager lanes per slot.
 ps_geom ps_choose(int L, bool ext, size_t cu_lds_bytes)
 {
   auto granules = [&](int w_) { return (ps_lds_bytes(L, w_, ext) + 1279) / 1280 * 1280; };
@@ -1304,11 +1315,13 @@ ps_geom ps_choose(int L, bool ext, size_t cu_lds_bytes)
   double best_rate = 0.0;
   for (int per_cu = 1; per_cu <= 4; per_cu *= 2) {
     const int nw = 16 / per_cu, threads = 64 * nw;
-    const double trip = per_cu == 1 ? 40.e3 : 25.e3;
+    const double serial = per_cu == 1 ? 0.82e3 : per_cu == 2 ? 0.90e3 : 0.96e3;
+    const double trip = per_cu == 1 ? 26.e3 : per_cu == 2 ? 23.5e3 : 24.5e3;
+    const double other = per_cu == 1 ? 24.e3 : per_cu == 2 ? 22.e3 : 10.e3;
     for (int w = 1; w <= 21; ++w) {
       if ((size_t)per_cu * granules(w) > cu_lds_bytes) break;
       const int trips = (w * L + threads - 1) / threads;
-      const double pass = 0.9e3 * L + trip * trips + 12.e3;
+      const double pass = serial * L + trip * trips + other;
       const double rate = per_cu * w / pass;
       if (rate > best_rate * 1.0001) { best_rate = rate; best = {nw, w, per_cu}; }
     }
