@@ -279,7 +279,7 @@ int mckpp_hip_status(mckpp_hip_handle h, int32_t *per_col, int64_t *n_flagged,
 int mckpp_hip_last_kernel_ms(mckpp_hip_handle h, double *ms, int32_t *nlaunch);
 
 /* Name of the column kernel this context launches for its grid and switches
- * ("k_column_wg<1>", "k_column_mw<2>", ...); static storage, never NULL. */
+ * ("k_column_ps", "k_column_ps<EXT>"); static storage, never NULL. */
 const char *mckpp_hip_kernel_name(mckpp_hip_handle h);
 
 /* Residency of the most recent cooperative column-kernel launch of the process: workgroups per

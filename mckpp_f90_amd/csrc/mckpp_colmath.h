@@ -1,4 +1,4 @@
-// mckpp_colmath.h - device arithmetic shared by the column kernels: equation of
+// mckpp_colmath.h - device arithmetic of the column kernel and the batch test kernels: equation of
 // state, specific heat, turbulent velocity scales, Jerlov transmission.  Every
 // function restates one reference routine operation for operation (citations
 // at each function) and is compiled with -ffp-contract=off.
@@ -10,22 +10,9 @@ namespace mckpp_dev {
 
 constexpr int NI = 890, NJ = 48, NT = NI + 2;
 
-#define FORJ _Pragma("unroll") for (int j = 0; j < LPL; ++j)
-
 __device__ __forceinline__ double dmax2(double a, double b) { return a > b ? a : b; }
 __device__ __forceinline__ double dmin2(double a, double b) { return a < b ? a : b; }
 __device__ __forceinline__ double dsign(double a, double b) { return __builtin_copysign(__builtin_fabs(a), b); }
-
-__device__ __forceinline__ double bcast(double x, int src_lane) { return __shfl(x, src_lane, 64); }
-__device__ __forceinline__ double first_lane(double x)
-{
-#ifdef MCKPP_NO_FIRSTLANE
-  return x;
-#endif
-  int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
-  int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
-  return __hiloint2double(hi, lo);
-}
 
 // ---------------------------------------------------------------------------
 // IEEE-754 correctly rounded fp64 division with the reciprocal refinement
@@ -202,23 +189,6 @@ __device__ __forceinline__ wscale_u wscale_prepare(double ustar)
   return w;
 }
 
-// same, with the (wave-uniform) results moved to scalar registers
-__device__ __forceinline__ double first_lane_d(double x)
-{
-  int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
-  int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ wscale_u wscale_prepare_uniform(double ustar)
-{
-  wscale_u w = wscale_prepare(ustar);
-  w.ju = __builtin_amdgcn_readfirstlane(w.ju);
-  w.ufrac = first_lane_d(w.ufrac);
-  w.ustar = first_lane_d(w.ustar);
-  w.ucube = first_lane_d(w.ucube);
-  return w;
-}
-
 __device__ __forceinline__ void wscale_dev(const mckpp_kparams &p, const wscale_u &w, double sigma,
                                            double hbl, double bfsfc, double &wm, double &ws)
 {
@@ -262,19 +232,6 @@ __device__ __forceinline__ double swfrac_dev(double fact, double z, int jw)
   double r1 = dmax2(div_fast(z * fact, a1[jw], jer_ra1_c[jw]), rmin);
   double r2 = dmax2(div_fast(z * fact, a2[jw], jer_ra2_c[jw]), rmin);
   return rfac[jw] * mckpp_exp(r1) + (1. - rfac[jw]) * mckpp_exp(r2);
-}
-
-// The same value for a wave-uniform depth with the two bands evaluated side by side: even lanes
-// take the first band, odd lanes the second, so the exp polynomial is issued once instead of twice.
-__device__ __forceinline__ double swfrac_dev_wave(double fact, double z, int jw, int lane)
-{
-  const double rmin = -80.;
-  const bool second = (lane & 1) != 0;
-  const double a = second ? jer_a2_c[jw] : jer_a1_c[jw], ra = second ? jer_ra2_c[jw] : jer_ra1_c[jw];
-  const double e = mckpp_exp(dmax2(div_fast(z * fact, a, ra), rmin));
-  const double e1 = first_lane(e);
-  const double e2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(e), 1), __builtin_amdgcn_readlane(__double2loint(e), 1));
-  return jer_rfac_c[jw] * e1 + (1. - jer_rfac_c[jw]) * e2;
 }
 
 

@@ -73,18 +73,11 @@ struct mckpp_kparams {
 
 // what the last cooperative-kernel launch looked like (for the residency check of the tests)
 struct mckpp_launch_info { int nblocks, threads, max_blocks_per_cu; size_t lds_bytes; };
-extern mckpp_launch_info g_mckpp_last_launch;
 
 // launchers
-// cooperative kernel, one wavefront per column (mckpp_kernels_wg.hip): 4 columns per workgroup, persistent
-// grid; columns of up to 61 levels.  `dp` is a device copy of `p` (every field but ntime is read from it;
+// The column step: packed, stateless-lane cooperative kernel (mckpp_kernels_ps.hip), persistent grid; level
+// phases loop over (slot, level) items.  `dp` is a device copy of `p` (every field but ntime is read from it;
 // ntime is passed by value)
-hipError_t mckpp_launch_column_kernel_wg(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu,
-                                         hipStream_t stream);
-// packed-lane kernel (mckpp_kernels_pk.hip): columns dealt back to back over the workgroup's lanes
-hipError_t mckpp_launch_column_kernel_pk(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu,
-                                         hipStream_t stream, mckpp_launch_info *info);
-// packed, stateless-lane kernel (mckpp_kernels_ps.hip): level phases loop over (slot, level) items
 hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu,
                                          hipStream_t stream, mckpp_launch_info *info);
 size_t mckpp_ps_scratch_doubles(int nzp1, int ext, int num_cu);   // what p.scratch must hold for that launch

@@ -1,8 +1,7 @@
 // mckpp_kernels.hip - the small gfx950 kernels around the column step: layout conversion between the
 // Fortran arrays (column index fastest) and the device rows (level fastest), surface-flux assembly
 // (mckpp_fluxes), the bottom-temperature override, output-window reductions, and the batch probes the
-// parity tests use.  The column step itself lives in mckpp_kernels_pk.hip (packed lanes, every depth)
-// and mckpp_kernels_wg.hip (one wavefront per column, 56..61 levels).
+// parity tests use.  The column step itself lives in mckpp_kernels_ps.hip.
 //
 // Arithmetic is written operation-for-operation in the reference's expression order and built with
 // -ffp-contract=off, so results are bitwise reproducible against the CPU oracle (tests/).
@@ -189,7 +188,6 @@ __global__ void k_window_mean(const double *__restrict__ sum, double *__restrict
 
 }  // namespace
 
-mckpp_launch_info g_mckpp_last_launch = {0, 0, 0, 0};
 
 hipError_t mckpp_launch_eos_batch(int64_t n, const double *s, const double *t, const double *p,
                                   double *alpha, double *beta, double *sig0, double *cp,

@@ -1,18 +1,24 @@
-// mckpp_kernels_ps.hip - packed, stateless-lane cooperative column kernel.
+// mckpp_kernels_ps.hip - the column step: packed, stateless-lane cooperative kernel.
 //
-// k_column_pk (mckpp_kernels_pk.hip) gives every column nzp1+2 lanes for the whole step; its waves are
-// parked at barriers ~80 % of the time waiting for the manager wave's serial phases, and the number of columns
-// in flight on a CU is capped by the wave slots (16 waves at 128 VGPRs) and by 13 LDS rows per column.
-// Here a level lane keeps NOTHING between phases: the iterate (U,V,T,S of the under-relaxation) lives in a
-// small cache-resident scratch block per (workgroup, slot), every other phase-crossing value in one of NINE
-// rows of the slot's LDS block (each row is reused three to five times in a pass, see the table below).  A
-// level phase is a loop over work items (slot, level) strided by the workgroup's threads, so a workgroup
-// serves as many slots as LDS holds, whatever its number of waves: the manager wave's serial phases cost the
-// same for 15 slots as for 8.  Manager phases, LDS layout, arithmetic: as k_column_pk.
-#include "mckpp_sweeps.h"
+// One launch takes every resident column through mckpp_physics_ocnstep (+ check_profile), or through
+// mckpp_initialize_ocean_model's per-column part, or one vmix(+ocnint) pass (p.mode).  A persistent grid of
+// workgroups, each with W column slots fed from an atomic queue; a column's iteration is a sequence of
+// level-parallel phases (L1..L7: every (slot, level) item of the workgroup, strided over its threads) and
+// serial phases (M0..M5: the manager wave, one lane per slot or per (slot, tridiagonal system)), separated by
+// workgroup barriers.
+//
+// A level lane keeps NOTHING between phases: the iterate (U,V,T,S of the under-relaxation) lives in a small
+// cache-resident scratch block per (workgroup, slot), every other phase-crossing value in one of NINE rows of
+// the slot's LDS block (each row is reused three to five times in a pass, see the table below).  So a
+// workgroup serves as many slots as LDS holds, whatever its number of waves, and the manager wave's serial
+// phases - the latency floor of a pass - cost the same for 15 slots as for 1.  (Round-2 history, measured on
+// 1e5 columns: one wavefront per column with 13 LDS rows 1.9e7 column-steps/s at 60 levels; nzp1+2 lanes per
+// column for the whole step 1.8e7; this kernel 2.2e7 - DESIGN.md section 4.)
+#include "mckpp_colmath.h"
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -76,8 +82,35 @@ __host__ __device__ inline size_t ps_lds_bytes(int L, int W, bool ext)
 }
 
 
-// ---- the manager wave's Thomas sweeps on this kernel's rows (arithmetic: serial_thomas_uts_n / _v_n of
-// mckpp_sweeps.h, solvers.F90:14-44, 112-161).  lane = (slot, system U|T|S).  The T and S systems store their
+// ---- the manager wave's serial sweeps, one lane per slot (x system) over the slots' level-interleaved rows
+// (element (row a, level i) of slot s at slots[s*SS + i*KS + a]; grid constants with stride CS).
+
+// bldepth_mod.F90:137: Rib(ku) = MAX(Rib(ku), Rib(ka) + epsln) down the column, four levels per trip
+__device__ __forceinline__ void ps_scan_rib(int W, int row, double *slots, int SS, int KS, int nz, const int *sact,
+                                            int sact_stride, int lane)
+{
+  const double epsln16 = 1.e-16;
+  if (lane < W && sact[lane * sact_stride]) {
+    double *r = slots + lane * SS + row;
+    double rb = 0.0;
+    int k = 2;
+    for (; k + 3 <= nz; k += 4) {
+      const double a0 = r[k * KS], a1 = r[(k + 1) * KS], a2 = r[(k + 2) * KS], a3 = r[(k + 3) * KS];
+      rb = dmax2(a0, rb + epsln16); const double b0 = rb;
+      rb = dmax2(a1, rb + epsln16); const double b1 = rb;
+      rb = dmax2(a2, rb + epsln16); const double b2 = rb;
+      rb = dmax2(a3, rb + epsln16);
+      r[k * KS] = b0; r[(k + 1) * KS] = b1; r[(k + 2) * KS] = b2; r[(k + 3) * KS] = rb;
+    }
+    for (; k <= nz; ++k) {
+      rb = dmax2(r[k * KS], rb + epsln16);
+      r[k * KS] = rb;
+    }
+  }
+}
+
+// tridcof + tridmat (solvers.F90:14-44, 112-161) for U, T, S, skewed by one level: iteration i forms
+// gam(i) = cl(i-1)/bet(i-1) and y(i-1) = num(i-1)/bet(i-1) over the same denominator.  lane = (slot, system).  The T and S systems store their
 // gam over the diffusivity row they have just consumed (level i's diffusivity is in a register before gam(i)
 // is written); the momentum system keeps difm, gam and its pivots for the V sweep.
 __device__ __forceinline__ void ps_thomas_uts(int W, double *slots, int SS, int KS, int CS, int nz, const double *c_t0,
@@ -92,10 +125,19 @@ __device__ __forceinline__ void ps_thomas_uts(int W, double *slots, int SS, int 
       double *y = base + (Q_YU + sys), *gm = base + (sys == 0 ? (int)Q_GM : (int)Q_DM + sys);
       double *betm = base + Q_BET;
       int bad = 0;
+      // The coefficients of tridcof share their products: with p(i) = tri(i,1) diff(i) and q(i) = tri(i,0) diff(i-1)
+      //   cl(i) = -p(i), cu(i) = -q(i), cc(i) = (1 + p(i)) + q(i)      (solvers.F90:28-40, same roundings: a
+      //   negation is exact), so a level forms p and q once; cu*x is -(q*x) exactly, hence cc - cu*gam = cc + q*gam.
       double dm1 = d[(1) * KS];
       double pm1 = c_t1[(1) * CS] * dm1;   // p(1)
       double bet = 1. + pm1;               // cc(1)
       double ynum = y[(1) * KS];           // y(1) = rhs(1)/bet, formed in the next level's step
+      // One level of the skewed sweep.  The serial wave issues one fp64 instruction every 6-10 cycles whether or
+      // not it depends on the previous one, so the sweep's time is its instruction count: the common case is one
+      // straight basic block (pivot chain bet -> 1/bet -> gam -> bet' interleaved with the solution chain, both
+      // on div_fast), and the two conditions that need other arithmetic - a zero pivot, or a tiny non-zero
+      // solution numerator that div_fast must not see - are detected at the end of the level before and sent
+      // through the slow copy of the step (IEEE sequences), practically never.
       unsigned long long rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum));   // wave mask, lives in SGPRs
       auto level = [&](int i, double di, double t0, double t1, double rhs, auto slow) {
         if (slow.value && bet == 0.) { bad = 1; bet = 1.E-12; }   // solvers.F90:140-151 would stop here
@@ -166,6 +208,9 @@ __device__ __forceinline__ void ps_thomas_v(int W, double *slots, int SS, int KS
     double yy = div_by_refined(y[(1) * KS], b1, rcp_refine(b1));
     y[(1) * KS] = yy;
     double dm1 = d[(1) * KS];
+    // Here the quotient is the dependent chain itself, so it takes div_fast unconditionally; a tiny
+    // non-zero numerator is noticed at the end of its level and the quotient is redone (IEEE
+    // sequence) at the top of the next one, before anything has used it.  Two levels per trip.
     double nprev = 0.0, bprev = 1.0;
     unsigned long long rare = 0ull;   // wave mask of lanes whose last numerator was tiny
     auto vstep = [&](int i, double rhs, double t0, double b, double r, double di) {
@@ -319,7 +364,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 #define END_ITEMS }
 
   // =========================== manager phases (wave 0) ===========================
-  // M0: slots whose column has finished pull the next one from the queue (refill of k_column_wg)
+  // M0: slots whose column has finished pull the next one from the queue 
   auto M0 = [&]() {
     bool a = false;
     if (lane < W) {
@@ -821,7 +866,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(5);
 
     // ---- M2: Rib(ku) = MAX(Rib(ku), Rib(ka)+epsln), bldepth_mod.F90:137
-    if (wv == mgr) { PRIO_HI(); serial_scan_rib_n(W, Q_YV, slots, SS, 1, ROWS, nz, sirec + I_ACT, I_COUNT, lane); PRIO_LO(); }
+    if (wv == mgr) { PRIO_HI(); ps_scan_rib(W, Q_YV, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane); PRIO_LO(); }
     STAMP(6);
     __syncthreads();
     STAMP(7);
@@ -1304,15 +1349,17 @@ struct ps_geom { int nw, w, per_cu; };
 // Slots per workgroup / waves / workgroups per CU.  A pass of a workgroup is its manager wave's serial phases
 // (independent of the number of slots: 0.8-1 k cycles per level) plus its level phases (23-26 k cycles per trip
 // of the item loop) plus barrier waits and finish rounds; 128 VGPRs allow 16 waves per CU.  The rate is slots in
-// flight / pass time: take the geometry that maximises it under the LDS each workgroup's slots need.  The
-// constants are fits to the per-phase cycle counts of profiles/r02/stamps.txt (one 16-wave workgroup: nothing
-// overlaps its barriers; four 4-wave workgroups: four manager waves share the CU with few level waves).
+// flight / pass time: take the geometry that maximises it under the LDS each workgroup's slots need, with no
+// more slots than the CU has columns to work on (fewer items, shorter passes).  The constants are
+// fits to the per-phase cycle counts of profiles/r02/stamps.txt (one 16-wave workgroup: nothing overlaps its
+// barriers; four 4-wave workgroups: four manager waves share the CU with few level waves).
 // <= 21 slots: three manager lanes per slot.
-ps_geom ps_choose(int L, bool ext, size_t cu_lds_bytes)
+ps_geom ps_choose(int L, bool ext, size_t cu_lds_bytes, int cols_per_cu, int *max_slots_per_cu)
 {
   auto granules = [&](int w_) { return (ps_lds_bytes(L, w_, ext) + 1279) / 1280 * 1280; };
   ps_geom best = {1, 1, 1};
   double best_rate = 0.0;
+  int most = 1;
   for (int per_cu = 1; per_cu <= 4; per_cu *= 2) {
     const int nw = 16 / per_cu, threads = 64 * nw;
     const double serial = per_cu == 1 ? 0.82e3 : per_cu == 2 ? 0.90e3 : 0.96e3;
@@ -1320,33 +1367,42 @@ ps_geom ps_choose(int L, bool ext, size_t cu_lds_bytes)
     const double other = per_cu == 1 ? 24.e3 : per_cu == 2 ? 22.e3 : 10.e3;
     for (int w = 1; w <= 21; ++w) {
       if ((size_t)per_cu * granules(w) > cu_lds_bytes) break;
+      if (per_cu * w > most) most = per_cu * w;
       const int trips = (w * L + threads - 1) / threads;
       const double pass = serial * L + trip * trips + other;
-      const double rate = per_cu * w / pass;
+      const int busy = per_cu * w < cols_per_cu ? per_cu * w : cols_per_cu;
+      const double rate = busy / pass;
       if (rate > best_rate * 1.0001) { best_rate = rate; best = {nw, w, per_cu}; }
     }
   }
   const int need = (best.w * L + 63) / 64;
   if (need < best.nw) best.nw = need;
+  if (max_slots_per_cu) *max_slots_per_cu = most;
   return best;
 }
 
-ps_geom ps_geometry(int L, bool ext)   // MCKPP_PS=<slots>x<waves>x<workgroups per CU> overrides the choice (experiments)
+// MCKPP_PS=<slots>x<waves>x<workgroups per CU> overrides the choice (experiments)
+ps_geom ps_geometry(int L, bool ext, int cols_per_cu, int *max_slots_per_cu)
 {
-  ps_geom g = ps_choose(L, ext, (size_t)160 * 1024);
+  ps_geom g = ps_choose(L, ext, (size_t)160 * 1024, cols_per_cu, max_slots_per_cu);
   if (const char *e = getenv("MCKPP_PS")) {
     int w = 0, nw = 0, b = 0;
-    if (sscanf(e, "%dx%dx%d", &w, &nw, &b) == 3 && w >= 1 && w <= 21 && nw >= 1 && nw <= 16 && b >= 1) g = {nw, w, b};
+    if (sscanf(e, "%dx%dx%d", &w, &nw, &b) == 3 && w >= 1 && w <= 21 && nw >= 1 && nw <= 16 && b >= 1 && b <= 16) {
+      g = {nw, w, b};
+      if (max_slots_per_cu && b * w > *max_slots_per_cu) *max_slots_per_cu = b * w;
+    }
   }
   return g;
 }
 
 }  // namespace
 
+// the scratch block covers whatever geometry a launch may choose (the choice depends on the column count)
 size_t mckpp_ps_scratch_doubles(int nzp1, int ext, int num_cu)
 {
-  const ps_geom g = ps_geometry(nzp1 + 2, ext != 0);
-  return (size_t)num_cu * g.per_cu * g.w * 4 * ps_scratch_ld(nzp1);
+  int most = 1;
+  (void)ps_geometry(nzp1 + 2, ext != 0, 1 << 20, &most);
+  return (size_t)num_cu * most * 4 * ps_scratch_ld(nzp1);
 }
 
 hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu, hipStream_t stream,
@@ -1356,8 +1412,8 @@ hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kpa
   const int L = p.nzp1 + 2;
   if (L > 1024) return hipErrorInvalidValue;
   const bool ext = p.ext != 0;
-  const ps_geom g = ps_geometry(L, ext);
-  if (!p.scratch || p.scratch_doubles < mckpp_ps_scratch_doubles(p.nzp1, p.ext, num_cu)) return hipErrorInvalidValue;
+  const ps_geom g = ps_geometry(L, ext, (p.ncol + num_cu - 1) / num_cu, nullptr);
+  if (!p.scratch || p.scratch_doubles < (size_t)num_cu * g.per_cu * g.w * 4 * ps_scratch_ld(p.nzp1)) return hipErrorInvalidValue;
   const size_t lds = ps_lds_bytes(L, g.w, ext);
   if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
   const void *fn = ext ? reinterpret_cast<const void *>(k_column_ps<true>) : reinterpret_cast<const void *>(k_column_ps<false>);

@@ -92,7 +92,6 @@ struct mckpp_hip_ctx {
   int num_cu = 256;
   double *d_series = nullptr;   // [nrec][8][ncol] forcing records (mckpp_hip_set_flux_series)
   int series_rec0 = 0, series_nrec = 0;
-  int kernel_variant = 5;   // 2: k_column_wg (one wavefront per column), 4: k_column_pk (packed lanes), 5: k_column_ps (packed, stateless lanes)
   mckpp_launch_info last_launch{};   // geometry of this context's most recent cooperative launch
   double *d_stage = nullptr;
   size_t stage_elems = 0;
@@ -180,7 +179,7 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
     return fail("mckpp_hip_init: iso_bot=%d outside 2..nzp1", c->iso_bot);
   const int nzp1 = c->nz + 1;
   const int lpl = (nzp1 + 2 + 63) / 64;
-  if (lpl > 8) return fail("mckpp_hip_init: nz=%d too deep (max 509 levels: a column takes nzp1+2 of the 512 lanes of a workgroup)", c->nz);
+  if (lpl > 8) return fail("mckpp_hip_init: nz=%d too deep (max 509 levels: profile rows are padded to at most 512 doubles)", c->nz);
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail("mckpp_hip_init: device %d of %d", device, ndev);
@@ -204,27 +203,12 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   h->ext = c->LDD || c->L_RELAX_SST || c->L_FCORR || c->L_FCORR_WITHZ || c->L_SFCORR || c->L_SFCORR_WITHZ ||
            c->L_RELAX_SAL || c->L_RELAX_OCNT || c->L_NO_FREEZE || c->L_NO_ISOTHERM || c->L_DAMP_CURR ||
            c->clim_present || c->L_ADVECT;
-  // Kernel choice: k_column_ps (packed, stateless level lanes) at every depth - measured against the other two
-  // on 1e5 columns: +12 % over k_column_wg at 60 levels, +13..40 % over k_column_pk at 40..150.
-  // MCKPP_KERNEL=wg|pk|ps overrides (experiments, tests).
-  h->kernel_variant = 5;
-  if (const char *kv = getenv("MCKPP_KERNEL")) {
-    if (strcmp(kv, "wg") == 0) h->kernel_variant = 2;
-    else if (strcmp(kv, "pk") == 0) h->kernel_variant = 4;
-    else if (strcmp(kv, "ps") == 0) h->kernel_variant = 5;
-    else return fail("mckpp_hip_init: MCKPP_KERNEL=%s (known: wg, pk, ps)", kv);
-  }
-  if (h->kernel_variant == 2 && nzp1 + 2 > 64) {
-    return fail("mckpp_hip_init: MCKPP_KERNEL=wg carries columns of up to 61 levels (nz=%d)", c->nz);
-  }
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipMalloc(&h->d_qhead, sizeof(int)));
   HIPCHK(hipMalloc(&h->d_params, sizeof(mckpp_kparams)));
-  if (h->kernel_variant == 5) {
-    h->scratch_doubles = mckpp_ps_scratch_doubles(nzp1, h->ext ? 1 : 0, h->num_cu);
-    HIPCHK(hipMalloc(&h->d_scratch, h->scratch_doubles * sizeof(double)));
-    HIPCHK(hipMemset(h->d_scratch, 0, h->scratch_doubles * sizeof(double)));
-  }
+  h->scratch_doubles = mckpp_ps_scratch_doubles(nzp1, h->ext ? 1 : 0, h->num_cu);
+  HIPCHK(hipMalloc(&h->d_scratch, h->scratch_doubles * sizeof(double)));
+  HIPCHK(hipMemset(h->d_scratch, 0, h->scratch_doubles * sizeof(double)));
   if (getenv("MCKPP_STAMP")) {
     HIPCHK(hipMalloc(&h->d_dbg, 32 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(h->d_dbg, 0, 32 * sizeof(unsigned long long)));
@@ -662,14 +646,7 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode, const forced_r
                                  forced->flsn, forced->el, h->stream));
     }
     HIPCHK(hipMemsetAsync(h->d_qhead, 0, sizeof(int), h->stream));
-    if (h->kernel_variant == 5) {
-      HIPCHK(mckpp_launch_column_kernel_ps(p, h->d_params, h->num_cu, h->stream, &h->last_launch));
-    } else if (h->kernel_variant == 4) {
-      HIPCHK(mckpp_launch_column_kernel_pk(p, h->d_params, h->num_cu, h->stream, &h->last_launch));
-    } else {
-      HIPCHK(mckpp_launch_column_kernel_wg(p, h->d_params, h->num_cu, h->stream));
-      h->last_launch = g_mckpp_last_launch;
-    }
+    HIPCHK(mckpp_launch_column_kernel_ps(p, h->d_params, h->num_cu, h->stream, &h->last_launch));
   }
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   h->nlaunch = nsteps;
@@ -734,20 +711,13 @@ int mckpp_hip_synchronize(mckpp_hip_handle h)
     unsigned long long t[32];
     HIPCHK(hipMemcpy(t, h->d_dbg, sizeof t, hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(h->d_dbg, 0, sizeof t));
-    if (h->kernel_variant == 4 || h->kernel_variant == 5) {
-      if (t[31]) {
-        const char *nm[23] = {"L1", "w", "M1L2", "w", "L3", "w", "M2", "w", "L4", "w", "M3", "w", "L5", "w", "L6", "w",
-                              "M4", "w", "L7", "w", "M5", "w", "finish"};
-        fprintf(stderr, "[mckpp stamps %s] wave-passes %llu; cycles per wave-pass:", h->kernel_variant == 4 ? "pk" : "ps", t[31]);
-        double tot = 0;
-        for (int i = 0; i < 23; ++i) { fprintf(stderr, " %s=%.0f", nm[i], (double)t[i] / (double)t[31]); tot += (double)t[i]; }
-        fprintf(stderr, " total=%.0f\n", tot / (double)t[31]);
-      }
-    } else if (t[11]) {
-      const char *nm[11] = {"refill", "A", "waitA", "scan", "C", "waitC", "UTS", "E", "waitE", "V", "G"};
-      fprintf(stderr, "[mckpp stamps] wave-passes %llu; cycles per wave-pass:", t[11]);
-      for (int i = 0; i < 11; ++i) fprintf(stderr, " %s=%.0f", nm[i], (double)t[i] / (double)t[11]);
-      fprintf(stderr, "\n");
+    if (t[31]) {
+      const char *nm[23] = {"L1", "w", "M1L2", "w", "L3", "w", "M2", "w", "L4", "w", "M3", "w", "L5", "w", "L6", "w",
+                            "M4", "w", "L7", "w", "M5", "w", "finish"};
+      fprintf(stderr, "[mckpp stamps ps] wave-passes %llu; cycles per wave-pass:", t[31]);
+      double tot = 0;
+      for (int i = 0; i < 23; ++i) { fprintf(stderr, " %s=%.0f", nm[i], (double)t[i] / (double)t[31]); tot += (double)t[i]; }
+      fprintf(stderr, " total=%.0f\n", tot / (double)t[31]);
     }
   }
   return 0;
@@ -756,9 +726,7 @@ int mckpp_hip_synchronize(mckpp_hip_handle h)
 const char *mckpp_hip_kernel_name(mckpp_hip_handle h)
 {
   if (!h) return "none";
-  if (h->kernel_variant == 2) return h->ext ? "k_column_wg<1,EXT>" : "k_column_wg<1>";
-  if (h->kernel_variant == 5) return h->ext ? "k_column_ps<EXT>" : "k_column_ps";
-  return h->ext ? "k_column_pk<EXT>" : "k_column_pk";
+  return h->ext ? "k_column_ps<EXT>" : "k_column_ps";
 }
 
 int mckpp_hip_kernel_residency(mckpp_hip_handle h, int32_t *blocks_per_cu, int32_t *max_blocks_per_cu,

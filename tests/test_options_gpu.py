@@ -189,15 +189,11 @@ def test_vary_bottom_temp(mk, nz, switches):
         ctx.bottomtemp(k3.bottom_temp)
 
 
-@pytest.mark.parametrize("nz,variant", [(69, None), (100, None), (150, None), (60, "pk"), (60, "wg")])
-def test_options_on_deep_columns(mk, monkeypatch, nz, variant):
-    """The optional physics on columns that span two or three wavefronts (k_column_pk<EXT>): the level
+@pytest.mark.parametrize("nz", [30, 69, 100, 150])
+def test_options_on_other_depths(mk, nz):
+    """The optional physics where a slot's items span one to three wavefronts (k_column_ps<EXT>): the level
     counts of check_profile (damped levels, frozen levels), the isotherm sums and the double-diffusion
-    neighbours cross wave boundaries here; and the same cases at 60 levels on both kernels."""
-    if variant is None:
-        monkeypatch.delenv("MCKPP_KERNEL", raising=False)
-    else:
-        monkeypatch.setenv("MCKPP_KERNEL", variant)
+    neighbours cross wave boundaries here."""
     nzp1 = nz + 1
     z = np.arange(nzp1)[None, :]
 
@@ -264,8 +260,7 @@ def test_options_on_deep_columns(mk, monkeypatch, nz, variant):
     _case(mk, 42, nz, dict(L_ADVECT=1), prep_adv, grid="stretched" if nz == 69 else "uniform")
 
 
-def test_optional_physics_kernel_selection(mk, monkeypatch):
-    monkeypatch.delenv("MCKPP_KERNEL", raising=False)
+def test_optional_physics_kernel_selection(mk):
     for nz, want in [(40, "k_column_ps<EXT>"), (60, "k_column_ps<EXT>"), (69, "k_column_ps<EXT>"), (150, "k_column_ps<EXT>")]:
         kc = mk.KppConstFields(nz)
         kc.L_DAMP_CURR = 1

@@ -570,29 +570,16 @@ def test_config4_100_levels_slice(mk):
     ctx.close()
 
 
-# ---- kernel variants -------------------------------------------------------------------------
-# The library holds three implementations of the column step: k_column_ps (the default: level phases loop
-# over (slot, level) items, nine LDS rows per column), k_column_pk (packed lanes: a column takes nzp1+2 lanes
-# wherever they fall in the workgroup) and k_column_wg (one wavefront per column, up to 61 levels).
-# MCKPP_KERNEL=wg|pk|ps selects one at init; all must reproduce the oracle's bits on every shape they accept.
+# ---- shapes of the column kernel ---------------------------------------------------------------
+# One kernel (k_column_ps) serves every depth: its level phases loop over (slot, level) items, so the shape of
+# a workgroup (slots, waves, trips of the item loop) changes with nz.  The cases below straddle those changes.
 
-@pytest.fixture
-def kernel_env(monkeypatch):
-    def set_variant(v):
-        if v is None:
-            monkeypatch.delenv("MCKPP_KERNEL", raising=False)
-        else:
-            monkeypatch.setenv("MCKPP_KERNEL", v)
-    return set_variant
-
-
-def test_default_kernel_selection(mk, kernel_env):
-    kernel_env(None)
-    for nz, want in [(10, "k_column_ps"), (40, "k_column_ps"), (60, "k_column_ps"), (69, "k_column_ps"), (150, "k_column_ps")]:
+def test_kernel_name_and_depth_limit(mk):
+    for nz in (10, 40, 60, 69, 150):
         kc = mk.KppConstFields(nz)
         mk.mckpp_physics_lookup(kc)
         ctx = mk.MckppHip(kc)
-        assert ctx.kernel_name == want, (nz, ctx.kernel_name)
+        assert ctx.kernel_name == "k_column_ps", (nz, ctx.kernel_name)
         ctx.close()
     kc = mk.KppConstFields(69)
     kc.LDD = True
@@ -600,43 +587,30 @@ def test_default_kernel_selection(mk, kernel_env):
     ctx = mk.MckppHip(kc)
     assert ctx.kernel_name == "k_column_ps<EXT>"     # optional-physics build
     ctx.close()
-    kernel_env("wg")                                 # the one-wavefront kernel refuses columns it cannot hold
-    with pytest.raises(mk.MckppHipError, match="61 levels"):
-        mk.MckppHip(kc)
-    kernel_env("v1")
-    with pytest.raises(mk.MckppHipError, match="known: wg, pk, ps"):
-        mk.MckppHip(kc)
-    kernel_env(None)
-    kc = mk.KppConstFields(510)                      # a column takes nzp1+2 of the 512 lanes of a workgroup
+    kc = mk.KppConstFields(510)                      # profile rows are padded to at most 512 doubles
     mk.mckpp_physics_lookup(kc)
     with pytest.raises(mk.MckppHipError, match="too deep"):
         mk.MckppHip(kc)
 
 
-@pytest.mark.parametrize("variant", ["wg", "pk", "ps"])
-@pytest.mark.parametrize("nz,ncol,nsteps,grid", [(40, 70, 2, "uniform"), (61, 67, 2, "uniform"), (62, 67, 2, "uniform"),
-                                                 (69, 131, 2, "stretched"), (125, 35, 2, "uniform"),
-                                                 (126, 35, 2, "uniform"), (150, 41, 2, "uniform")])
-def test_every_kernel_variant_bitexact(mk, kernel_env, variant, nz, ncol, nsteps, grid):
-    """Same inputs through each implementation; 61/62 and 125/126 levels straddle the points where a
-    column stops fitting one (two) wave(s) with its two virtual equation-of-state slots."""
-    if variant == "wg" and nz > 61:
-        pytest.skip("k_column_wg holds columns of up to 61 levels")
-    kernel_env(variant)
+@pytest.mark.parametrize("nz,ncol,nsteps,grid", [(12, 90, 2, "uniform"), (40, 70, 2, "uniform"), (61, 67, 2, "uniform"),
+                                                 (62, 67, 2, "uniform"), (69, 131, 2, "stretched"),
+                                                 (125, 35, 2, "uniform"), (126, 35, 2, "uniform"), (150, 41, 2, "uniform")])
+def test_every_depth_bitexact(mk, nz, ncol, nsteps, grid):
+    """12 levels: four small workgroups per CU; 40..69: two workgroups of 8 waves with 13-21 slots, one or two
+    trips of the item loop; 125..150: one 16-wave workgroup.  61/62 and 125/126 levels straddle a wave boundary
+    of a column's items (nzp1 + 2 of them with the two equation-of-state items)."""
     out, k3, ob, kc, oc = _run_both(mk, ncol, nz, nsteps, grid=grid, land_every=5, jerlov_mix=True)
-    want = {"wg": "k_column_wg<", "pk": "k_column_pk", "ps": "k_column_ps"}[variant]
-    assert kc._hip_ctx.kernel_name.startswith(want), kc._hip_ctx.kernel_name
+    assert kc._hip_ctx.kernel_name == "k_column_ps"
     for tag, res in out:
-        _assert_bitexact(res, f"{variant} nz={nz} {tag}")
+        _assert_bitexact(res, f"nz={nz} {tag}")
 
 
-@pytest.mark.parametrize("variant,nz", [("wg", 40), ("wg", 60), ("pk", 40), ("pk", 60), ("pk", 69), ("pk", 100), ("pk", 150),
-                                        ("ps", 40), ("ps", 60), ("ps", 69), ("ps", 100), ("ps", 150)])
-def test_instability_trap_every_variant(mk, kernel_env, variant, nz):
-    """The retry round (violation counts and rmsd sums over lanes of several waves in k_column_pk)."""
+@pytest.mark.parametrize("nz", [40, 60, 69, 100, 150])
+def test_instability_trap_every_depth(mk, nz):
+    """The retry round (violation counts and rmsd sums over the items of a slot, spread over several waves)."""
     from oracle import orc
 
-    kernel_env(variant)
     ncol = 45
     oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1)
     kc, k3 = cm.make_hip_case(ncol, nz)
@@ -659,21 +633,20 @@ def test_instability_trap_every_variant(mk, kernel_env, variant, nz):
         orc.physics_driver(oc, ob, nt)
         st, nf, npass = ctx.status()
         assert np.array_equal(st, ob["status"]) and np.array_equal(npass, ob["npasses"])
-        _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS), f"trap {variant} nz={nz} step {nt}")
+        _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS), f"trap nz={nz} step {nt}")
         flagged |= set(np.nonzero(st & 4)[0].tolist())
     assert set(bad.tolist()) <= flagged
     if nz > 66:
         assert set(deep.tolist()) <= flagged
 
 
-def test_config2_pass_every_variant(mk, kernel_env):
-    """configs[1]-style single vmix+ocnint pass on both kernels."""
+def test_config2_pass_every_depth(mk):
+    """configs[1]-style single vmix+ocnint pass."""
     from oracle import orc
 
     fields = ["U", "V", "T", "S", "hmix", "kmix", "uref", "vref", "rho", "cp", "buoy", "difm", "difs", "dift",
               "ghat", "Rig", "dbloc", "Shsq", "wXNT1"]
-    for variant, nz in [("wg", 60), ("pk", 40), ("pk", 60), ("pk", 69), ("pk", 100), ("pk", 150), ("ps", 40), ("ps", 60), ("ps", 100)]:
-        kernel_env(variant)
+    for nz in (40, 60, 69, 100, 150):
         ncol = 300
         oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1)
         kc, k3 = cm.make_hip_case(ncol, nz)
@@ -681,25 +654,23 @@ def test_config2_pass_every_variant(mk, kernel_env):
         ob["sflux"] = sf
         cm.set_forcing_3d(k3, sf)
         ctx = mk.MckppHip(kc)
-        assert ctx.kernel_name.startswith({"wg": "k_column_wg<", "pk": "k_column_pk", "ps": "k_column_ps"}[variant])
         ctx.upload(k3)
         ctx.vmix_pass(1)
         ctx.download(k3)
         orc.vmix_batch(oc, ob, 1)
-        _assert_bitexact(cm.compare(k3, ob, nz, fields), f"pass {variant} nz={nz}")
+        _assert_bitexact(cm.compare(k3, ob, nz, fields), f"pass nz={nz}")
         ctx.close()
 
 
-@pytest.mark.parametrize("variant,nz", [("wg", 40), ("wg", 60), ("pk", 40), ("pk", 60), ("pk", 69), ("pk", 100), ("ps", 40), ("ps", 60), ("ps", 69), ("ps", 100)])
-def test_tiny_and_denormal_velocities_take_the_ieee_paths(mk, kernel_env, variant, nz):
-    """The kernels drop the v_div_scale rescaling where operand ranges are known and guard the
+@pytest.mark.parametrize("nz", [40, 60, 69, 100])
+def test_tiny_and_denormal_velocities_take_the_ieee_paths(mk, nz):
+    """The kernel drops the v_div_scale rescaling where operand ranges are known and guard the
     quotients whose numerators can be tiny non-zero numbers (velocities diffused down a deep column):
     reference-level averages, Thomas solution numerators.  Profiles of 1e-290 ... denormal velocities
     (and an almost-vanishing wind stress) push those guards into their IEEE fallbacks; the results
     must still be the oracle's bits."""
     from oracle import orc
 
-    kernel_env(variant)
     ncol = 48
     oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1)
     kc, k3 = cm.make_hip_case(ncol, nz)
@@ -714,7 +685,7 @@ def test_tiny_and_denormal_velocities_take_the_ieee_paths(mk, kernel_env, varian
     ob["V_init"][:, 1:nz + 2] = k3.U[:, :, 1]
     ctx = mk.mckpp_initialize_ocean_model(k3, kc)
     orc.init_ocean(oc, ob, 0)
-    _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS), f"tiny {variant} init")
+    _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS), f"tiny nz={nz} init")
     sf = cm.synth.forcing(ncol, "bench")
     sf[::2, 0] = 1e-300      # taux: wU(0,1) = -taux/rho tiny, drives tiny momentum right-hand sides
     sf[::2, 1] = -3e-310     # tauy
@@ -725,7 +696,7 @@ def test_tiny_and_denormal_velocities_take_the_ieee_paths(mk, kernel_env, varian
         orc.physics_driver(oc, ob, nt)
         st, nf, npass = ctx.status()
         assert np.array_equal(st, ob["status"]) and np.array_equal(npass, ob["npasses"])
-        _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS), f"tiny {variant} nz={nz} step {nt}")
+        _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS), f"tiny nz={nz} step {nt}")
     u = np.abs(k3.U[:, :, 0])
     assert np.any((u > 0) & (u < 1e-292))     # the guarded range was really exercised
 
@@ -860,10 +831,9 @@ def test_three_day_diurnal_run_bitexact(mk, nz, grid, nsteps):
     assert max(passes) > 6 and np.ptp(k3.hmix[active]) > 5.0     # the run was not a steady state
 
 
-def test_seeded_sweep_of_shapes_and_forcings(mk, kernel_env):
-    """A seeded sweep over column depths (2 ... 509 levels, including every wave-count boundary),
-    grids, time steps, Jerlov types, land masks and randomly perturbed forcing, three steps each on
-    whatever kernel the library selects - and the same shape on the other cooperative kernel."""
+def test_seeded_sweep_of_shapes_and_forcings(mk):
+    """A seeded sweep over column depths (2 ... 509 levels, including every wave-count boundary of a column's
+    items), grids, time steps, Jerlov types, land masks and randomly perturbed forcing, three steps each."""
     from oracle import orc
 
     rng = np.random.default_rng(20261003)
@@ -873,34 +843,32 @@ def test_seeded_sweep_of_shapes_and_forcings(mk, kernel_env):
         grid = "stretched" if (i % 3 == 1 and nz >= 10) else "uniform"
         dto = [3600.0, 1200.0, 900.0][i % 3]
         ncol = int(rng.integers(3, 40))
-        for variant in ((None, "wg" if 56 > nz else "pk") if nz <= 61 else (None,)):
-            kernel_env(variant)
-            oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1, grid=grid, dto=dto)
-            kc, k3 = cm.make_hip_case(ncol, nz, grid=grid, dto=dto, land_every=int(rng.integers(0, 6)))
-            jer = rng.integers(1, 6, ncol).astype(np.int32)
-            k3.jerlov[:] = jer
-            ob["jerlov"] = jer
-            ctx = mk.mckpp_initialize_ocean_model(k3, kc)
-            orc.init_ocean(oc, ob, 0)
-            active = np.nonzero(k3.run_physics)[0]
-            _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS, active), f"sweep nz={nz} {variant} init")
-            r2 = np.random.default_rng(1000 + i)        # same forcing for both kernels
-            for nt in (1, 2, 3):
-                sf = cm.synth.forcing(ncol, "bench", t_seconds=(nt - 1) * dto + 6 * 3600.0)
-                sf[:, 0] *= r2.uniform(0.0, 3.0, ncol)
-                sf[:, 1] = r2.uniform(-0.2, 0.2, ncol)
-                sf[:, 3] *= r2.uniform(0.0, 2.0, ncol)
-                sf[:, 5] += r2.uniform(-1e-4, 1e-4, ncol)
-                ob["sflux"] = sf
-                cm.set_forcing_3d(k3, sf)
-                mk.mckpp_physics_driver(k3, kc, nt)
-                orc.physics_driver(oc, ob, nt)
-                st, nf, npass = ctx.status()
-                assert np.array_equal(st[active], ob["status"][active]), (nz, variant, nt)
-                assert np.array_equal(npass[active], ob["npasses"][active]), (nz, variant, nt)
-                _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS, active), f"sweep nz={nz} {variant} step {nt}")
-            ctx.close()
-            kc._hip_ctx = None
+        oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1, grid=grid, dto=dto)
+        kc, k3 = cm.make_hip_case(ncol, nz, grid=grid, dto=dto, land_every=int(rng.integers(0, 6)))
+        jer = rng.integers(1, 6, ncol).astype(np.int32)
+        k3.jerlov[:] = jer
+        ob["jerlov"] = jer
+        ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+        orc.init_ocean(oc, ob, 0)
+        active = np.nonzero(k3.run_physics)[0]
+        _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS, active), f"sweep nz={nz} init")
+        r2 = np.random.default_rng(1000 + i)
+        for nt in (1, 2, 3):
+            sf = cm.synth.forcing(ncol, "bench", t_seconds=(nt - 1) * dto + 6 * 3600.0)
+            sf[:, 0] *= r2.uniform(0.0, 3.0, ncol)
+            sf[:, 1] = r2.uniform(-0.2, 0.2, ncol)
+            sf[:, 3] *= r2.uniform(0.0, 2.0, ncol)
+            sf[:, 5] += r2.uniform(-1e-4, 1e-4, ncol)
+            ob["sflux"] = sf
+            cm.set_forcing_3d(k3, sf)
+            mk.mckpp_physics_driver(k3, kc, nt)
+            orc.physics_driver(oc, ob, nt)
+            st, nf, npass = ctx.status()
+            assert np.array_equal(st[active], ob["status"][active]), (nz, nt)
+            assert np.array_equal(npass[active], ob["npasses"][active]), (nz, nt)
+            _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS, active), f"sweep nz={nz} step {nt}")
+        ctx.close()
+        kc._hip_ctx = None
 
 
 def test_full_size_soak_determinism_and_sample_parity(mk):
@@ -944,12 +912,13 @@ def test_full_size_soak_determinism_and_sample_parity(mk):
     _assert_bitexact(cm.compare(sub, ob, nz, cm.PROFILE_FIELDS + cm.SCALAR_FIELDS + ["hmixd0", "hmixd1"]), "soak sample")
 
 
-@pytest.mark.parametrize("nz,ncol,want", [(60, 20000, 2), (40, 20000, 2), (69, 20000, 2), (100, 20000, 2), (150, 20000, 2)])
-def test_tuned_residency_is_what_the_device_grants(mk, kernel_env, nz, ncol, want):
-    """The cooperative kernel is tuned to a number of resident workgroups per CU (k_column_ps: two workgroups
-    of 8 waves at <= 128 VGPRs, each with as many slots as half the CU's LDS holds).  One more LDS row or a few
-    more registers silently drops a workgroup per CU (-40 %), so ask the runtime."""
-    kernel_env(None)
+@pytest.mark.parametrize("nz,ncol,want", [(60, 20000, 2), (40, 20000, 4), (69, 20000, 2), (100, 20000, 1), (150, 20000, 1),
+                                          (60, 3000, None)])
+def test_tuned_residency_is_what_the_device_grants(mk, nz, ncol, want):
+    """The cooperative kernel is tuned to a number of resident workgroups per CU (two workgroups of 8 waves at
+    <= 128 VGPRs at 60 levels, each with as many slots as half the CU's LDS holds; four of 4 waves for shallow
+    columns, one of 16 for deep ones; fewer slots when a CU has few columns to work through).  One more LDS row
+    or a few more registers silently drops a workgroup per CU (-40 %), so ask the runtime."""
     kc, k3 = cm.make_hip_case(ncol, nz)
     ctx = mk.MckppHip(kc)
     ctx.upload(k3)
@@ -957,12 +926,12 @@ def test_tuned_residency_is_what_the_device_grants(mk, kernel_env, nz, ncol, wan
     ctx.step(1, 1)
     ctx.synchronize()
     asked, fit, threads, lds = ctx.kernel_residency()
-    assert asked == want and fit >= asked, (ctx.kernel_name, asked, fit, threads, lds)
+    assert (want is None or asked == want) and fit >= asked, (ctx.kernel_name, asked, fit, threads, lds)
     ctx.close()
 
 
-@pytest.mark.parametrize("variant,nz", [("wg", 60), ("pk", 60), ("pk", 100), ("ps", 60), ("ps", 100)])
-def test_zero_pivot_on_device(mk, kernel_env, variant, nz):
+@pytest.mark.parametrize("nz", [60, 100])
+def test_zero_pivot_on_device(mk, nz):
     """The reference STOPs when the Thomas pivot vanishes (src/mckpp_physics_solvers.F90:140-151); the
     device sets MCKPP_ST_ZERO_PIVOT, continues with bet = 1e-12 and lets the instability trap deal with
     whatever comes out.  A crafted tri() makes cc(i) - cu(i) gam(i) exactly zero for the momentum system - once at
@@ -972,7 +941,6 @@ def test_zero_pivot_on_device(mk, kernel_env, variant, nz):
     oracle's, bit for bit, through the retries and the final reset."""
     from oracle import orc
 
-    kernel_env(variant)
     ncol = 70
     hit = 0
     for level in (nz - 6, nz):
@@ -983,7 +951,6 @@ def test_zero_pivot_on_device(mk, kernel_env, variant, nz):
         oc.tri0[level] = 0.0
         oc.tri1[level] = -1.0e4
         ctx = mk.mckpp_initialize_ocean_model(k3, kc)
-        assert ctx.kernel_name.startswith({"wg": "k_column_wg", "pk": "k_column_pk", "ps": "k_column_ps"}[variant])
         orc.init_ocean(oc, ob, 0)
         sf = cm.synth.forcing(ncol, "bench")
         ob["sflux"] = sf
@@ -992,9 +959,9 @@ def test_zero_pivot_on_device(mk, kernel_env, variant, nz):
             mk.mckpp_physics_driver(k3, kc, nt)
             orc.physics_driver(oc, ob, nt)
             st, nf, npass = ctx.status()
-            assert np.array_equal(st, ob["status"]), (variant, nz, level, nt)
+            assert np.array_equal(st, ob["status"]), (nz, level, nt)
             assert np.array_equal(npass, ob["npasses"])
-            _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS), f"zero pivot {variant} nz={nz} level {level} step {nt}")
+            _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS), f"zero pivot nz={nz} level {level} step {nt}")
             assert (st & orc.ST_ZERO_PIVOT).any(), (level, nt, st)       # columns whose level still has the background 1e-4
             hit += int(((st & orc.ST_ZERO_PIVOT) != 0).sum())
         ctx.close()
@@ -1002,14 +969,13 @@ def test_zero_pivot_on_device(mk, kernel_env, variant, nz):
     assert hit >= ncol        # most columns, at one level or the other
 
 
-@pytest.mark.parametrize("variant,nz", [("wg", 60), ("pk", 100)])
-def test_long_iteration_status_on_device(mk, kernel_env, variant, nz):
+@pytest.mark.parametrize("nz", [60, 100])
+def test_long_iteration_status_on_device(mk, nz):
     """MCKPP_ST_LONG_ITER (src/mckpp_physics_ocnstep_mod.F90:171-191): with itermax = 4 the second model
     step from the analytic start profile (which needs ~30 passes per column at itermax = 200) keeps
     iterating only while hmix deepens, and columns that go beyond itermax+1 passes are flagged."""
     from oracle import orc
 
-    kernel_env(variant)
     ncol = 120
     oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1, itermax=4)
     kc, k3 = cm.make_hip_case(ncol, nz)
@@ -1025,21 +991,20 @@ def test_long_iteration_status_on_device(mk, kernel_env, variant, nz):
         orc.physics_driver(oc, ob, nt)
         st, nf, npass = ctx.status()
         assert np.array_equal(st, ob["status"]) and np.array_equal(npass, ob["npasses"])
-        _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS), f"long iteration {variant} nz={nz} step {nt}")
+        _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS), f"long iteration nz={nz} step {nt}")
         long_it = (st & orc.ST_LONG_ITER) != 0
         assert np.all(npass[long_it] > 5)
         seen += int(long_it.sum())
     assert seen > 0, "no column exceeded itermax+1 passes"
 
 
-@pytest.mark.parametrize("variant,nz", [("wg", 60), ("pk", 40), ("pk", 60), ("pk", 69), ("pk", 100), ("ps", 40), ("ps", 60), ("ps", 100)])
-def test_verticalmixing_alone(mk, kernel_env, variant, nz):
+@pytest.mark.parametrize("nz", [40, 60, 69, 100])
+def test_verticalmixing_alone(mk, nz):
     """mckpp_hip_vmix_only = mckpp_physics_verticalmixing (src/mckpp_physics_verticalmixing_mod.F90:14) by
     itself, the third routine of the reference's call surface: after two model steps, one more vmix on the
     resident state must give the oracle's hmixn / kmixn and vmix diagnostics and leave the state alone."""
     from oracle import orc
 
-    kernel_env(variant)
     ncol = 150
     oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1)
     kc, k3 = cm.make_hip_case(ncol, nz, land_every=7)
@@ -1058,7 +1023,7 @@ def test_verticalmixing_alone(mk, kernel_env, variant, nz):
     ctx.download(k3)
     fields = ["hmix", "kmix", "uref", "vref", "rho", "cp", "buoy", "difm", "difs", "dift", "ghat", "Rig", "dbloc",
               "Shsq", "wXNT1"]
-    _assert_bitexact(cm.compare(k3, ob, nz, fields, active), f"vmix only {variant} nz={nz}")
+    _assert_bitexact(cm.compare(k3, ob, nz, fields, active), f"vmix only nz={nz}")
     assert np.array_equal(k3.wU[active, 0, :2], np.stack([ob["wU1"][active, 0], ob["wU2"][active, 0]], axis=1))
     for n, v in before.items():
         assert np.array_equal(getattr(k3, n), v), n

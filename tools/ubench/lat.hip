@@ -1,5 +1,5 @@
 // Single-wave latency / issue micro-benchmarks for gfx950 (one workgroup of 64 lanes, few lanes active as in
-// the manager phases of k_column_pk).  Prints shader-clock cycles per operation.
+// the manager phases of the column kernel).  Prints shader-clock cycles per operation.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define N 2048
