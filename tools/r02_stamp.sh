@@ -8,7 +8,7 @@ rm -f /tmp/st/mckpp_f90_amd/csrc/*.o
 make -C /tmp/st/mckpp_f90_amd/csrc EXTRA="-DMCKPP_PS_STAMPS" > /tmp/st/build.log 2>&1 || { tail -5 /tmp/st/build.log; exit 1; }
 cp mckpp_f90_amd/libmckpp_hip.so /tmp/lib_keep.so
 cp /tmp/st/mckpp_f90_amd/libmckpp_hip.so mckpp_f90_amd/libmckpp_hip.so
-B="python bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 2"
+B="python bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 2 $BENCH_ARGS"   # BENCH_ARGS: e.g. "--grid stretched --dto 1200 --land 0.35"
 for cfg in ${CFGS:-40 60 69 100}; do
   IFS=: read nz g <<< "$cfg"
   if [ -z "$g" ]; then
