@@ -189,7 +189,8 @@ __device__ __forceinline__ wscale_u wscale_prepare(double ustar)
   return w;
 }
 
-__device__ __forceinline__ void wscale_dev(const mckpp_kparams &p, const wscale_u &w, double sigma,
+template <class KP>
+__device__ __forceinline__ void wscale_dev(const KP &p, const wscale_u &w, double sigma,
                                            double hbl, double bfsfc, double &wm, double &ws)
 {
   const double zmin = -4.e-7, zmax = 0.0, c1 = 5.0;
@@ -203,13 +204,14 @@ __device__ __forceinline__ void wscale_dev(const mckpp_kparams &p, const wscale_
     iz = iz > 0 ? iz : 0;
     double zfrac = q - (double)iz;
     double fzfrac = 1. - zfrac;
-    const double2 *r0 = p.wtab + (size_t)w.ju * NT + iz;
-    double2 t00 = r0[0], t10 = r0[1], t01 = r0[NT], t11 = r0[NT + 1];
-    double wam = (fzfrac)*t01.x + zfrac * t11.x;
-    double wbm = (fzfrac)*t00.x + zfrac * t10.x;
+    const auto r0 = p.wtab + 2 * ((size_t)w.ju * NT + iz), r1 = r0 + 2 * NT;   // {wmt, wst} pairs
+    const double t00x = r0[0], t00y = r0[1], t10x = r0[2], t10y = r0[3];
+    const double t01x = r1[0], t01y = r1[1], t11x = r1[2], t11y = r1[3];
+    double wam = (fzfrac)*t01x + zfrac * t11x;
+    double wbm = (fzfrac)*t00x + zfrac * t10x;
     wm = (1. - w.ufrac) * wbm + w.ufrac * wam;
-    double was = (fzfrac)*t01.y + zfrac * t11.y;
-    double wbs = (fzfrac)*t00.y + zfrac * t10.y;
+    double was = (fzfrac)*t01y + zfrac * t11y;
+    double wbs = (fzfrac)*t00y + zfrac * t10y;
     ws = (1. - w.ufrac) * wbs + w.ufrac * was;
   } else {
     const double den = w.ucube + c1 * zehat;

@@ -30,7 +30,15 @@ enum { CI_OLD = 0, CI_NEW, CI_JERLOV, CI_INITFLAG, CI_STATUS, CI_NPASS, CI_LOCEA
 // (configs[1]); VMIX: mckpp_physics_verticalmixing alone - diagnostics and hmix/kmix only, state untouched
 enum { MCKPP_MODE_STEP = 0, MCKPP_MODE_INIT = 1, MCKPP_MODE_PASS = 2, MCKPP_MODE_VMIX = 3 };
 
-struct mckpp_kparams {
+// The kernel parameter block, once with plain pointers (host code, by-value kernel arguments) and once with
+// pointers typed as global memory: a pointer that a kernel loads from the block in memory is otherwise a generic
+// pointer - flat instructions, 64-bit VGPR address arithmetic, LDS waits tied to memory traffic - whereas
+// through mckpp_kparams_dev (same layout) every access is a global_load / global_store.
+template <class T> using mckpp_ptr_plain = T *;
+template <class T> using mckpp_ptr_global = __attribute__((address_space(1))) T *;
+
+template <template <class> class P>
+struct mckpp_kparams_t {
   int nz, nzp1, ncol, ld;
   int ntime, itermax, mode, diag;
   int L_SSref, LDD, clim_present, pad0;
@@ -39,37 +47,40 @@ struct mckpp_kparams {
   double cg;      // blmix_mod.F90:62, host-evaluated (libm pow)
   double dm_nz;   // dm(NZ)
   // constants, device pointers; Fortran-indexed, padded to ldc doubles
-  const double *zm, *hm, *tri0, *tri1;
-  const double *swfrac_tab;  // [6][ldc]  swfrac(k), k=1..nzp1, per Jerlov type
-  const double *swdk_tab;    // [6][ldc]  swdk_opt(k), k=0..nz
+  P<const double> zm, hm, tri0, tri1;
+  P<const double> swfrac_tab;  // [6][ldc]  swfrac(k), k=1..nzp1, per Jerlov type
+  P<const double> swdk_tab;    // [6][ldc]  swdk_opt(k), k=0..nz
   int ldc, pad1;
-  const double2 *wtab;       // [(NJ+2)][(NI+2)] {wmt, wst}
+  P<const double> wtab;        // [(NJ+2)][(NI+2)] pairs {wmt, wst}
   // state
-  double *U, *V, *T, *S;
-  double *Us[2], *Vs[2], *Ts[2], *Ss[2];
-  const double *U_init, *V_init;
-  double *cs;
-  int *ci;
-  int *qhead;   // column queue head for the persistent cooperative kernel (zeroed per launch)
-  unsigned long long *dbg;   // optional [16] phase-cycle accumulators (diagnostic builds of a run only)
+  P<double> U, V, T, S;
+  P<double> Us[2], Vs[2], Ts[2], Ss[2];
+  P<const double> U_init, V_init;
+  P<double> cs;
+  P<int> ci;
+  P<int> qhead;   // column queue head for the persistent cooperative kernel (zeroed per launch)
+  P<unsigned long long> dbg;   // optional [32] phase-cycle accumulators (diagnostic builds of a run only)
   // optional physics: ext != 0 selects the kernel build that carries it
   int ext, L_RELAX_SST, L_RELAX_CALCONLY, L_FCORR, L_FCORR_WITHZ, L_SFCORR, L_SFCORR_WITHZ;
   int L_RELAX_SAL, L_RELAX_OCNT, L_NO_FREEZE, L_NO_ISOTHERM, L_DAMP_CURR, iso_bot, dt_uvdamp, maxmodeadv;
   double iso_thresh;
-  const double *dm;      // dm(0:nz)
-  const double *hsum;    // hsum(n) = hm(1)+...+hm(n), summed in that order (rhsmod's delta)
-  const double *xs;      // [ncol][MCKPP_XS]: relax_sst, SST0, fcorr_twod, relax_sal, relax_ocnT
-  const double *fcorr_withz, *sfcorr_withz, *ocnT_clim, *sal_clim;   // profile rows
-  double *tinc_fcorr, *sinc_fcorr, *ocnTcorr, *scorr;                // diagnostic rows
-  const int *adv_i;      // [ncol][1+maxmodeadv]: nmodeadv(2), modeadv(:,2)
-  const double *adv_d;   // [ncol][maxmodeadv]:   advection(:,2)
+  P<const double> dm;      // dm(0:nz)
+  P<const double> hsum;    // hsum(n) = hm(1)+...+hm(n), summed in that order (rhsmod's delta)
+  P<const double> xs;      // [ncol][MCKPP_XS]: relax_sst, SST0, fcorr_twod, relax_sal, relax_ocnT
+  P<const double> fcorr_withz, sfcorr_withz, ocnT_clim, sal_clim;   // profile rows
+  P<double> tinc_fcorr, sinc_fcorr, ocnTcorr, scorr;                // diagnostic rows
+  P<const int> adv_i;      // [ncol][1+maxmodeadv]: nmodeadv(2), modeadv(:,2)
+  P<const double> adv_d;   // [ncol][maxmodeadv]:   advection(:,2)
   // diagnostics (all or none)
-  double *rho, *cp, *buoy, *talpha, *sbeta, *difm, *difs, *dift, *ghat;
-  double *wU1, *wU2, *wX1, *wX2, *wX3, *wXNT1, *Rig, *dbloc, *Shsq;
+  P<double> rho, cp, buoy, talpha, sbeta, difm, difs, dift, ghat;
+  P<double> wU1, wU2, wX1, wX2, wX3, wXNT1, Rig, dbloc, Shsq;
   // k_column_ps: the iterate's scratch rows, one block per (workgroup, slot) (mckpp_ps_scratch_doubles)
-  double *scratch;
+  P<double> scratch;
   size_t scratch_doubles;
 };
+using mckpp_kparams = mckpp_kparams_t<mckpp_ptr_plain>;
+using mckpp_kparams_dev = mckpp_kparams_t<mckpp_ptr_global>;
+static_assert(sizeof(mckpp_kparams) == sizeof(mckpp_kparams_dev), "same layout");
 
 // what the last cooperative-kernel launch looked like (for the residency check of the tests)
 struct mckpp_launch_info { int nblocks, threads, max_blocks_per_cu; size_t lds_bytes; };

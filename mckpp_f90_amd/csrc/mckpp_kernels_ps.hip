@@ -284,7 +284,8 @@ template <bool EXT>
 __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_kparams *__restrict__ pp, const int ntime, const int L,
                                                      const int W, const unsigned Lmagic)
 {
-  const mckpp_kparams &p = *pp;
+  // through the block typed with global pointers (mckpp_device.h): global_load / global_store, SGPR bases
+  const mckpp_kparams_dev &p = *reinterpret_cast<const mckpp_kparams_dev *>(pp);
   extern __shared__ double lds[];
   constexpr int ROWS = EXT ? (int)Q_COUNT_EXT : (int)Q_COUNT;
   const int NL = ps_nl(L), SS = ps_ss(L, EXT);
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // index = level-1, each element read and rewritten in place by the one item that owns it.  The block is
   // reused by every column the slot serves, so it stays in L2.
   const int LS = ps_scratch_ld(nzp1);
-  double *const scr0 = p.scratch + (size_t)blockIdx.x * (size_t)W * (size_t)(4 * LS);
+  const auto scr0 = p.scratch + (size_t)blockIdx.x * (size_t)W * (size_t)(4 * LS);
 
 // one level-parallel phase: every active (slot, level) item, strided by the workgroup's threads
 #define FOR_ITEMS                                                                         \
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     const bool is1 = k == 1, isnz = k == nz, isnzp1 = k == nzp1;                          \
     const int kr = act ? k : 1;                                                           \
     const size_t ro = (size_t)col * p.ld;                                                 \
-    double *const xs_ = scr0 + (size_t)slot * (size_t)(4 * LS) + (kr - 1);   /* iterate U, V, T, S of this item */ \
+    const auto xs_ = scr0 + (size_t)slot * (size_t)(4 * LS) + (kr - 1);   /* iterate U, V, T, S of this item */ \
     auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };             \
     (void)sc; (void)actz; (void)virt1; (void)virt2; (void)is1; (void)isnz; (void)isnzp1; (void)kr; (void)ro; (void)xs_;
 #define END_ITEMS }
@@ -373,15 +374,15 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       int st = msi[I_STATE];
       if (st == PS_ACTIVE && msi[I_FIN] == F_FINAL) st = PS_EMPTY;   // its outputs are stored (barrier before M0)
       if (st == PS_EMPTY) {
-        const int c = atomicAdd(p.qhead, 1);
+        const int c = atomicAdd((int *)p.qhead, 1);
         msi[I_FIN] = F_NONE;
         if (c >= p.ncol) {
           st = PS_DONE;
           msi[I_ACT] = 0;
         } else {
           st = PS_ACTIVE;
-          const int *ci = p.ci + (size_t)c * MCKPP_CI;
-          const double *cs = p.cs + (size_t)c * MCKPP_CS;
+          const auto ci = p.ci + (size_t)c * MCKPP_CI;
+          const auto cs = p.cs + (size_t)c * MCKPP_CS;
           int old = ci[CI_OLD], newi = ci[CI_NEW], status = 0;
           if (old < 0 || old > 1) { old = newi; status |= 16; }
           if (newi < 0 || newi > 1) { newi = old; status |= 16; }
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   auto ext_rhs = [&](double *my, const int *si, int col, int k, int kmixe, double To_k, double So_k, double &rhsT,
                      double &rhsS) {
     const double dto = p.dto;
-    const double *xs = p.xs + (size_t)col * MCKPP_XS;
+    const auto xs = p.xs + (size_t)col * MCKPP_XS;
     const double rhok = my[k * ROWS + Q_RHO], cpk = my[k * ROWS + Q_CP];
     const size_t oin = (size_t)col * p.ld + (k - 1);
     if (k == 1) {
@@ -598,8 +599,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     rhsT = rhsT + tinc;
     const double ocnTcorr = tinc * rhok * cpk / dto;
     // prescribed advection of salinity, rhsmod with jsclr = 2 (:179-184)
-    const int *ai = p.adv_i + (size_t)col * (p.maxmodeadv + 1);
-    const double *ad = p.adv_d + (size_t)col * (p.maxmodeadv + 1);
+    const auto ai = p.adv_i + (size_t)col * (p.maxmodeadv + 1);
+    const auto ad = p.adv_d + (size_t)col * (p.maxmodeadv + 1);
     const int nmode = ai[0];
     const int nzi = nz, km = kmixe;
     for (int im = 0; im < nmode; ++im) {
@@ -1186,7 +1187,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         }
       }
       if (fstep && is1) {   // level-1 references, before any override touches the profiles
-        double *cs = p.cs + (size_t)col * MCKPP_CS;
+        const auto cs = p.cs + (size_t)col * MCKPP_CS;
         cs[CS_UREF] = U; cs[CS_VREF] = V; cs[CS_TREF] = T;
         cs[CS_SSURF] = p.L_SSref ? cs[CS_SSREF] : S + sc[C_SREF];
       }
@@ -1243,8 +1244,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     FOR_ITEMS
       if (!act) continue;   // the two equation-of-state items exist for L1 only
       if (si[I_FIN] != F_FINAL) continue;
-      double *cs = p.cs + (size_t)col * MCKPP_CS;
-      int *ci = p.ci + (size_t)col * MCKPP_CI;
+      const auto cs = p.cs + (size_t)col * MCKPP_CS;
+      const auto ci = p.ci + (size_t)col * MCKPP_CI;
       const size_t o = ro + (k - 1);
       if (p.mode == MCKPP_MODE_STEP) {
         double reset_out = (double)si[I_NRESET];
@@ -1335,8 +1336,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   }
 #ifdef MCKPP_PS_STAMPS
   if (p.dbg && wv == mgr && lane == 0) {
-    for (int i = 0; i < 23; ++i) atomicAdd(p.dbg + i, tacc[i]);
-    atomicAdd(p.dbg + 31, tacc[23]);
+    for (int i = 0; i < 23; ++i) atomicAdd((unsigned long long *)p.dbg + i, tacc[i]);
+    atomicAdd((unsigned long long *)p.dbg + 31, tacc[23]);
   }
 #endif
 #undef STAMP

@@ -594,7 +594,7 @@ static void fill_params(mckpp_hip_ctx *h, mckpp_kparams &p, int ntime, int mode)
   p.hmixtolfrac = h->c.hmixtolfrac; p.dto = h->c.dto; p.grav = h->c.grav; p.vonk = h->c.vonk; p.sice = h->c.sice;
   p.Vtc = h->Vtc; p.cg = h->cg; p.dm_nz = h->dm_nz;
   p.zm = h->d_zm; p.hm = h->d_hm; p.tri0 = h->d_tri0; p.tri1 = h->d_tri1;
-  p.swfrac_tab = h->d_swfrac_tab; p.swdk_tab = h->d_swdk_tab; p.ldc = h->ldc; p.wtab = h->d_wtab;
+  p.swfrac_tab = h->d_swfrac_tab; p.swdk_tab = h->d_swdk_tab; p.ldc = h->ldc; p.wtab = reinterpret_cast<const double *>(h->d_wtab);
   p.U = h->d_prof[P_U]; p.V = h->d_prof[P_V]; p.T = h->d_prof[P_T]; p.S = h->d_prof[P_S];
   p.Us[0] = h->d_prof[P_US0]; p.Us[1] = h->d_prof[P_US1]; p.Vs[0] = h->d_prof[P_VS0]; p.Vs[1] = h->d_prof[P_VS1];
   p.Ts[0] = h->d_prof[P_TS0]; p.Ts[1] = h->d_prof[P_TS1]; p.Ss[0] = h->d_prof[P_SS0]; p.Ss[1] = h->d_prof[P_SS1];
