@@ -342,6 +342,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // the iterate of the under-relaxation between passes: four scratch rows per (workgroup, slot), element
   // index = level-1, each element read and rewritten in place by the one item that owns it.  The block is
   // reused by every column the slot serves, so it stays in L2.
+  double rU = 0.0, rV = 0.0, rT = 0.0, rS = 0.0;   // the iterate of this thread's first item (the others: scratch)
   const int LS = ps_scratch_ld(nzp1);
   const auto scr0 = p.scratch + (size_t)blockIdx.x * (size_t)W * (size_t)(4 * LS);
 
@@ -360,8 +361,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     const int kr = act ? k : 1;                                                           \
     const size_t ro = (size_t)col * p.ld;                                                 \
     const auto xs_ = scr0 + (size_t)slot * (size_t)(4 * LS) + (kr - 1);   /* iterate U, V, T, S of this item */ \
+    const bool first_ = it_ < nthreads;   /* the thread's first item: its iterate stays in registers */   \
     auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };             \
-    (void)sc; (void)actz; (void)virt1; (void)virt2; (void)is1; (void)isnz; (void)isnzp1; (void)kr; (void)ro; (void)xs_;
+    (void)sc; (void)actz; (void)virt1; (void)virt2; (void)is1; (void)isnz; (void)isnzp1; (void)kr; (void)ro; (void)xs_; (void)first_;
 #define END_ITEMS }
 
   // =========================== manager phases (wave 0) ===========================
@@ -691,8 +693,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           S = 2. * sn - so;
           yu = U; yv = V; yt = T; ys = S;
         } else {
-          U = act ? xs_[0] : 0.0; V = act ? xs_[LS] : 0.0; S = act ? xs_[3 * LS] : 0.0;
-          T = act ? xs_[2 * LS] : sc[C_T1X + par];   // the two EOS items follow level 1, whose item rewrites it now
+          if (first_) { U = rU; V = rV; T = rT; S = rS; }
+          else if (act) { U = xs_[0]; V = xs_[LS]; T = xs_[2 * LS]; S = xs_[3 * LS]; }
+          if (!act) T = sc[C_T1X + par];   // the two EOS items follow level 1, whose item rewrites it now
           yu = row(Q_YU)[kr]; yv = row(Q_YV)[kr]; yt = row(Q_YT)[kr]; ys = row(Q_YS)[kr];
         }
         // under-relaxation, ocnstep_mod.F90:123-132 / :142-151 (an EOS item follows level 1's temperature)
@@ -701,7 +704,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           U = lambda * U + (1 - lambda) * yu;
           V = lambda * V + (1 - lambda) * yv;
           S = lambda * S + (1 - lambda) * ys;
-          xs_[0] = U; xs_[LS] = V; xs_[2 * LS] = T; xs_[3 * LS] = S;
+          if (first_) { rU = U; rV = V; rT = T; rS = S; }
+          else { xs_[0] = U; xs_[LS] = V; xs_[2 * LS] = T; xs_[3 * LS] = S; }
           if (is1) sc[C_T1X + (par ^ 1)] = T;
         }
       } else {
@@ -987,7 +991,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         const double wX0_1 = sc[C_WX01], wX0_2 = sc[C_WX02];
         const strided<ROWS> yU = row(Q_YU), yT = row(Q_YT), yS = row(Q_YS);
         if (actz) {
-          const double V = xs_[LS];   // of the iterate (its row holds ghat by now)
+          const double V = first_ ? rV : xs_[LS];   // of the iterate (its row holds ghat by now)
           const double difm = row(Q_DM)[k], difs = aDs[k], dift = aDt[k], ghat = aGh[k];
           const int jer = si[I_JER];
           const double rho0cp0 = sc[C_RHO0CP0], r_rc = sc[C_RRC], sflux3 = sc[C_SFLUX3];
@@ -1372,7 +1376,7 @@ ps_geom ps_choose(int L, bool ext, size_t cu_lds_bytes, int cols_per_cu, int *ma
       const int trips = (w * L + threads - 1) / threads;
       const double pass = serial * L + trip * trips + other;
       const int busy = per_cu * w < cols_per_cu ? per_cu * w : cols_per_cu;
-      const double rate = busy / pass;
+      const double rate = (per_cu == 1 ? 0.93 : 1.0) * busy / pass;   // measured: the fit flatters the lone workgroup by 5-7 %
       if (rate > best_rate * 1.0001) { best_rate = rate; best = {nw, w, per_cu}; }
     }
   }
