@@ -606,6 +606,47 @@ def test_every_depth_bitexact(mk, nz, ncol, nsteps, grid):
         _assert_bitexact(res, f"nz={nz} {tag}")
 
 
+@pytest.mark.parametrize("nz,geometry", [(60, "1x1x1"), (60, "3x2x4"), (60, "16x4x2"), (60, "21x16x1"), (60, "5x8x2"),
+                                         (23, "21x2x4"), (150, "3x4x2"), (150, "13x16x1")])
+def test_forced_workgroup_geometries(mk, monkeypatch, nz, geometry):
+    """MCKPP_PS=<slots>x<waves>x<workgroups per CU> forces shapes the launcher would not pick: a single-wave
+    workgroup (the manager wave does all the level work too), one to six trips of the item loop, 21 slots (all 63
+    manager lanes of the U,T,S sweeps), more workgroups than the queue has columns for.  Trapped columns
+    included, so the finish round's counts and sums run on those shapes as well."""
+    from oracle import orc
+
+    monkeypatch.setenv("MCKPP_PS", geometry)
+    slots, waves, per_cu = (int(x) for x in geometry.split("x"))
+    ncol = 97
+    oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1)
+    kc, k3 = cm.make_hip_case(ncol, nz, land_every=6)
+    jer = 1 + (np.arange(ncol) % 5).astype(np.int32)
+    k3.jerlov[:] = jer
+    ob["jerlov"] = jer
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    orc.init_ocean(oc, ob, 0)
+    active = np.nonzero(k3.run_physics)[0]
+    _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS, active), f"{geometry} init")
+    bad = np.arange(3, ncol, 7)
+    k3.U[bad, 0:4, 0] = 50.0
+    ob["U"][bad, 1:5] = 50.0
+    ctx.upload(k3)
+    sf = cm.synth.forcing(ncol, "bench")
+    ob["sflux"] = sf
+    cm.set_forcing_3d(k3, sf)
+    trapped = np.zeros(ncol, dtype=bool)
+    for nt in (1, 2):
+        mk.mckpp_physics_driver(k3, kc, nt)
+        orc.physics_driver(oc, ob, nt)
+        st, nf, npass = ctx.status()
+        assert np.array_equal(st[active], ob["status"][active]) and np.array_equal(npass[active], ob["npasses"][active])
+        _assert_bitexact(cm.compare(k3, ob, nz, ALL_FIELDS, active), f"{geometry} nz={nz} step {nt}")
+        trapped |= (st & 4) != 0
+    asked, fit, threads, lds = ctx.kernel_residency()
+    assert threads == 64 * waves, (geometry, threads)
+    assert trapped[np.intersect1d(bad, active)].all()      # the trap fired on every bad ocean column
+
+
 @pytest.mark.parametrize("nz", [40, 60, 69, 100, 150])
 def test_instability_trap_every_depth(mk, nz):
     """The retry round (violation counts and rmsd sums over the items of a slot, spread over several waves)."""
