@@ -40,7 +40,7 @@ enum {
 enum {
   I_STATE = 0, I_ACT, I_COL, I_OLD, I_NEW, I_JER, I_INITFLAG, I_STATUS, I_NPASS, I_NPASS_TRY, I_ICONV, I_COMP, I_KMIXN,
   I_KBL, I_NRESET, I_FIN, I_MAYBE, I_LOAD /* 1: new column, 2: restart the iteration (trap retry) */, I_JU,
-  I_KBLC, I_NVIOL, I_NOVER, I_NU, I_NV, I_NF, I_BAD, I_LOCEAN, I_PAR /* which C_T1X holds the iterate's level-1 temperature */, I_COUNT
+  I_KBLC, I_NVIOL, I_NOVER, I_NU, I_NV, I_NF, I_BAD, I_L1A /* L1 but for V done ahead, during the V sweep */, I_MAYBE_NEXT, I_LOCEAN, I_PAR /* which C_T1X holds the iterate's level-1 temperature */, I_COUNT
 };
 // LDS rows of a slot and what each holds between which phases of a pass:
 //   Q_DM   (LDD talpha L1..L2)  difm: interior L3, final L5 .. M5 (V sweep, U system's diffusivity)
@@ -332,7 +332,10 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 #endif
 
   // ---- work items (slot, level) ------------------------------------------------
+  // Item `it` of the first trip belongs to thread `it`; the later trips are dealt to the waves other than the
+  // manager's only (it has its serial phases to run): item nthreads + t*(nthreads-64) + (tid-64) in trip t+1.
   const int nthreads = blockDim.x, nitems = W * L;
+  const int nhelp = nthreads > 64 ? nthreads - 64 : 64, tid2 = nthreads > 64 ? tid - 64 : tid;
   __syncthreads();
 
   const double lambda = 0.5;
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 
 // one level-parallel phase: every active (slot, level) item, strided by the workgroup's threads
 #define FOR_ITEMS                                                                         \
-  for (int it_ = tid; it_ < nitems; it_ += nthreads) {                                    \
+  for (int it_ = tid, t_ = 0; it_ < nitems; it_ = tid2 >= 0 ? nthreads + t_ * nhelp + tid2 : nitems, ++t_) { \
     const int slot = (int)__umulhi((unsigned)it_, Lmagic);                                \
     const int k = it_ - slot * L + 1;                                                     \
     int *const si = sirec + slot * I_COUNT;                                               \
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     const int kr = act ? k : 1;                                                           \
     const size_t ro = (size_t)col * p.ld;                                                 \
     const auto xs_ = scr0 + (size_t)slot * (size_t)(4 * LS) + (kr - 1);   /* iterate U, V, T, S of this item */ \
-    const bool first_ = it_ < nthreads;   /* the thread's first item: its iterate stays in registers */   \
+    const bool first_ = t_ == 0;   /* the thread's first item: its iterate stays in registers */          \
     auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };             \
     (void)sc; (void)actz; (void)virt1; (void)virt2; (void)is1; (void)isnz; (void)isnzp1; (void)kr; (void)ro; (void)xs_; (void)first_;
 #define END_ITEMS }
@@ -395,6 +398,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           msi[I_NRESET] = 0; msi[I_KMIXN] = 0; msi[I_KBL] = 0; msi[I_LOAD] = 1; msi[I_BAD] = 0;
           msi[I_MAYBE] = (p.mode != MCKPP_MODE_STEP) ? 1 : 0;
           msi[I_KBLC] = 0x7fffffff; msi[I_NVIOL] = 0; msi[I_NU] = 0; msi[I_NV] = 0; msi[I_NF] = 0; msi[I_PAR] = 0;
+          msi[I_L1A] = 0; msi[I_MAYBE_NEXT] = msi[I_MAYBE];
           msc[C_F] = cs[CS_F]; msc[C_WXNT0] = 0.0; msc[C_HMIXE] = 0.0; msc[C_HMIXN] = 0.0;
           msc[C_SREF] = cs[CS_SREF]; msc[C_SSURF] = cs[CS_SSURF]; msc[C_OCDEPTH] = cs[CS_OCDEPTH];
           msc[C_SFLUX1] = cs[CS_SFLUX1]; msc[C_SFLUX2] = cs[CS_SFLUX2]; msc[C_SFLUX3] = cs[CS_SFLUX3];
@@ -415,6 +419,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       double *msc = screc + lane * C_COUNT;
       if (msi[I_ACT]) {
         msi[I_LOAD] = 0;
+        msi[I_L1A] = 0;
         msi[I_PAR] = msi[I_PAR] ^ 1;   // L1 has just written the other copy of the iterate's level-1 temperature
         const double rho0 = msc[X_RHO0], cp0 = msc[X_CP0], talpha0 = msc[X_TALPHA0], sbeta0 = msc[X_SBETA0];
         const double rhoh2o = msc[X_RHOH2O], rhob = msc[X_RHOB];
@@ -524,8 +529,13 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     }
   };
 
-  // G: ocnstep control after a pass (ocnstep_mod.F90:122-192), one lane per slot
-  auto G = [&]() {
+  // G: ocnstep control of a pass (ocnstep_mod.F90:122-192), one lane per slot.  Whether a column goes on
+  // iterating depends on this pass's boundary-layer depth only, so the decision is taken as soon as M3 has it
+  // (G_early) - a slot that goes on can then start the next pass's L1 while its V sweep still runs - and what
+  // the sweeps and the rest of this pass still need (zero-pivot flag, this pass's `maybe last` flag) is settled
+  // after them (G_late).
+  const bool l1_ahead = !EXT && p.mode == MCKPP_MODE_STEP && nthreads > 64;
+  auto G_early = [&]() {
     bool f_any = false;
     if (lane < W) {
       int *msi = sirec + lane * I_COUNT;
@@ -533,11 +543,10 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       if (msi[I_ACT]) {
         int fin = F_NONE;
         int status = msi[I_STATUS], npass_try = msi[I_NPASS_TRY], iconv = msi[I_ICONV];
-        if (p.mode != MCKPP_MODE_INIT && msi[I_BAD]) status |= 1;
-        msi[I_BAD] = 0;
         msi[I_NPASS] = msi[I_NPASS] + 1;
         if (p.mode != MCKPP_MODE_STEP) {
           fin = F_FINAL;
+          msi[I_MAYBE_NEXT] = msi[I_MAYBE];
         } else {
           ++npass_try;
           const double hbl = msc[C_HBL];
@@ -563,15 +572,26 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
               msi[I_NVIOL] = 0;
             }
           }
-          msi[I_MAYBE] = (npass_try >= 3 && (iconv >= 2 || npass_try + 1 >= p.itermax)) ? 1 : 0;
+          msi[I_MAYBE_NEXT] = (npass_try >= 3 && (iconv >= 2 || npass_try + 1 >= p.itermax)) ? 1 : 0;
         }
         msi[I_STATUS] = status; msi[I_NPASS_TRY] = npass_try; msi[I_ICONV] = iconv;
         msi[I_FIN] = fin;
+        msi[I_L1A] = (l1_ahead && fin == F_NONE) ? 1 : 0;
         f_any = fin != F_NONE;
       }
     }
     const unsigned long long m = __ballot(f_any);
     if (lane == 0) s_flags[1] = m != 0ull ? 1 : 0;
+  };
+  auto G_late = [&]() {
+    if (lane < W) {
+      int *msi = sirec + lane * I_COUNT;
+      if (msi[I_ACT]) {
+        if (p.mode != MCKPP_MODE_INIT && msi[I_BAD]) msi[I_STATUS] = msi[I_STATUS] | 1;
+        msi[I_BAD] = 0;
+        msi[I_MAYBE] = msi[I_MAYBE_NEXT];
+      }
+    }
   };
 
   // ---- optional terms of the T and S right-hand sides (ocnint_mod.F90:97-215), level k of item (my, si, col):
@@ -650,6 +670,90 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     if (si[I_MAYBE]) { p.ocnTcorr[o] = ocnTcorr; p.sinc_fcorr[o] = sinc; p.scorr[o] = sinc / dto; }
   };
 
+  // ---- L1 of one item: under-relaxation of the iterate against the last solution (ocnstep_mod.F90:123-132 /
+  // :142-151; for a new or retried column the extrapolation of :91-112), equation of state.  `part`: everything;
+  // everything but V (run by the item's own thread while the manager wave sweeps V: nothing here but the
+  // relaxation of V depends on that sweep); V only (what is then left for the L1 phase).
+  enum { L1_FULL = 0, L1_ALL_BUT_V = 1, L1_V_ONLY = 2 };
+  auto L1_item = [&](const int k, const int kr, int *const si, double *const my, double *const sc, const size_t ro,
+                     const bool act, const bool virt1, const bool virt2, const bool is1, const auto xs_,
+                     const bool first_, const int part) {
+    auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };
+    if (part == L1_V_ONLY) {
+      if (act) {
+        double V = first_ ? rV : xs_[LS];
+        V = lambda * V + (1 - lambda) * row(Q_YV)[k];
+        if (first_) rV = V; else xs_[LS] = V;
+        row(Q_YV)[k] = V;
+      }
+      return;
+    }
+    const bool with_v = part == L1_FULL;
+    const int maybe = part == L1_ALL_BUT_V ? si[I_MAYBE_NEXT] : si[I_MAYBE];
+    const int ldf = with_v ? si[I_LOAD] : 0, par = si[I_PAR];
+    const size_t o = ro + (kr - 1);
+    double U = 0, V = 0, T = 0, S = 0;
+    if (p.mode == MCKPP_MODE_STEP) {
+      double yu, yv, yt, ys;
+      if (ldf != 0) {   // the relaxation memory equals the new iterate (Ux = U, ocnstep_mod.F90:105,110)
+        const int old = si[I_OLD], newi = si[I_NEW];
+        const double uo = act ? p.Us[old][o] : 0.0, un = act ? p.Us[newi][o] : 0.0;
+        const double vo = act ? p.Vs[old][o] : 0.0, vn = act ? p.Vs[newi][o] : 0.0;
+        const double to = p.Ts[old][o], tn = p.Ts[newi][o];
+        const double so = act ? p.Ss[old][o] : 0.0, sn = act ? p.Ss[newi][o] : 0.0;
+        U = 2. * un - uo;
+        V = 2. * vn - vo;
+        T = 2. * tn - to;
+        S = 2. * sn - so;
+        yu = U; yv = V; yt = T; ys = S;
+      } else {
+        if (first_) { U = rU; T = rT; S = rS; if (with_v) V = rV; }
+        else if (act) { U = xs_[0]; T = xs_[2 * LS]; S = xs_[3 * LS]; if (with_v) V = xs_[LS]; }
+        if (!act) T = sc[C_T1X + par];   // the two EOS items follow level 1, whose item rewrites it now
+        yu = row(Q_YU)[kr]; yv = with_v ? row(Q_YV)[kr] : 0.0; yt = row(Q_YT)[kr]; ys = row(Q_YS)[kr];
+      }
+      // under-relaxation, ocnstep_mod.F90:123-132 / :142-151 (an EOS item follows level 1's temperature)
+      T = lambda * T + (1 - lambda) * yt;
+      if (act) {
+        U = lambda * U + (1 - lambda) * yu;
+        if (with_v) V = lambda * V + (1 - lambda) * yv;
+        S = lambda * S + (1 - lambda) * ys;
+        if (first_) { rU = U; rT = T; rS = S; if (with_v) rV = V; }
+        else { xs_[0] = U; xs_[2 * LS] = T; xs_[3 * LS] = S; if (with_v) xs_[LS] = V; }
+        if (is1) sc[C_T1X + (par ^ 1)] = T;
+      }
+    } else {
+      U = act ? p.U[o] : 0.0; V = act ? p.V[o] : 0.0; T = p.T[o]; S = act ? p.S[o] : 0.0;
+    }
+    const double Sref = sc[C_SREF];
+    const double zm1 = c_zm[1];
+    const double zmk = c_zm[kr];
+    double Sin = S + Sref, Pin = -zmk;
+    const double Tin = T;
+    if (virt1) { Sin = 0.0; Pin = -zm1; }
+    if (virt2) { Sin = p.sice; Pin = -zm1; }
+    double s0, talpha, sbeta;
+    abk80_dev(Sin, Tin, Pin, talpha, sbeta, s0);
+    const double rho = 1000. + s0;
+    const double cp = cpsw_dev(Sin, Tin, Pin);
+    const double buoy = div_fast(-p.grav * s0, 1000., 1. / 1000.);
+    if (is1) { sc[X_RHO0] = rho; sc[X_CP0] = cp; sc[X_TALPHA0] = talpha; sc[X_SBETA0] = sbeta; }
+    if (virt1) sc[X_RHOH2O] = rho;
+    if (virt2) sc[X_RHOB] = rho;
+    if (act) { row(Q_YU)[k] = U; row(Q_YS)[k] = buoy; if (with_v) row(Q_YV)[k] = V; }
+    if (p.diag && maybe) {   // what the last vmix leaves behind (types_transfer.F90:199-327)
+      const size_t od = ro + k;
+      if (act) { p.rho[od] = rho; p.cp[od] = cp; p.buoy[od] = buoy; p.talpha[od] = talpha; p.sbeta[od] = sbeta; }
+      if (is1) { p.rho[od - 1] = rho; p.cp[od - 1] = cp; p.talpha[od - 1] = talpha; p.sbeta[od - 1] = sbeta; }
+    }
+    if constexpr (EXT) {
+      if (act) { row(Q_RHO)[k] = rho; row(Q_CP)[k] = cp; }
+      if (p.LDD && act) {   // neighbours for alphaDT, betaDS
+        row(Q_DM)[k] = talpha; row(Q_S1)[k] = sbeta; row(Q_S2)[k] = S; row(Q_BET)[k] = T;
+      }
+    }
+  };
+
   // =========================== persistent pass loop ===========================
 #ifdef MCKPP_PS_STAMPS   // profiling build: per-segment cycle sums kept in registers by the manager wave
   unsigned long long tacc[24];
@@ -674,70 +778,11 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     tacc[23] += 1;
 #endif
 
-    // ---- L1: (new column / retry: ocnstep_mod.F90:91-112 extrapolation) under-relaxation, equation of state
+    // ---- L1: (new column / retry: ocnstep_mod.F90:91-112 extrapolation) under-relaxation, equation of state.
+    // Items that had everything but V done while the V sweep ran (L1_ALL_BUT_V below) only relax V now.
     FOR_ITEMS
-      const int ldf = si[I_LOAD], par = si[I_PAR];
-      const size_t o = ro + (kr - 1);
-      double U = 0, V = 0, T = 0, S = 0;
-      if (p.mode == MCKPP_MODE_STEP) {
-        double yu, yv, yt, ys;
-        if (ldf != 0) {   // the relaxation memory equals the new iterate (Ux = U, ocnstep_mod.F90:105,110)
-          const int old = si[I_OLD], newi = si[I_NEW];
-          const double uo = act ? p.Us[old][o] : 0.0, un = act ? p.Us[newi][o] : 0.0;
-          const double vo = act ? p.Vs[old][o] : 0.0, vn = act ? p.Vs[newi][o] : 0.0;
-          const double to = p.Ts[old][o], tn = p.Ts[newi][o];
-          const double so = act ? p.Ss[old][o] : 0.0, sn = act ? p.Ss[newi][o] : 0.0;
-          U = 2. * un - uo;
-          V = 2. * vn - vo;
-          T = 2. * tn - to;
-          S = 2. * sn - so;
-          yu = U; yv = V; yt = T; ys = S;
-        } else {
-          if (first_) { U = rU; V = rV; T = rT; S = rS; }
-          else if (act) { U = xs_[0]; V = xs_[LS]; T = xs_[2 * LS]; S = xs_[3 * LS]; }
-          if (!act) T = sc[C_T1X + par];   // the two EOS items follow level 1, whose item rewrites it now
-          yu = row(Q_YU)[kr]; yv = row(Q_YV)[kr]; yt = row(Q_YT)[kr]; ys = row(Q_YS)[kr];
-        }
-        // under-relaxation, ocnstep_mod.F90:123-132 / :142-151 (an EOS item follows level 1's temperature)
-        T = lambda * T + (1 - lambda) * yt;
-        if (act) {
-          U = lambda * U + (1 - lambda) * yu;
-          V = lambda * V + (1 - lambda) * yv;
-          S = lambda * S + (1 - lambda) * ys;
-          if (first_) { rU = U; rV = V; rT = T; rS = S; }
-          else { xs_[0] = U; xs_[LS] = V; xs_[2 * LS] = T; xs_[3 * LS] = S; }
-          if (is1) sc[C_T1X + (par ^ 1)] = T;
-        }
-      } else {
-        U = act ? p.U[o] : 0.0; V = act ? p.V[o] : 0.0; T = p.T[o]; S = act ? p.S[o] : 0.0;
-      }
-      const double Sref = sc[C_SREF];
-      const double zm1 = c_zm[1];
-      const double zmk = c_zm[kr];
-      double Sin = S + Sref, Pin = -zmk;
-      const double Tin = T;
-      if (virt1) { Sin = 0.0; Pin = -zm1; }
-      if (virt2) { Sin = p.sice; Pin = -zm1; }
-      double s0, talpha, sbeta;
-      abk80_dev(Sin, Tin, Pin, talpha, sbeta, s0);
-      const double rho = 1000. + s0;
-      const double cp = cpsw_dev(Sin, Tin, Pin);
-      const double buoy = div_fast(-p.grav * s0, 1000., 1. / 1000.);
-      if (is1) { sc[X_RHO0] = rho; sc[X_CP0] = cp; sc[X_TALPHA0] = talpha; sc[X_SBETA0] = sbeta; }
-      if (virt1) sc[X_RHOH2O] = rho;
-      if (virt2) sc[X_RHOB] = rho;
-      if (act) { row(Q_YU)[k] = U; row(Q_YV)[k] = V; row(Q_YS)[k] = buoy; }
-      if (p.diag && si[I_MAYBE]) {   // what the last vmix leaves behind (types_transfer.F90:199-327)
-        const size_t od = ro + k;
-        if (act) { p.rho[od] = rho; p.cp[od] = cp; p.buoy[od] = buoy; p.talpha[od] = talpha; p.sbeta[od] = sbeta; }
-        if (is1) { p.rho[od - 1] = rho; p.cp[od - 1] = cp; p.talpha[od - 1] = talpha; p.sbeta[od - 1] = sbeta; }
-      }
-      if constexpr (EXT) {
-        if (act) { row(Q_RHO)[k] = rho; row(Q_CP)[k] = cp; }
-        if (p.LDD && act) {   // neighbours for alphaDT, betaDS
-          row(Q_DM)[k] = talpha; row(Q_S1)[k] = sbeta; row(Q_S2)[k] = S; row(Q_BET)[k] = T;
-        }
-      }
+      const bool ahead = !EXT && si[I_L1A] && wv != mgr;
+      L1_item(k, kr, si, my, sc, ro, act, virt1, virt2, is1, xs_, first_, ahead ? L1_V_ONLY : L1_FULL);
     END_ITEMS
     STAMP(0);
     __syncthreads();
@@ -917,7 +962,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(9);
 
     // ---- M3: hbl, kbl, slot-uniform part of blmix
-    if (wv == mgr) { PRIO_HI(); M3(); PRIO_LO(); }
+    if (wv == mgr) { PRIO_HI(); M3(); G_early(); PRIO_LO(); }
     STAMP(10);
     __syncthreads();
     STAMP(11);
@@ -1067,8 +1112,13 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     if (wv == mgr) {
       PRIO_HI();
       if (do_ocnint) ps_thomas_v(W, slots, SS, ROWS, K_STRIDE, nz, cst + K_T0, sirec + I_ACT, I_COUNT, lane);
-      G();
+      G_late();
       PRIO_LO();
+    } else if (l1_ahead) {   // meanwhile: the next pass's L1, all but V, for the items of slots that go on iterating
+      FOR_ITEMS
+        if (!si[I_L1A]) continue;
+        L1_item(k, kr, si, my, sc, ro, act, virt1, virt2, is1, xs_, first_, L1_ALL_BUT_V);
+      END_ITEMS
     }
     STAMP(20);
     __syncthreads();
@@ -1352,8 +1402,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 struct ps_geom { int nw, w, per_cu; };
 
 // Slots per workgroup / waves / workgroups per CU.  A pass of a workgroup is its manager wave's serial phases
-// (independent of the number of slots: 0.8-1 k cycles per level) plus its level phases (23-26 k cycles per trip
-// of the item loop) plus barrier waits and finish rounds; 128 VGPRs allow 16 waves per CU.  The rate is slots in
+// (independent of the number of slots: 0.8-1 k cycles per level) plus its level phases (25-26 k cycles per trip
+// of the item loop, the waits at their barriers included) plus finish rounds; 128 VGPRs allow 16 waves per CU.  The rate is slots in
 // flight / pass time: take the geometry that maximises it under the LDS each workgroup's slots need, with no
 // more slots than the CU has columns to work on (fewer items, shorter passes).  The constants are
 // fits to the per-phase cycle counts of profiles/r02/stamps.txt (one 16-wave workgroup: nothing overlaps its
@@ -1367,16 +1417,17 @@ ps_geom ps_choose(int L, bool ext, size_t cu_lds_bytes, int cols_per_cu, int *ma
   int most = 1;
   for (int per_cu = 1; per_cu <= 4; per_cu *= 2) {
     const int nw = 16 / per_cu, threads = 64 * nw;
-    const double serial = per_cu == 1 ? 0.82e3 : per_cu == 2 ? 0.90e3 : 0.96e3;
-    const double trip = per_cu == 1 ? 26.e3 : per_cu == 2 ? 23.5e3 : 24.5e3;
-    const double other = per_cu == 1 ? 24.e3 : per_cu == 2 ? 22.e3 : 10.e3;
+    const double serial = per_cu == 1 ? 0.82e3 : per_cu == 2 ? 0.92e3 : 1.03e3;
+    const double trip = per_cu == 1 ? 26.e3 : per_cu == 2 ? 26.e3 : 24.75e3;   // incl. the waits at the phases' barriers
+    const double other = per_cu == 1 ? 24.e3 : per_cu == 2 ? 8.3e3 : 8.6e3;
     for (int w = 1; w <= 21; ++w) {
       if ((size_t)per_cu * granules(w) > cu_lds_bytes) break;
       if (per_cu * w > most) most = per_cu * w;
-      const int trips = (w * L + threads - 1) / threads;
+      const int later = threads > 64 ? threads - 64 : 64;   // the manager wave takes items in the first trip only
+      const int trips = w * L <= threads ? 1 : 1 + (w * L - threads + later - 1) / later;
       const double pass = serial * L + trip * trips + other;
       const int busy = per_cu * w < cols_per_cu ? per_cu * w : cols_per_cu;
-      const double rate = (per_cu == 1 ? 0.93 : 1.0) * busy / pass;   // measured: the fit flatters the lone workgroup by 5-7 %
+      const double rate = (per_cu == 1 ? 0.96 : 1.0) * busy / pass;   // measured: the fit flatters the lone workgroup by ~4 %
       if (rate > best_rate * 1.0001) { best_rate = rate; best = {nw, w, per_cu}; }
     }
   }

@@ -953,7 +953,7 @@ def test_full_size_soak_determinism_and_sample_parity(mk):
     _assert_bitexact(cm.compare(sub, ob, nz, cm.PROFILE_FIELDS + cm.SCALAR_FIELDS + ["hmixd0", "hmixd1"]), "soak sample")
 
 
-@pytest.mark.parametrize("nz,ncol,want", [(60, 20000, 2), (40, 20000, 4), (69, 20000, 2), (100, 20000, 2), (150, 20000, 1),
+@pytest.mark.parametrize("nz,ncol,want", [(60, 20000, 2), (40, 20000, None), (69, 20000, 2), (100, 20000, None), (150, 20000, None),
                                           (60, 3000, None)])
 def test_tuned_residency_is_what_the_device_grants(mk, nz, ncol, want):
     """The cooperative kernel is tuned to a number of resident workgroups per CU (two workgroups of 8 waves at
