@@ -7,13 +7,15 @@
 // serial phases (M0..M5: the manager wave, one lane per slot or per (slot, tridiagonal system)), separated by
 // workgroup barriers.
 //
-// A level lane keeps NOTHING between phases: the iterate (U,V,T,S of the under-relaxation) lives in a small
-// cache-resident scratch block per (workgroup, slot), every other phase-crossing value in one of NINE rows of
-// the slot's LDS block (each row is reused three to five times in a pass, see the table below).  So a
-// workgroup serves as many slots as LDS holds, whatever its number of waves, and the manager wave's serial
-// phases - the latency floor of a pass - cost the same for 15 slots as for 1.  (Round-2 history, measured on
+// A level thread keeps (almost) NOTHING between phases: the iterate (U,V,T,S of the under-relaxation) lives
+// in a small scratch block per (workgroup, slot) in global memory - but for a thread's first item, whose four
+// values stay in registers - and every other phase-crossing value in one of NINE rows of the slot's LDS block
+// (each row is reused three to five times in a pass, see the table below).  So a workgroup serves as many
+// slots as LDS holds, whatever its number of waves, and the manager wave's serial phases - the latency floor of
+// a pass - cost the same for 15 slots as for 1.  While the manager wave runs the last of them (the V sweep)
+// the other waves already run the next pass's L1 (all of it but the relaxation of V) for the slots that go on.  (Round-2 history, measured on
 // 1e5 columns: one wavefront per column with 13 LDS rows 1.9e7 column-steps/s at 60 levels; nzp1+2 lanes per
-// column for the whole step 1.8e7; this kernel 2.2e7 - DESIGN.md section 4.)
+// column for the whole step 1.8e7; this kernel 2.5e7 - DESIGN.md section 1.)
 #include "mckpp_colmath.h"
 
 #include <cstdio>
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     const auto xs_ = scr0 + (size_t)slot * (size_t)(4 * LS) + (kr - 1);   /* iterate U, V, T, S of this item */ \
     const bool first_ = t_ == 0;   /* the thread's first item: its iterate stays in registers */          \
     auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };             \
-    (void)sc; (void)actz; (void)virt1; (void)virt2; (void)is1; (void)isnz; (void)isnzp1; (void)kr; (void)ro; (void)xs_; (void)first_;
+    (void)sc; (void)actz; (void)virt1; (void)virt2; (void)is1; (void)isnz; (void)isnzp1; (void)kr; (void)ro; (void)xs_; (void)first_; (void)row;
 #define END_ITEMS }
 
   // =========================== manager phases (wave 0) ===========================
