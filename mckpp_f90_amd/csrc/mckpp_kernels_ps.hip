@@ -80,7 +80,7 @@ __host__ __device__ inline int ps_scratch_ld(int nzp1) { return (nzp1 + 7) & ~7;
 __host__ __device__ inline size_t ps_lds_bytes(int L, int W, bool ext)
 {
   return (size_t)(K_STRIDE * ps_nl(L) + 2 + W * ps_ss(L, ext) + W * C_COUNT) * sizeof(double) +
-         (size_t)(W * I_COUNT + 4 + 8) * sizeof(int);
+         (size_t)(W * I_COUNT + 4) * sizeof(int);
 }
 
 
@@ -260,24 +260,11 @@ __device__ __forceinline__ void ps_thomas_v(int W, double *slots, int SS, int KS
   }
 }
 
-#ifndef MCKPP_PS_MGR_SIMD
-#define MCKPP_PS_MGR_SIMD -1
-#endif
-
 template <int KS>
 struct strided {   // x[i] of a level-interleaved row
   double *b;
   __device__ __forceinline__ double &operator[](int i) const { return b[i * KS]; }
 };
-
-// the manager wave's serial phases are what the other waves of the workgroup wait for
-#ifndef MCKPP_PS_PRIO   // measured: raising the manager wave's priority costs 3 % (its phases are latency-, not issue-bound)
-#define PRIO_HI()
-#define PRIO_LO()
-#else
-#define PRIO_HI() __builtin_amdgcn_s_setprio(3)
-#define PRIO_LO() __builtin_amdgcn_s_setprio(0)
-#endif
 
 template <bool EXT>
 #ifndef MCKPP_PS_MINW
@@ -314,24 +301,10 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   if (tid == 0) { c_misc[0] = rcp_refine(p.hm[1]); c_misc[1] = rcp_refine(p.vonk); }
   for (int i = tid; i < W * I_COUNT; i += blockDim.x) sirec[i] = 0;   // every slot PS_EMPTY
   if (tid < 4) s_flags[tid] = 0;
-  // The manager is wave 0.  (Experiment kept behind MCKPP_PS_MGR_SIMD >= 0: electing the wave that sits on a
-  // given SIMD, so that the serial chains of all workgroups of a CU share one SIMD - measured 0.8-0.9x; one
-  // SIMD per workgroup chosen from blockIdx - 0.97x.  Raising the manager's s_setprio: 0.97x.)
-  int mgr = 0;
-#if MCKPP_PS_MGR_SIMD >= 0
-  {
-    int *s_simd = s_flags + 4;   // [8] SIMD id per wave
-    const int simd = (__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4) & 3);   // HW_REG_HW_ID bits 5:4
-    if (lane == 0) s_simd[wv] = simd;
-    __syncthreads();
-    const int nwv = blockDim.x >> 6;
-    mgr = -1;
-    for (int w = 0; w < nwv; ++w)
-      if (mgr < 0 && s_simd[w] == MCKPP_PS_MGR_SIMD) mgr = w;
-    if (mgr < 0) mgr = 0;
-    mgr = __builtin_amdgcn_readfirstlane(mgr);
-  }
-#endif
+  // The manager is wave 0 (the item map below gives it items in the first trip only).  Measured and dropped:
+  // electing the wave that sits on a given SIMD, so that the serial chains of all workgroups of a CU share one
+  // SIMD (0.8-0.9x), or one SIMD per workgroup chosen from blockIdx (0.97x); raising its s_setprio (0.97x).
+  const int mgr = 0;
 
   // ---- work items (slot, level) ------------------------------------------------
   // Item `it` of the first trip belongs to thread `it`; the later trips are dealt to the waves other than the
@@ -918,7 +891,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(5);
 
     // ---- M2: Rib(ku) = MAX(Rib(ku), Rib(ka)+epsln), bldepth_mod.F90:137
-    if (wv == mgr) { PRIO_HI(); ps_scan_rib(W, Q_YV, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane); PRIO_LO(); }
+    if (wv == mgr) { ps_scan_rib(W, Q_YV, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane); }
     STAMP(6);
     __syncthreads();
     STAMP(7);
@@ -964,7 +937,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(9);
 
     // ---- M3: hbl, kbl, slot-uniform part of blmix
-    if (wv == mgr) { PRIO_HI(); M3(); G_early(); PRIO_LO(); }
+    if (wv == mgr) { M3(); G_early(); }
     STAMP(10);
     __syncthreads();
     STAMP(11);
@@ -1077,10 +1050,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 
     // ---- M4: Thomas factorise + sweep for U, T, S (solvers.F90:14-44, 112-161)
     if (wv == mgr && do_ocnint) {
-      PRIO_HI();
       ps_thomas_uts(W, slots, SS, ROWS, K_STRIDE, nz, cst + K_T0, cst + K_T1, sirec + I_ACT, I_COUNT, sirec + I_BAD,
                     I_COUNT, lane);
-      PRIO_LO();
     }
     STAMP(16);
     __syncthreads();
@@ -1110,12 +1081,10 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     __syncthreads();
     STAMP(19);
 
-    // ---- M5: Thomas sweep for V on the stored momentum factorisation; ocnstep control
+    // ---- M5: Thomas sweep for V on the stored momentum factorisation | the next pass's L1 but for V
     if (wv == mgr) {
-      PRIO_HI();
       if (do_ocnint) ps_thomas_v(W, slots, SS, ROWS, K_STRIDE, nz, cst + K_T0, sirec + I_ACT, I_COUNT, lane);
       G_late();
-      PRIO_LO();
     } else if (l1_ahead) {   // meanwhile: the next pass's L1, all but V, for the items of slots that go on iterating
       FOR_ITEMS
         if (!si[I_L1A]) continue;
