@@ -311,6 +311,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // manager's only (it has its serial phases to run): item nthreads + t*(nthreads-64) + (tid-64) in trip t+1.
   const int nthreads = blockDim.x, nitems = W * L;
   const int nhelp = nthreads > 64 ? nthreads - 64 : 64, tid2 = nthreads > 64 ? tid - 64 : tid;
+  const int nitems_lm = W * nzp1;
+  const unsigned Wmagic = W > 1 ? 0xFFFFFFFFu / (unsigned)W + 1u : 0u;   // it / W == umulhi(it, Wmagic) for it < 2^16
   __syncthreads();
 
   const double lambda = 0.5;
@@ -343,6 +345,26 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };             \
     (void)sc; (void)actz; (void)virt1; (void)virt2; (void)is1; (void)isnz; (void)isnzp1; (void)kr; (void)ro; (void)xs_; (void)first_; (void)row;
 #define END_ITEMS }
+// The same items in level-major order (item = (level-1)*W + slot, the equation-of-state items left out), for a
+// phase whose cost grows with depth and that talks to the others through LDS only (L2: its reference-level
+// loop runs over the layers above a tenth of the item's depth).  A wave then holds a few levels of every slot
+// - its lanes loop equally long - and a thread's first item comes from the top of the columns, its later ones
+// from the bottom, so every thread gets a deep and a shallow item.
+#define FOR_ITEMS_BY_LEVEL                                                                \
+  for (int j_ = tid, t_ = 0; j_ < nitems_lm; j_ = tid2 >= 0 ? nthreads + t_ * nhelp + tid2 : nitems_lm, ++t_) { \
+    const int it_ = t_ == 0 ? j_ : nitems_lm - 1 - (j_ - nthreads);                       \
+    const int k = (W == 1 ? it_ : (int)__umulhi((unsigned)it_, Wmagic)) + 1;   /* the magic of W = 1 is 2^32 */ \
+    const int slot = it_ - (k - 1) * W;                                                   \
+    int *const si = sirec + slot * I_COUNT;                                               \
+    if (!si[I_ACT]) continue;                                                             \
+    double *const my = slots + slot * SS;                                                 \
+    double *const sc = screc + slot * C_COUNT;                                            \
+    const int col = si[I_COL];                                                            \
+    const bool act = true, actz = k <= nz;                                                \
+    const bool is1 = k == 1, isnz = k == nz, isnzp1 = k == nzp1;                          \
+    const size_t ro = (size_t)col * p.ld;                                                 \
+    auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };             \
+    (void)sc; (void)act; (void)actz; (void)is1; (void)isnz; (void)isnzp1; (void)ro; (void)row;
 
   // =========================== manager phases (wave 0) ===========================
   // M0: slots whose column has finished pull the next one from the queue 
@@ -729,6 +751,78 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     }
   };
 
+  // ---- L2 of one item (level k <= nzp1 of a slot): surface-layer reference averages, Ri pieces
+  // (verticalmixing_mod.F90:111-137)
+  auto L2_item = [&](const int k, int *const si, double *const my, double *const sc, const size_t ro, const bool actz,
+                     const bool is1, const bool isnz, const bool isnzp1) {
+    const bool act = true;
+    auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };
+    const strided<ROWS> aU = row(Q_YU), aV = row(Q_YV), aB = row(Q_YS);
+    const double U = act ? aU[k] : 0.0, V = act ? aV[k] : 0.0, buoy = aB[k];
+    const double zmk = c_zm[k];
+    const double zm1 = c_zm[1];
+    const double U1 = aU[1], V1 = aV[1], Bu1 = aB[1];
+    const double zref = eps01 * zmk, rzref = rcp_refine(zref);
+    double wz = dmax2(zm1, zref);
+    double ur = div_fast_guarded(U1 * wz, zref, rzref), vr = div_fast_guarded(V1 * wz, zref, rzref),
+           br = div_fast(Bu1 * wz, zref, rzref);
+    // The layers above zref (verticalmixing_mod.F90:118-131: wz = MIN(dz, zm(kl)-zref), del = 0.5 wz/dz).  Every
+    // layer but the one zref lies in is taken whole - wz = dz, del = 0.5 exactly - and needs neither the minimum
+    // nor the division; the one partial layer is the last of its lane and is done after the loop.
+    bool live = actz;
+    int klp = 0;
+    double zk = zm1, Uk = U1, Vk = V1, Bk = Bu1;
+    for (int kl = 1; kl <= nz; ++kl) {
+      live = live && !(zref >= zk);
+      if (!__any(live)) break;
+      const double zk1 = c_zm[kl + 1], Uk1 = aU[kl + 1], Vk1 = aV[kl + 1], Bk1 = aB[kl + 1];
+      if (live) {
+        const double dzk = zk - zk1;
+        if (dzk > zk - zref) {   // the minimum is zm(kl)-zref < dz: partial layer (then zref > zm(kl+1): the last)
+          klp = kl;
+          live = false;
+        } else {
+          ur = ur - div_fast_guarded(dzk * (Uk + 0.5 * (Uk1 - Uk)), zref, rzref);
+          vr = vr - div_fast_guarded(dzk * (Vk + 0.5 * (Vk1 - Vk)), zref, rzref);
+          br = br - div_fast(dzk * (Bk + 0.5 * (Bk1 - Bk)), zref, rzref);
+        }
+      }
+      zk = zk1; Uk = Uk1; Vk = Vk1; Bk = Bk1;
+    }
+    if (klp) {
+      const double zl = c_zm[klp], zl1 = c_zm[klp + 1];
+      const double Ul = aU[klp], Ul1 = aU[klp + 1], Vl = aV[klp], Vl1 = aV[klp + 1], Bl = aB[klp], Bl1 = aB[klp + 1];
+      const double dzk = zl - zl1, wz2 = zl - zref;
+      const double del = div_fast(0.5 * wz2, dzk, c_rdz[klp]);
+      ur = ur - div_fast_guarded(wz2 * (Ul + del * (Ul1 - Ul)), zref, rzref);
+      vr = vr - div_fast_guarded(wz2 * (Vl + del * (Vl1 - Vl)), zref, rzref);
+      br = br - div_fast(wz2 * (Bl + del * (Bl1 - Bl)), zref, rzref);
+    }
+    if constexpr (EXT) {
+      if (p.LDD && act) {   // verticalmixing_mod.F90:103-108
+        const double talpha = row(Q_DM)[k], sbeta = row(Q_S1)[k], T = row(Q_BET)[k], S = row(Q_S2)[k];
+        row(Q_X1)[k] = 0.5 * (talpha + row(Q_DM)[k + 1]) * (T - row(Q_BET)[k + 1]);
+        row(Q_X2)[k] = 0.5 * (sbeta + row(Q_S1)[k + 1]) * (S - row(Q_S2)[k + 1]);
+      }
+    }
+    const double bk1 = aB[k + 1], uk1 = aU[k + 1], vk1 = aV[k + 1];
+    const double Ritop = (zref - zmk) * (br - buoy);
+    const double dbloc = buoy - bk1;
+    const double dVsq = (ur - U) * (ur - U) + (vr - V) * (vr - V);
+    const double shsq = (U - uk1) * (U - uk1) + (V - vk1) * (V - vk1);
+    if (p.mode != MCKPP_MODE_STEP && isnz) { sc[C_UREFNZ] = ur; sc[C_VREFNZ] = vr; }
+    const double zdiff = zmk - c_zm[k + 1];
+    const double shs = shsq + 1.e-16;
+    const double Rig = div_fast(dbloc * zdiff, shs, rcp_refine(shs));
+    if (actz) { row(Q_GM)[k] = Rig; row(Q_YT)[k] = dbloc; row(Q_DT)[k] = Ritop; row(Q_DS)[k] = dVsq; }
+    if (is1) row(Q_GM)[0] = 0.0;
+    if (isnzp1) row(Q_GM)[k] = 0.0;
+    if (p.diag && si[I_MAYBE]) {
+      const size_t od = ro + k;
+      if (actz) { p.Rig[od] = Rig; p.dbloc[od] = dbloc; p.Shsq[od] = shsq; }
+    }
+  };
+
   // =========================== persistent pass loop ===========================
 #ifdef MCKPP_PS_STAMPS   // profiling build: per-segment cycle sums kept in registers by the manager wave
   unsigned long long tacc[24];
@@ -765,57 +859,16 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 
     // ---- M1 | L2: surface fluxes (wave 0) | reference-level loop, Ri pieces (verticalmixing_mod.F90:111-137)
     if (wv == mgr) M1();
-    FOR_ITEMS
-      if (!act) continue;   // the two equation-of-state items exist for L1 only
-      const strided<ROWS> aU = row(Q_YU), aV = row(Q_YV), aB = row(Q_YS);
-      const double U = act ? aU[k] : 0.0, V = act ? aV[k] : 0.0, buoy = aB[k];
-      const double zmk = c_zm[k];
-      const double zm1 = c_zm[1];
-      const double U1 = aU[1], V1 = aV[1], Bu1 = aB[1];
-      const double zref = eps01 * zmk, rzref = rcp_refine(zref);
-      double wz = dmax2(zm1, zref);
-      double ur = div_fast_guarded(U1 * wz, zref, rzref), vr = div_fast_guarded(V1 * wz, zref, rzref),
-             br = div_fast(Bu1 * wz, zref, rzref);
-      bool live = actz;
-      double zk = zm1, Uk = U1, Vk = V1, Bk = Bu1;
-      for (int kl = 1; kl <= nz; ++kl) {
-        live = live && !(zref >= zk);
-        if (!__any(live)) break;
-        const double zk1 = c_zm[kl + 1], Uk1 = aU[kl + 1], Vk1 = aV[kl + 1], Bk1 = aB[kl + 1];
-        if (live) {
-          const double dzk = zk - zk1, rdzk = c_rdz[kl];
-          double wz2 = dmin2(zk - zk1, zk - zref);
-          double del = div_fast(0.5 * wz2, dzk, rdzk);
-          ur = ur - div_fast_guarded(wz2 * (Uk + del * (Uk1 - Uk)), zref, rzref);
-          vr = vr - div_fast_guarded(wz2 * (Vk + del * (Vk1 - Vk)), zref, rzref);
-          br = br - div_fast(wz2 * (Bk + del * (Bk1 - Bk)), zref, rzref);
-        }
-        zk = zk1; Uk = Uk1; Vk = Vk1; Bk = Bk1;
-      }
-      if constexpr (EXT) {
-        if (p.LDD && act) {   // verticalmixing_mod.F90:103-108
-          const double talpha = row(Q_DM)[k], sbeta = row(Q_S1)[k], T = row(Q_BET)[k], S = row(Q_S2)[k];
-          row(Q_X1)[k] = 0.5 * (talpha + row(Q_DM)[k + 1]) * (T - row(Q_BET)[k + 1]);
-          row(Q_X2)[k] = 0.5 * (sbeta + row(Q_S1)[k + 1]) * (S - row(Q_S2)[k + 1]);
-        }
-      }
-      const double bk1 = aB[k + 1], uk1 = aU[k + 1], vk1 = aV[k + 1];
-      const double Ritop = (zref - zmk) * (br - buoy);
-      const double dbloc = buoy - bk1;
-      const double dVsq = (ur - U) * (ur - U) + (vr - V) * (vr - V);
-      const double shsq = (U - uk1) * (U - uk1) + (V - vk1) * (V - vk1);
-      if (p.mode != MCKPP_MODE_STEP && isnz) { sc[C_UREFNZ] = ur; sc[C_VREFNZ] = vr; }
-      const double zdiff = zmk - c_zm[k + 1];
-      const double shs = shsq + 1.e-16;
-      const double Rig = div_fast(dbloc * zdiff, shs, rcp_refine(shs));
-      if (actz) { row(Q_GM)[k] = Rig; row(Q_YT)[k] = dbloc; row(Q_DT)[k] = Ritop; row(Q_DS)[k] = dVsq; }
-      if (is1) row(Q_GM)[0] = 0.0;
-      if (isnzp1) row(Q_GM)[k] = 0.0;
-      if (p.diag && si[I_MAYBE]) {
-        const size_t od = ro + k;
-        if (actz) { p.Rig[od] = Rig; p.dbloc[od] = dbloc; p.Shsq[od] = shsq; }
-      }
-    END_ITEMS
+    if (nzp1 >= 50) {   // measured: the level-major order pays from ~50 levels on (+2 % at 60, +13 % on the stretched 69-level grid; -2 % at 40)
+      FOR_ITEMS_BY_LEVEL
+        L2_item(k, si, my, sc, ro, actz, is1, isnz, isnzp1);
+      END_ITEMS
+    } else {
+      FOR_ITEMS
+        if (!act) continue;   // the two equation-of-state items exist for L1 only
+        L2_item(k, si, my, sc, ro, actz, is1, isnz, isnzp1);
+      END_ITEMS
+    }
     STAMP(2);
     __syncthreads();
     STAMP(3);
