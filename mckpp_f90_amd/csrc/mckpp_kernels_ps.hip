@@ -1451,7 +1451,7 @@ ps_geom ps_choose(int L, bool ext, size_t cu_lds_bytes, int cols_per_cu, int *ma
       const int trips = w * L <= threads ? 1 : 1 + (w * L - threads + later - 1) / later;
       const double pass = serial * L + trip * trips + other;
       const int busy = per_cu * w < cols_per_cu ? per_cu * w : cols_per_cu;
-      const double rate = (per_cu == 1 ? 0.96 : 1.0) * busy / pass;   // measured: the fit flatters the lone workgroup by ~4 %
+      const double rate = busy / pass;
       if (rate > best_rate * 1.0001) { best_rate = rate; best = {nw, w, per_cu}; }
     }
   }
