@@ -165,6 +165,20 @@ __device__ __forceinline__ void abk80_dev(double S, double T1, double P, double 
   Alpha = div_fast(-Alpha, Rho, r_Rho);
 }
 
+// Sig0 alone: the part of Sig80 (:371-398) that abk80_dev's Sig0 comes from, same operations.  Everything
+// else in abk80_dev serves Alpha and Beta.
+__device__ __forceinline__ double sig0_dev(double S, double T1)
+{
+  double T = T1;
+  if (T < -2.) T = -2.;
+  double SR = __builtin_sqrt(__builtin_fabs(S));
+  double R1 = ((((6.536332E-9 * T - 1.120083E-6) * T + 1.001685E-4) * T - 9.095290E-3) * T + 6.793952E-2) * T - .157406;
+  double R2 = (((5.3875E-9 * T - 8.2467E-7) * T + 7.6438E-5) * T - 4.0899E-3) * T + 8.24493E-1;
+  double R3 = (-1.6546E-6 * T + 1.0227E-4) * T - 5.72466E-3;
+  double R4 = 4.8314E-4;
+  return (R4 * S + R3 * SR + R2) * S + R1;
+}
+
 // Turbulent velocity scales, src/mckpp_physics_verticalmixing_wscale_mod.F90:12-97.
 // ustar is constant over a vmix pass, so its table row / fraction are hoisted.
 struct wscale_u {

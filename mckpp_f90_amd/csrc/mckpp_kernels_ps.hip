@@ -32,7 +32,7 @@ enum { F_NONE = 0, F_TRAP = 1, F_FINAL = 2 };
 // per-slot double record
 enum {
   C_B0 = 0, C_B0SOL, C_USTAR, C_UFRAC, C_UCUBE, C_HEK, C_WU01, C_WU02, C_WX01, C_WX02, C_WXNT0, C_UREFNZ, C_VREFNZ,
-  C_RHO0CP0, C_RRC, X_RHO0, X_CP0, X_TALPHA0, X_SBETA0, X_RHOH2O, X_RHOB,
+  C_RHO0CP0, C_RRC, X_T1 /* level-1 T and S the last L1 worked on */, X_S1, X_RHOH2O, X_RHOB,
   C_F, C_HMIXE, C_HMIXN, C_HBL, C_RHBL, C_STABLE, C_BFSFC, C_CASEA,
   C_GAT1, C_DAT1 = C_GAT1 + 3, C_DKM1 = C_DAT1 + 3,
   C_SREF = C_DKM1 + 3, C_SSURF, C_OCDEPTH, C_SFLUX1, C_SFLUX2, C_SFLUX3, C_SFLUX4, C_SFLUX5, C_SFLUX6,
@@ -418,7 +418,11 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         msi[I_LOAD] = 0;
         msi[I_L1A] = 0;
         msi[I_PAR] = msi[I_PAR] ^ 1;   // L1 has just written the other copy of the iterate's level-1 temperature
-        const double rho0 = msc[X_RHO0], cp0 = msc[X_CP0], talpha0 = msc[X_TALPHA0], sbeta0 = msc[X_SBETA0];
+        // Level 1's density, specific heat and expansion coefficients: evaluated here, under L2, from the T and S
+        // its L1 item worked on (that item itself needs sigma-0 only on passes that cannot be the last)
+        double talpha0, sbeta0, s0_1;
+        abk80_dev(msc[X_S1], msc[X_T1], -c_zm[1], talpha0, sbeta0, s0_1);
+        const double rho0 = 1000. + s0_1, cp0 = cpsw_dev(msc[X_S1], msc[X_T1], -c_zm[1]);
         const double rhoh2o = msc[X_RHOH2O], rhob = msc[X_RHOB];
         const double sflux1 = msc[C_SFLUX1], sflux2 = msc[C_SFLUX2], sflux3 = msc[C_SFLUX3], sflux4 = msc[C_SFLUX4],
                      sflux5 = msc[C_SFLUX5], sflux6 = msc[C_SFLUX6];
@@ -729,12 +733,20 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     const double Tin = T;
     if (virt1) { Sin = 0.0; Pin = -zm1; }
     if (virt2) { Sin = p.sice; Pin = -zm1; }
-    double s0, talpha, sbeta;
-    abk80_dev(Sin, Tin, Pin, talpha, sbeta, s0);
+    // Only sigma-0 (density, buoyancy) feeds the pass; alpha, beta and cp of the levels are diagnostics of the
+    // last vmix (and inputs of the optional physics), level 1's are formed in M1: passes that cannot be the
+    // last evaluate a tenth of the equation of state.
+    const bool full_eos = EXT || (p.diag && maybe);
+    double s0, talpha = 0.0, sbeta = 0.0, cp = 0.0;
+    if (full_eos) {
+      abk80_dev(Sin, Tin, Pin, talpha, sbeta, s0);
+      cp = cpsw_dev(Sin, Tin, Pin);
+    } else {
+      s0 = sig0_dev(Sin, Tin);
+    }
     const double rho = 1000. + s0;
-    const double cp = cpsw_dev(Sin, Tin, Pin);
     const double buoy = div_fast(-p.grav * s0, 1000., 1. / 1000.);
-    if (is1) { sc[X_RHO0] = rho; sc[X_CP0] = cp; sc[X_TALPHA0] = talpha; sc[X_SBETA0] = sbeta; }
+    if (is1) { sc[X_T1] = Tin; sc[X_S1] = Sin; }
     if (virt1) sc[X_RHOH2O] = rho;
     if (virt2) sc[X_RHOB] = rho;
     if (act) { row(Q_YU)[k] = U; row(Q_YS)[k] = buoy; if (with_v) row(Q_YV)[k] = V; }
