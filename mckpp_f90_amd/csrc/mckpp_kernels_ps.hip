@@ -13,9 +13,9 @@
 // (each row is reused three to five times in a pass, see the table below).  So a workgroup serves as many
 // slots as LDS holds, whatever its number of waves, and the manager wave's serial phases - the latency floor of
 // a pass - cost the same for 15 slots as for 1.  While the manager wave runs the last of them (the V sweep)
-// the other waves already run the next pass's L1 (all of it but the relaxation of V) for the slots that go on.  (Round-2 history, measured on
-// 1e5 columns: one wavefront per column with 13 LDS rows 1.9e7 column-steps/s at 60 levels; nzp1+2 lanes per
-// column for the whole step 1.8e7; this kernel 2.5e7 - DESIGN.md section 1.)
+// the other waves already run the next pass's L1 (all of it but the relaxation of V) for the slots that go on.
+// (Round-2 history, measured on 1e5 columns x 60 levels: one wavefront per column with 13 LDS rows 1.9e7
+// column-steps/s; nzp1+2 lanes per column for the whole step 1.8e7; this kernel 2.7e7 - DESIGN.md section 1.)
 #include "mckpp_colmath.h"
 
 #include <cstdio>
@@ -42,7 +42,8 @@ enum {
 enum {
   I_STATE = 0, I_ACT, I_COL, I_OLD, I_NEW, I_JER, I_INITFLAG, I_STATUS, I_NPASS, I_NPASS_TRY, I_ICONV, I_COMP, I_KMIXN,
   I_KBL, I_NRESET, I_FIN, I_MAYBE, I_LOAD /* 1: new column, 2: restart the iteration (trap retry) */, I_JU,
-  I_KBLC, I_NVIOL, I_NOVER, I_NU, I_NV, I_NF, I_BAD, I_L1A /* L1 but for V done ahead, during the V sweep */, I_MAYBE_NEXT, I_LOCEAN, I_PAR /* which C_T1X holds the iterate's level-1 temperature */, I_COUNT
+  I_KBLC, I_NVIOL, I_NOVER, I_NU, I_NV, I_NF, I_BAD, I_L1A /* L1 but for V done ahead, during the V sweep */,
+  I_MAYBE_NEXT, I_LOCEAN, I_PAR /* which C_T1X holds the iterate's level-1 temperature */, I_COUNT
 };
 // LDS rows of a slot and what each holds between which phases of a pass:
 //   Q_DM   (LDD talpha L1..L2)  difm: interior L3, final L5 .. M5 (V sweep, U system's diffusivity)
@@ -112,9 +113,10 @@ __device__ __forceinline__ void ps_scan_rib(int W, int row, double *slots, int S
 }
 
 // tridcof + tridmat (solvers.F90:14-44, 112-161) for U, T, S, skewed by one level: iteration i forms
-// gam(i) = cl(i-1)/bet(i-1) and y(i-1) = num(i-1)/bet(i-1) over the same denominator.  lane = (slot, system).  The T and S systems store their
-// gam over the diffusivity row they have just consumed (level i's diffusivity is in a register before gam(i)
-// is written); the momentum system keeps difm, gam and its pivots for the V sweep.
+// gam(i) = cl(i-1)/bet(i-1) and y(i-1) = num(i-1)/bet(i-1) over the same denominator.  lane = (slot, system).
+// The T and S systems store their gam over the diffusivity row they have just consumed (level i's diffusivity
+// is in a register before gam(i) is written); the momentum system keeps difm, gam and its pivots for the V
+// sweep.
 __device__ __forceinline__ void ps_thomas_uts(int W, double *slots, int SS, int KS, int CS, int nz, const double *c_t0,
                                               const double *c_t1, const int *sact, int sact_stride, int *sbad,
                                               int sbad_stride, int lane)
@@ -871,7 +873,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 
     // ---- M1 | L2: surface fluxes (wave 0) | reference-level loop, Ri pieces (verticalmixing_mod.F90:111-137)
     if (wv == mgr) M1();
-    if (nzp1 >= 50) {   // measured: the level-major order pays from ~50 levels on (+2 % at 60, +13 % on the stretched 69-level grid; -2 % at 40)
+    // measured: the level-major order pays from ~50 levels on (+2 % at 60, +13 % on the stretched 69-level grid,
+    // -2 % at 40)
+    if (nzp1 >= 50) {
       FOR_ITEMS_BY_LEVEL
         L2_item(k, si, my, sc, ro, actz, is1, isnz, isnzp1);
       END_ITEMS
@@ -1439,11 +1443,11 @@ struct ps_geom { int nw, w, per_cu; };
 
 // Slots per workgroup / waves / workgroups per CU.  A pass of a workgroup is its manager wave's serial phases
 // (independent of the number of slots: 0.8-1 k cycles per level) plus its level phases (25-26 k cycles per trip
-// of the item loop, the waits at their barriers included) plus finish rounds; 128 VGPRs allow 16 waves per CU.  The rate is slots in
-// flight / pass time: take the geometry that maximises it under the LDS each workgroup's slots need, with no
-// more slots than the CU has columns to work on (fewer items, shorter passes).  The constants are
-// fits to the per-phase cycle counts of profiles/r02/stamps.txt (one 16-wave workgroup: nothing overlaps its
-// barriers; four 4-wave workgroups: four manager waves share the CU with few level waves).
+// of the item loop, the waits at their barriers included) plus finish rounds; 128 VGPRs allow 16 waves per CU.
+// The rate is slots in flight / pass time: take the geometry that maximises it under the LDS each workgroup's
+// slots need, with no more slots than the CU has columns to work on (fewer items, shorter passes).  The
+// constants are fits to the per-phase cycle counts of profiles/r02/stamps.txt (one 16-wave workgroup: nothing
+// overlaps its barriers; four 4-wave workgroups: four manager waves share the CU with few level waves).
 // <= 21 slots: three manager lanes per slot.
 ps_geom ps_choose(int L, bool ext, size_t cu_lds_bytes, int cols_per_cu, int *max_slots_per_cu)
 {
