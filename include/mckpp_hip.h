@@ -282,9 +282,10 @@ int mckpp_hip_last_kernel_ms(mckpp_hip_handle h, double *ms, int32_t *nlaunch);
  * ("k_column_ps", "k_column_ps<EXT>"); static storage, never NULL. */
 const char *mckpp_hip_kernel_name(mckpp_hip_handle h);
 
-/* Residency of the most recent cooperative column-kernel launch of the process: workgroups per
- * CU the launch asked for, how many the runtime says fit (registers, LDS), threads and dynamic
- * LDS bytes per workgroup.  The kernels are tuned for blocks_per_cu == max_blocks_per_cu. */
+/* Residency of this context's most recent column-kernel launch: workgroups per CU the launcher asked
+ * for (its geometry is chosen per launch from the column depth and count), how many the runtime says fit
+ * (registers, LDS), threads and dynamic LDS bytes per workgroup.  The launcher's choice assumes
+ * max_blocks_per_cu >= blocks_per_cu. */
 int mckpp_hip_kernel_residency(mckpp_hip_handle h, int32_t *blocks_per_cu, int32_t *max_blocks_per_cu,
                                int32_t *threads_per_block, int64_t *lds_bytes_per_block);
 
