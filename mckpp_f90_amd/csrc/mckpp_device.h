@@ -91,7 +91,7 @@ struct mckpp_launch_info { int nblocks, threads, max_blocks_per_cu; size_t lds_b
 // ntime is passed by value)
 hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu,
                                          hipStream_t stream, mckpp_launch_info *info);
-size_t mckpp_ps_scratch_doubles(int nzp1, int ext, int num_cu);   // what p.scratch must hold for that launch
+size_t mckpp_ps_scratch_doubles(int nzp1, int variant, int num_cu);   // what p.scratch must hold (variant: 0 default physics, 1 optional, 2 optional with double diffusion)
 hipError_t mckpp_launch_eos_batch(int64_t n, const double *s, const double *t, const double *p,
                                   double *alpha, double *beta, double *sig0, double *cp,
                                   hipStream_t stream);

@@ -57,30 +57,32 @@ enum {
 //   Q_GM   Rig L2..L3; gam of the momentum system M4..M5
 //   Q_BET  (LDD T L1..L2) pivots of the momentum system M4..M5
 // In the instability trap Q_DM, Q_DT, Q_DS, Q_GM carry the four rmsd terms, in the isotherm check Q_DM, Q_DT.
-// Optional-physics build: rho, cp (L1..L6), alphaDT, betaDS (L2..L3), LDD sbeta and S (L1..L2).
+// Optional-physics builds: rho, cp (L1..L6); with double diffusion also alphaDT, betaDS (L2..L3), LDD sbeta and
+// S (L1..L2).  Three kernel variants XV: 0 default physics (9 rows), 1 optional physics (11), 2 optional physics
+// with double diffusion (15).
 enum { Q_DM = 0, Q_DT, Q_DS, Q_YU, Q_YT, Q_YS, Q_YV, Q_GM, Q_BET, Q_COUNT,
-       Q_RHO = Q_COUNT, Q_CP, Q_X1, Q_X2, Q_S1, Q_S2, Q_COUNT_EXT };
+       Q_RHO = Q_COUNT, Q_CP, Q_COUNT_EXT, Q_X1 = Q_COUNT_EXT, Q_X2, Q_S1, Q_S2, Q_COUNT_EXT_DD };
 // LDS layout.  A slot's rows are interleaved per level: element (row a, level i) sits at i*ROWS + a
 // doubles, so a level lane reaches all its rows and the rows of its neighbours through ONE base register
 // plus immediate offsets (the column depth, hence any row-major row length, is a run-time value).  ROWS is
-// odd (9 / 15): 32 consecutive levels fall on 32 distinct banks.  The grid constants are interleaved the
+// odd (9 / 11 / 15): 32 consecutive levels fall on 32 distinct banks.  The grid constants are interleaved the
 // same way with a stride of 7.  Host and device agree on the sizes through these:
 enum { K_ZM = 0, K_HM, K_T0, K_T1, K_RDZ, K_DTOHK, K_STRIDE = 7 };
-__host__ __device__ inline int ps_rows(bool ext) { return ext ? (int)Q_COUNT_EXT : (int)Q_COUNT; }
+__host__ __device__ inline int ps_rows(int xv) { return xv == 2 ? (int)Q_COUNT_EXT_DD : xv == 1 ? (int)Q_COUNT_EXT : (int)Q_COUNT; }
 __host__ __device__ inline int ps_nl(int L) { return L; }   // level indices 0..nzp1+1 (L = nzp1+2 items per column)
-__host__ __device__ inline int ps_ss(int L, bool ext)
+__host__ __device__ inline int ps_ss(int L, int xv)
 {
   // lane (slot s, system m) of the serial sweeps touches s*SS + i*ROWS + m: an odd SS that is not +-1 (mod 32
   // doubles) spreads the 3W lanes over the banks about evenly (LDS is the scarce resource here: no more padding)
-  int s = ps_rows(ext) * ps_nl(L);
+  int s = ps_rows(xv) * ps_nl(L);
   if (!(s & 1)) ++s;
   while ((s & 31) == 1 || (s & 31) == 31) s += 2;
   return s;
 }
 __host__ __device__ inline int ps_scratch_ld(int nzp1) { return (nzp1 + 7) & ~7; }   // row length of the iterate's scratch
-__host__ __device__ inline size_t ps_lds_bytes(int L, int W, bool ext)
+__host__ __device__ inline size_t ps_lds_bytes(int L, int W, int xv)
 {
-  return (size_t)(K_STRIDE * ps_nl(L) + 2 + W * ps_ss(L, ext) + W * C_COUNT) * sizeof(double) +
+  return (size_t)(K_STRIDE * ps_nl(L) + 2 + W * ps_ss(L, xv) + W * C_COUNT) * sizeof(double) +
          (size_t)(W * I_COUNT + 4) * sizeof(int);
 }
 
@@ -268,7 +270,7 @@ struct strided {   // x[i] of a level-interleaved row
   __device__ __forceinline__ double &operator[](int i) const { return b[i * KS]; }
 };
 
-template <bool EXT>
+template <int XV>
 #ifndef MCKPP_PS_MINW
 #define MCKPP_PS_MINW 4
 #endif
@@ -278,8 +280,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // through the block typed with global pointers (mckpp_device.h): global_load / global_store, SGPR bases
   const mckpp_kparams_dev &p = *reinterpret_cast<const mckpp_kparams_dev *>(pp);
   extern __shared__ double lds[];
-  constexpr int ROWS = EXT ? (int)Q_COUNT_EXT : (int)Q_COUNT;
-  const int NL = ps_nl(L), SS = ps_ss(L, EXT);
+  constexpr bool EXT = XV != 0, DD = XV == 2;
+  constexpr int ROWS = XV == 2 ? (int)Q_COUNT_EXT_DD : XV == 1 ? (int)Q_COUNT_EXT : (int)Q_COUNT;
+  const int NL = ps_nl(L), SS = ps_ss(L, XV);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nz = p.nz, nzp1 = p.nzp1;
@@ -537,7 +540,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // (G_early) - a slot that goes on can then start the next pass's L1 while its V sweep still runs - and what
   // the sweeps and the rest of this pass still need (zero-pivot flag, this pass's `maybe last` flag) is settled
   // after them (G_late).
-  const bool l1_ahead = !EXT && p.mode == MCKPP_MODE_STEP && nthreads > 64;
+  // (not with double diffusion: its L1 stages neighbour values in rows the V sweep is reading)
+  const bool l1_ahead = p.mode == MCKPP_MODE_STEP && nthreads > 64 && !(EXT && p.LDD);
   auto G_early = [&]() {
     bool f_any = false;
     if (lane < W) {
@@ -738,7 +742,10 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     // Only sigma-0 (density, buoyancy) feeds the pass; alpha, beta and cp of the levels are diagnostics of the
     // last vmix (and inputs of the optional physics), level 1's are formed in M1: passes that cannot be the
     // last evaluate a tenth of the equation of state.
-    const bool full_eos = EXT || (p.diag && maybe);
+    // (Optional physics: rho cp enters the right-hand sides under three switches, double diffusion needs alpha
+    // and beta, and the correction diagnostics of a pass that may be the last need rho cp too.)
+    const bool full_eos = (maybe && (p.diag || EXT)) ||
+                          (EXT && (p.LDD || p.L_RELAX_SST || p.L_FCORR || p.L_FCORR_WITHZ));
     double s0, talpha = 0.0, sbeta = 0.0, cp = 0.0;
     if (full_eos) {
       abk80_dev(Sin, Tin, Pin, talpha, sbeta, s0);
@@ -759,7 +766,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     }
     if constexpr (EXT) {
       if (act) { row(Q_RHO)[k] = rho; row(Q_CP)[k] = cp; }
-      if (p.LDD && act) {   // neighbours for alphaDT, betaDS
+      if (DD && p.LDD && act) {   // neighbours for alphaDT, betaDS
         row(Q_DM)[k] = talpha; row(Q_S1)[k] = sbeta; row(Q_S2)[k] = S; row(Q_BET)[k] = T;
       }
     }
@@ -813,7 +820,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       br = br - div_fast(wz2 * (Bl + del * (Bl1 - Bl)), zref, rzref);
     }
     if constexpr (EXT) {
-      if (p.LDD && act) {   // verticalmixing_mod.F90:103-108
+      if (DD && p.LDD && act) {   // verticalmixing_mod.F90:103-108
         const double talpha = row(Q_DM)[k], sbeta = row(Q_S1)[k], T = row(Q_BET)[k], S = row(Q_S2)[k];
         row(Q_X1)[k] = 0.5 * (talpha + row(Q_DM)[k + 1]) * (T - row(Q_BET)[k + 1]);
         row(Q_X2)[k] = 0.5 * (sbeta + row(Q_S1)[k + 1]) * (S - row(Q_S2)[k + 1]);
@@ -864,7 +871,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     // ---- L1: (new column / retry: ocnstep_mod.F90:91-112 extrapolation) under-relaxation, equation of state.
     // Items that had everything but V done while the V sweep ran (L1_ALL_BUT_V below) only relax V now.
     FOR_ITEMS
-      const bool ahead = !EXT && si[I_L1A] && wv != mgr;
+      const bool ahead = l1_ahead && si[I_L1A] && wv != mgr;
       L1_item(k, kr, si, my, sc, ro, act, virt1, virt2, is1, xs_, first_, ahead ? L1_V_ONLY : L1_FULL);
     END_ITEMS
     STAMP(0);
@@ -911,7 +918,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       double ds_i = (0.00001 + fri * 0.005);
       double dt_i = ds_i;   // dift = difs, rimix_mod.F90:95-97
       if constexpr (EXT) {
-        if (p.LDD) {   // ddmix_mod.F90:12-52
+        if (DD && p.LDD) {   // ddmix_mod.F90:12-52
           const double Rrho0 = 1.9, dsfmax = 1.0e-4;
           const double aDT = row(Q_X1)[k], bDS = row(Q_X2)[k];
           if ((aDT > bDS) && (bDS > 0.)) {
@@ -1309,7 +1316,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       if (act) { U = row(Q_YU)[k]; V = row(Q_YV)[k]; T = row(Q_YT)[k]; S = row(Q_YS)[k]; }
       if (act) { p.Us[newi][o] = U; p.Vs[newi][o] = V; p.Ts[newi][o] = T; p.Ss[newi][o] = S; }
       if (si[I_COMP] && act) {   // overrides.F90:57-78
-        if (EXT && p.clim_present) { T = p.ocnT_clim[o]; S = p.sal_clim[o]; row(Q_YT)[k] = T; row(Q_YS)[k] = S; }
+        if (p.clim_present) { T = p.ocnT_clim[o]; S = p.sal_clim[o]; row(Q_YT)[k] = T; row(Q_YS)[k] = S; }
         U = p.U_init[o]; V = p.V_init[o];
         row(Q_YU)[k] = U; row(Q_YV)[k] = V;
       }
@@ -1449,9 +1456,9 @@ struct ps_geom { int nw, w, per_cu; };
 // constants are fits to the per-phase cycle counts of profiles/r02/stamps.txt (one 16-wave workgroup: nothing
 // overlaps its barriers; four 4-wave workgroups: four manager waves share the CU with few level waves).
 // <= 21 slots: three manager lanes per slot.
-ps_geom ps_choose(int L, bool ext, size_t cu_lds_bytes, int cols_per_cu, int *max_slots_per_cu)
+ps_geom ps_choose(int L, int xv, size_t cu_lds_bytes, int cols_per_cu, int *max_slots_per_cu)
 {
-  auto granules = [&](int w_) { return (ps_lds_bytes(L, w_, ext) + 1279) / 1280 * 1280; };
+  auto granules = [&](int w_) { return (ps_lds_bytes(L, w_, xv) + 1279) / 1280 * 1280; };
   ps_geom best = {1, 1, 1};
   double best_rate = 0.0;
   int most = 1;
@@ -1478,9 +1485,9 @@ ps_geom ps_choose(int L, bool ext, size_t cu_lds_bytes, int cols_per_cu, int *ma
 }
 
 // MCKPP_PS=<slots>x<waves>x<workgroups per CU> overrides the choice (experiments)
-ps_geom ps_geometry(int L, bool ext, int cols_per_cu, int *max_slots_per_cu)
+ps_geom ps_geometry(int L, int xv, int cols_per_cu, int *max_slots_per_cu)
 {
-  ps_geom g = ps_choose(L, ext, (size_t)160 * 1024, cols_per_cu, max_slots_per_cu);
+  ps_geom g = ps_choose(L, xv, (size_t)160 * 1024, cols_per_cu, max_slots_per_cu);
   if (const char *e = getenv("MCKPP_PS")) {
     int w = 0, nw = 0, b = 0;
     if (sscanf(e, "%dx%dx%d", &w, &nw, &b) == 3 && w >= 1 && w <= 21 && nw >= 1 && nw <= 16 && b >= 1 && b <= 16) {
@@ -1494,10 +1501,10 @@ ps_geom ps_geometry(int L, bool ext, int cols_per_cu, int *max_slots_per_cu)
 }  // namespace
 
 // the scratch block covers whatever geometry a launch may choose (the choice depends on the column count)
-size_t mckpp_ps_scratch_doubles(int nzp1, int ext, int num_cu)
+size_t mckpp_ps_scratch_doubles(int nzp1, int xv, int num_cu)
 {
   int most = 1;
-  (void)ps_geometry(nzp1 + 2, ext != 0, 1 << 20, &most);
+  (void)ps_geometry(nzp1 + 2, xv, 1 << 20, &most);
   return (size_t)num_cu * most * 4 * ps_scratch_ld(nzp1);
 }
 
@@ -1507,12 +1514,14 @@ hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kpa
   if (p.ncol <= 0) return hipSuccess;
   const int L = p.nzp1 + 2;
   if (L > 1024) return hipErrorInvalidValue;
-  const bool ext = p.ext != 0;
-  const ps_geom g = ps_geometry(L, ext, (p.ncol + num_cu - 1) / num_cu, nullptr);
+  const int xv = p.ext ? (p.LDD ? 2 : 1) : 0;   // kernel variant: default physics / optional / optional with double diffusion
+  const ps_geom g = ps_geometry(L, xv, (p.ncol + num_cu - 1) / num_cu, nullptr);
   if (!p.scratch || p.scratch_doubles < (size_t)num_cu * g.per_cu * g.w * 4 * ps_scratch_ld(p.nzp1)) return hipErrorInvalidValue;
-  const size_t lds = ps_lds_bytes(L, g.w, ext);
+  const size_t lds = ps_lds_bytes(L, g.w, xv);
   if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
-  const void *fn = ext ? reinterpret_cast<const void *>(k_column_ps<true>) : reinterpret_cast<const void *>(k_column_ps<false>);
+  const void *fn = xv == 2   ? reinterpret_cast<const void *>(k_column_ps<2>)
+                   : xv == 1 ? reinterpret_cast<const void *>(k_column_ps<1>)
+                             : reinterpret_cast<const void *>(k_column_ps<0>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   int nblocks = num_cu * g.per_cu;
@@ -1535,7 +1544,8 @@ hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kpa
     }
   }
   const unsigned Lmagic = (unsigned)(0x100000000ull / (unsigned long long)L) + 1u;   // it / L == umulhi(it, Lmagic) for it < 2^20
-  if (ext) hipLaunchKernelGGL(k_column_ps<true>, dim3((unsigned)nblocks), dim3(64 * g.nw), lds, stream, dp, p.ntime, L, g.w, Lmagic);
-  else hipLaunchKernelGGL(k_column_ps<false>, dim3((unsigned)nblocks), dim3(64 * g.nw), lds, stream, dp, p.ntime, L, g.w, Lmagic);
+  if (xv == 2) hipLaunchKernelGGL(k_column_ps<2>, dim3((unsigned)nblocks), dim3(64 * g.nw), lds, stream, dp, p.ntime, L, g.w, Lmagic);
+  else if (xv == 1) hipLaunchKernelGGL(k_column_ps<1>, dim3((unsigned)nblocks), dim3(64 * g.nw), lds, stream, dp, p.ntime, L, g.w, Lmagic);
+  else hipLaunchKernelGGL(k_column_ps<0>, dim3((unsigned)nblocks), dim3(64 * g.nw), lds, stream, dp, p.ntime, L, g.w, Lmagic);
   return hipGetLastError();
 }

@@ -73,7 +73,9 @@ struct mckpp_hip_ctx {
   int *d_ipt = nullptr;
   double *d_prof[P_COUNT] = {};
   double *d_diag[D_COUNT] = {};
-  bool ext = false;   // any optional-physics switch on (kernel build with the N3 code)
+  bool ext = false;          // any optional-physics switch on: the context carries their input / output fields
+  bool ext_kernel = false;   // ... and needs the kernel build with the N3 code (a T/S climatology for the reset of
+                             // failed columns alone - the shipped namelist - does not: the default build reads it)
   double *d_ext_in[E_COUNT] = {};
   double *d_ext_out[O_COUNT] = {};
   double *d_xs = nullptr, *d_adv_d = nullptr, *d_dm = nullptr, *d_hsum = nullptr;
@@ -203,10 +205,12 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   h->ext = c->LDD || c->L_RELAX_SST || c->L_FCORR || c->L_FCORR_WITHZ || c->L_SFCORR || c->L_SFCORR_WITHZ ||
            c->L_RELAX_SAL || c->L_RELAX_OCNT || c->L_NO_FREEZE || c->L_NO_ISOTHERM || c->L_DAMP_CURR ||
            c->clim_present || c->L_ADVECT;
+  h->ext_kernel = c->LDD || c->L_RELAX_SST || c->L_FCORR || c->L_FCORR_WITHZ || c->L_SFCORR || c->L_SFCORR_WITHZ ||
+                  c->L_RELAX_SAL || c->L_RELAX_OCNT || c->L_NO_FREEZE || c->L_NO_ISOTHERM || c->L_DAMP_CURR || c->L_ADVECT;
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipMalloc(&h->d_qhead, sizeof(int)));
   HIPCHK(hipMalloc(&h->d_params, sizeof(mckpp_kparams)));
-  h->scratch_doubles = mckpp_ps_scratch_doubles(nzp1, h->ext ? 1 : 0, h->num_cu);
+  h->scratch_doubles = mckpp_ps_scratch_doubles(nzp1, h->ext_kernel ? (c->LDD ? 2 : 1) : 0, h->num_cu);
   HIPCHK(hipMalloc(&h->d_scratch, h->scratch_doubles * sizeof(double)));
   HIPCHK(hipMemset(h->d_scratch, 0, h->scratch_doubles * sizeof(double)));
   if (getenv("MCKPP_STAMP")) {
@@ -600,7 +604,7 @@ static void fill_params(mckpp_hip_ctx *h, mckpp_kparams &p, int ntime, int mode)
   p.Ts[0] = h->d_prof[P_TS0]; p.Ts[1] = h->d_prof[P_TS1]; p.Ss[0] = h->d_prof[P_SS0]; p.Ss[1] = h->d_prof[P_SS1];
   p.U_init = h->d_prof[P_UINIT]; p.V_init = h->d_prof[P_VINIT];
   p.cs = h->d_cs; p.ci = h->d_ci; p.qhead = h->d_qhead; p.dbg = h->d_dbg;
-  p.ext = h->ext ? 1 : 0;
+  p.ext = h->ext_kernel ? 1 : 0;
   p.L_RELAX_SST = h->c.L_RELAX_SST; p.L_RELAX_CALCONLY = h->c.L_RELAX_CALCONLY; p.L_FCORR = h->c.L_FCORR;
   p.L_FCORR_WITHZ = h->c.L_FCORR_WITHZ; p.L_SFCORR = h->c.L_SFCORR; p.L_SFCORR_WITHZ = h->c.L_SFCORR_WITHZ;
   p.L_RELAX_SAL = h->c.L_RELAX_SAL; p.L_RELAX_OCNT = h->c.L_RELAX_OCNT; p.L_NO_FREEZE = h->c.L_NO_FREEZE;
@@ -726,7 +730,7 @@ int mckpp_hip_synchronize(mckpp_hip_handle h)
 const char *mckpp_hip_kernel_name(mckpp_hip_handle h)
 {
   if (!h) return "none";
-  return h->ext ? "k_column_ps<EXT>" : "k_column_ps";
+  return h->ext_kernel ? "k_column_ps<EXT>" : "k_column_ps";
 }
 
 int mckpp_hip_kernel_residency(mckpp_hip_handle h, int32_t *blocks_per_cu, int32_t *max_blocks_per_cu,

@@ -131,6 +131,30 @@ def test_no_freeze_and_isotherm_and_clim_reset(mk):
     _case(mk, 60, 40, sw, prep, nsteps=3)
 
 
+@pytest.mark.parametrize("nz", [40, 69])
+def test_climatology_reset_alone_runs_on_the_default_kernel(mk, nz):
+    """The shipped namelist names T and S climatology files (ocnT_file, sal_file /= 'none') and switches nothing
+    else on: check_profile then resets a failed column's T and S to the climatology instead of leaving them
+    (src/mckpp_physics_overrides.F90:57-78).  That needs the two input fields but none of the optional-physics
+    kernel code, so such a context runs the default build."""
+    def prep(k3, ob):
+        nzp1 = k3.X.shape[1]
+        _set2(k3, ob, "ocnT_clim", 8.0 + 10.0 * np.exp(-np.arange(nzp1) / 15.0)[None, :] * np.ones((k3.npts, 1)))
+        _set2(k3, ob, "sal_clim", np.asarray(k3.X[:, :, 1]) * 0.5)
+        k3.U[2::3, 0:3, 0] = 40.0              # absurd currents: trap, ten retries, reset to climatology + U_init
+        ob.a["U"][2::3, 1:4] = 40.0
+    k3, ob = _case(mk, 60, nz, dict(clim_present=1), prep, nsteps=1, grid="stretched" if nz == 69 else "uniform")
+    clim = 8.0 + 10.0 * np.exp(-np.arange(nz + 1) / 15.0)
+    assert np.array_equal(np.asarray(k3.X[2, :, 0]), clim)      # a failed column came back as the climatology
+    kc = mk.KppConstFields(nz)
+    kc.clim_present = 1
+    mk.mckpp_physics_lookup(kc)
+    ctx = mk.MckppHip(kc)
+    assert ctx.kernel_name == "k_column_ps"
+    ctx.close()
+    _case(mk, 60, nz, dict(clim_present=1), prep, nsteps=3, grid="stretched" if nz == 69 else "uniform")
+
+
 @pytest.mark.parametrize("grid", ["uniform", "stretched"])
 def test_prescribed_advection_modes(mk, grid):
     def prep(k3, ob):
