@@ -234,6 +234,52 @@ __device__ __forceinline__ void wscale_dev(const KP &p, const wscale_u &w, doubl
   }
 }
 
+// The same look-up in two stages, for a caller with several of them in flight: the eight table entries are
+// fetched whatever the sign of zehat (the index is clamped into the table either way), so the loads of two
+// look-ups can be issued together and their latencies overlap; wscale_finish then does what wscale_dev does.
+struct wscale_t {
+  double zehat, zfrac;
+  double t00x, t00y, t10x, t10y, t01x, t01y, t11x, t11y;
+};
+
+template <class KP>
+__device__ __forceinline__ wscale_t wscale_fetch(const KP &p, const wscale_u &w, double sigma, double hbl, double bfsfc)
+{
+  const double zmin = -4.e-7, zmax = 0.0;
+  const double deltaz = (zmax - zmin) / (NI + 1);
+  wscale_t t;
+  t.zehat = p.vonk * sigma * hbl * bfsfc;
+  const double zdiff = t.zehat - zmin;
+  const double q = div_fast(zdiff, deltaz, 1. / deltaz);
+  int iz = (int)q;
+  iz = iz < NI ? iz : NI;
+  iz = iz > 0 ? iz : 0;
+  t.zfrac = q - (double)iz;
+  const auto r0 = p.wtab + 2 * ((size_t)w.ju * NT + iz), r1 = r0 + 2 * NT;
+  t.t00x = r0[0]; t.t00y = r0[1]; t.t10x = r0[2]; t.t10y = r0[3];
+  t.t01x = r1[0]; t.t01y = r1[1]; t.t11x = r1[2]; t.t11y = r1[3];
+  return t;
+}
+
+template <class KP>
+__device__ __forceinline__ void wscale_finish(const KP &p, const wscale_u &w, const wscale_t &t, double &wm, double &ws)
+{
+  const double zmax = 0.0, c1 = 5.0;
+  if (t.zehat <= zmax) {
+    const double zfrac = t.zfrac, fzfrac = 1. - zfrac;
+    double wam = (fzfrac)*t.t01x + zfrac * t.t11x;
+    double wbm = (fzfrac)*t.t00x + zfrac * t.t10x;
+    wm = (1. - w.ufrac) * wbm + w.ufrac * wam;
+    double was = (fzfrac)*t.t01y + zfrac * t.t11y;
+    double wbs = (fzfrac)*t.t00y + zfrac * t.t10y;
+    ws = (1. - w.ufrac) * wbs + w.ufrac * was;
+  } else {
+    const double den = w.ucube + c1 * t.zehat;
+    wm = div_fast(p.vonk * w.ustar * w.ucube, den, rcp_refine(den));
+    ws = wm;
+  }
+}
+
 // Jerlov tables, src/mckpp_physics_swfrac_mod.F90:59-61 (constant memory: indexed by a run-time water type)
 static __constant__ double jer_rfac_c[6] = {0, 0.58, 0.62, 0.67, 0.77, 0.78};
 static __constant__ double jer_a1_c[6] = {0, 0.35, 0.6, 1.0, 1.5, 1.4};

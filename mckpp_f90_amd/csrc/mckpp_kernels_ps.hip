@@ -46,9 +46,12 @@ enum {
   I_MAYBE_NEXT, I_LOCEAN, I_PAR /* which C_T1X holds the iterate's level-1 temperature */, I_COUNT
 };
 // LDS rows of a slot and what each holds between which phases of a pass:
-//   Q_DM   (LDD talpha L1..L2)  difm: interior L3, final L5 .. M5 (V sweep, U system's diffusivity)
-//   Q_DT   Ritop L2..L3; dift L3/L5 .. M4, where the T system's gam overwrites it level by level
-//   Q_DS   dVsq L2..L3;  difs likewise, then the S system's gam
+//   Q_DM   (LDD talpha L1..L2)  difm: interior L3, final L5 .. L7
+//   Q_DT   Ritop L2..L3; dift L3/L5 .. M4, where the T system's gam overwrites it level by level; q = -cu of the
+//          momentum system L7..M5 (V sweep)
+//   Q_DS   dVsq L2..L3; with double diffusion difs L3/L5 .. M4, then the S system's gam - without it difs = dift
+//          bit for bit, T and S share Q_DT and its gam, and Q_DS takes their pivots in M4; refined reciprocals
+//          of the momentum pivots L7..M5 (V sweep)
 //   Q_YU   previous U solution .. L1; U of the iterate L1..L2; Monin-Obukhov depth L3..L4; rhs L6; solution M4
 //   Q_YT   previous T solution .. L1; dbloc L2..L3; rhs L6; solution M4
 //   Q_YS   previous S solution .. L1; buoyancy L1..L2; hmin candidates L4..M3; rhs L6; solution M4
@@ -89,8 +92,13 @@ __host__ __device__ inline size_t ps_lds_bytes(int L, int W, int xv)
 
 // ---- the manager wave's serial sweeps, one lane per slot (x system) over the slots' level-interleaved rows
 // (element (row a, level i) of slot s at slots[s*SS + i*KS + a]; grid constants with stride CS).
+// One wave issues an instruction every 6-10 cycles whether or not it depends on the one before, so a sweep costs
+// its instruction count: everything that is not on a recurrence is done elsewhere (by all threads, in a level
+// phase), operands are fetched a trip ahead, and the conditions that need other arithmetic are tested once per
+// trip of two levels, after the fact (the trip is then redone from the state it started with).
 
-// bldepth_mod.F90:137: Rib(ku) = MAX(Rib(ku), Rib(ka) + epsln) down the column, four levels per trip
+// bldepth_mod.F90:137: Rib(ku) = MAX(Rib(ku), Rib(ka) + epsln) down the column, four levels per trip, the next
+// trip's values fetched before the current trip's recurrence runs
 __device__ __forceinline__ void ps_scan_rib(int W, int row, double *slots, int SS, int KS, int nz, const int *sact,
                                             int sact_stride, int lane)
 {
@@ -99,6 +107,7 @@ __device__ __forceinline__ void ps_scan_rib(int W, int row, double *slots, int S
     double *r = slots + lane * SS + row;
     double rb = 0.0;
     int k = 2;
+#ifdef T_NOPF_SCAN
     for (; k + 3 <= nz; k += 4) {
       const double a0 = r[k * KS], a1 = r[(k + 1) * KS], a2 = r[(k + 2) * KS], a3 = r[(k + 3) * KS];
       rb = dmax2(a0, rb + epsln16); const double b0 = rb;
@@ -107,6 +116,25 @@ __device__ __forceinline__ void ps_scan_rib(int W, int row, double *slots, int S
       rb = dmax2(a3, rb + epsln16);
       r[k * KS] = b0; r[(k + 1) * KS] = b1; r[(k + 2) * KS] = b2; r[(k + 3) * KS] = rb;
     }
+#else
+    if (k + 3 <= nz) {
+      double a0 = r[k * KS], a1 = r[(k + 1) * KS], a2 = r[(k + 2) * KS], a3 = r[(k + 3) * KS];
+      for (;;) {
+        const int kn = k + 4;
+        const bool more = kn + 3 <= nz;
+        double n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+        if (more) { n0 = r[kn * KS]; n1 = r[(kn + 1) * KS]; n2 = r[(kn + 2) * KS]; n3 = r[(kn + 3) * KS]; }
+        rb = dmax2(a0, rb + epsln16); const double b0 = rb;
+        rb = dmax2(a1, rb + epsln16); const double b1 = rb;
+        rb = dmax2(a2, rb + epsln16); const double b2 = rb;
+        rb = dmax2(a3, rb + epsln16);
+        r[k * KS] = b0; r[(k + 1) * KS] = b1; r[(k + 2) * KS] = b2; r[(k + 3) * KS] = rb;
+        k = kn;
+        if (!more) break;
+        a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+      }
+    }
+#endif
     for (; k <= nz; ++k) {
       rb = dmax2(r[k * KS], rb + epsln16);
       r[k * KS] = rb;
@@ -114,22 +142,79 @@ __device__ __forceinline__ void ps_scan_rib(int W, int row, double *slots, int S
   }
 }
 
-// tridcof + tridmat (solvers.F90:14-44, 112-161) for U, T, S, skewed by one level: iteration i forms
-// gam(i) = cl(i-1)/bet(i-1) and y(i-1) = num(i-1)/bet(i-1) over the same denominator.  lane = (slot, system).
-// The T and S systems store their gam over the diffusivity row they have just consumed (level i's diffusivity
-// is in a register before gam(i) is written); the momentum system keeps difm, gam and its pivots for the V
-// sweep.
-__device__ __forceinline__ void ps_thomas_uts(int W, double *slots, int SS, int KS, int CS, int nz, const double *c_t0,
-                                              const double *c_t1, const int *sact, int sact_stride, int *sbad,
-                                              int sbad_stride, int lane)
+// back substitution yn(i) = yn(i) - gam(i+1) yn(i+1) (solvers.F90:156-158), four levels per trip, the next trip's
+// operands fetched before the current trip's recurrence runs
+__device__ __forceinline__ void ps_backsub(double *y, const double *gm, int KS, int nz)
 {
+  double yy = y[(nz) * KS];
+  int i = nz - 1;
+#ifdef T_NOPF_BACK
+  for (; i >= 4; i -= 4) {
+    const double y0 = y[(i) * KS], y1 = y[(i - 1) * KS], y2 = y[(i - 2) * KS], y3 = y[(i - 3) * KS];
+    const double g0 = gm[(i + 1) * KS], g1 = gm[(i) * KS], g2 = gm[(i - 1) * KS], g3 = gm[(i - 2) * KS];
+    yy = y0 - g0 * yy; const double r0 = yy;
+    yy = y1 - g1 * yy; const double r1 = yy;
+    yy = y2 - g2 * yy; const double r2 = yy;
+    yy = y3 - g3 * yy;
+    y[(i) * KS] = r0; y[(i - 1) * KS] = r1; y[(i - 2) * KS] = r2; y[(i - 3) * KS] = yy;
+  }
+#else
+  if (i >= 4) {
+    double y0 = y[(i) * KS], y1 = y[(i - 1) * KS], y2 = y[(i - 2) * KS], y3 = y[(i - 3) * KS];
+    double g0 = gm[(i + 1) * KS], g1 = gm[(i) * KS], g2 = gm[(i - 1) * KS], g3 = gm[(i - 2) * KS];
+    for (;;) {
+      const int j = i - 4;
+      const bool more = j >= 4;
+      double ny0 = 0, ny1 = 0, ny2 = 0, ny3 = 0, ng0 = 0, ng1 = 0, ng2 = 0, ng3 = 0;
+      if (more) {
+        ny0 = y[(j) * KS]; ny1 = y[(j - 1) * KS]; ny2 = y[(j - 2) * KS]; ny3 = y[(j - 3) * KS];
+        ng0 = gm[(j + 1) * KS]; ng1 = gm[(j) * KS]; ng2 = gm[(j - 1) * KS]; ng3 = gm[(j - 2) * KS];
+      }
+      yy = y0 - g0 * yy; const double r0 = yy;
+      yy = y1 - g1 * yy; const double r1 = yy;
+      yy = y2 - g2 * yy; const double r2 = yy;
+      yy = y3 - g3 * yy;
+      y[(i) * KS] = r0; y[(i - 1) * KS] = r1; y[(i - 2) * KS] = r2; y[(i - 3) * KS] = yy;
+      i = j;
+      if (!more) break;
+      y0 = ny0; y1 = ny1; y2 = ny2; y3 = ny3; g0 = ng0; g1 = ng1; g2 = ng2; g3 = ng3;
+    }
+  }
+#endif
+  for (; i >= 1; --i) {
+    yy = y[(i) * KS] - gm[(i + 1) * KS] * yy;
+    y[(i) * KS] = yy;
+  }
+}
+
+// The rows of tridiagonal system `sys` (0 momentum, 1 temperature, 2 salinity) of kernel variant XV: its
+// diffusivity, where its gam goes and where its pivots go.  Without double diffusion dift and difs are the same
+// numbers (rimix_mod.F90:95-97 sets them equal, blmix and enhance treat them alike), so T and S share one
+// diffusivity row and one factorisation: both lanes form the same gam and pivots and store them to the same
+// places (gam over the diffusivities just consumed, the pivots in the row difs would have had); the momentum
+// system keeps difm, gam and its pivots for the V sweep.  With double diffusion the pivots of T and S go to two
+// staging rows that are dead by then, so no lane's store needs a predicate.
+template <int XV> struct ps_sysrows {
+  static constexpr bool DD = XV == 2;
+  __device__ static __forceinline__ int d(int sys) { return sys == 0 ? (int)Q_DM : (DD && sys == 2) ? (int)Q_DS : (int)Q_DT; }
+  __device__ static __forceinline__ int gam(int sys) { return sys == 0 ? (int)Q_GM : d(sys); }
+  __device__ static __forceinline__ int bet(int sys) { return sys == 0 ? (int)Q_BET : DD ? (sys == 1 ? (int)Q_X1 : (int)Q_X2) : (int)Q_DS; }
+};
+
+// tridcof + tridmat, forward part (solvers.F90:14-44, 112-154) for U, T, S, skewed by one level: iteration i forms
+// gam(i) = cl(i-1)/bet(i-1) and y(i-1) = num(i-1)/bet(i-1) over the same denominator.  lane = (slot, system).
+template <int XV>
+__device__ __forceinline__ void ps_thomas_uts_fwd(int W, double *slots, int SS, int CS, int nz, const double *c_t0,
+                                                  const double *c_t1, const int *sact, int sact_stride, int *sbad,
+                                                  int sbad_stride, int lane)
+{
+  constexpr int KS = XV == 2 ? (int)Q_COUNT_EXT_DD : XV == 1 ? (int)Q_COUNT_EXT : (int)Q_COUNT;
   if (lane < 3 * W) {
     const int sl = lane / 3, sys = lane - 3 * sl;
     if (sact[sl * sact_stride]) {
       double *base = slots + sl * SS;
-      const double *d = base + (Q_DM + sys);
-      double *y = base + (Q_YU + sys), *gm = base + (sys == 0 ? (int)Q_GM : (int)Q_DM + sys);
-      double *betm = base + Q_BET;
+      const double *d = base + ps_sysrows<XV>::d(sys);
+      double *y = base + (Q_YU + sys), *gm = base + ps_sysrows<XV>::gam(sys), *betp = base + ps_sysrows<XV>::bet(sys);
       int bad = 0;
       // The coefficients of tridcof share their products: with p(i) = tri(i,1) diff(i) and q(i) = tri(i,0) diff(i-1)
       //   cl(i) = -p(i), cu(i) = -q(i), cc(i) = (1 + p(i)) + q(i)      (solvers.F90:28-40, same roundings: a
@@ -138,15 +223,13 @@ __device__ __forceinline__ void ps_thomas_uts(int W, double *slots, int SS, int 
       double pm1 = c_t1[(1) * CS] * dm1;   // p(1)
       double bet = 1. + pm1;               // cc(1)
       double ynum = y[(1) * KS];           // y(1) = rhs(1)/bet, formed in the next level's step
-      // One level of the skewed sweep.  The serial wave issues one fp64 instruction every 6-10 cycles whether or
-      // not it depends on the previous one, so the sweep's time is its instruction count: the common case is one
-      // straight basic block (pivot chain bet -> 1/bet -> gam -> bet' interleaved with the solution chain, both
-      // on div_fast), and the two conditions that need other arithmetic - a zero pivot, or a tiny non-zero
-      // solution numerator that div_fast must not see - are detected at the end of the level before and sent
-      // through the slow copy of the step (IEEE sequences), practically never.
-      unsigned long long rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum));   // wave mask, lives in SGPRs
+      // One level: the pivot chain bet -> 1/bet -> gam -> bet' interleaved with the solution chain, both on
+      // div_fast.  Two conditions need other arithmetic - a zero pivot (solvers.F90:140-151 would stop there), or a
+      // tiny non-zero solution numerator that div_fast must not see; they practically never occur, so a trip of two
+      // levels runs straight through, the state each of its levels started from is tested once at its end, and if
+      // any lane of the wave was in either condition the trip is redone from its saved state with IEEE sequences.
       auto level = [&](int i, double di, double t0, double t1, double rhs, auto slow) {
-        if (slow.value && bet == 0.) { bad = 1; bet = 1.E-12; }   // solvers.F90:140-151 would stop here
+        if (slow.value && bet == 0.) { bad = 1; bet = 1.E-12; }
         const double clm1 = -pm1;
         const double q = t0 * dm1;          // -cu(i)
         const double p = t1 * di;           // -cl(i)
@@ -154,17 +237,50 @@ __device__ __forceinline__ void ps_thomas_uts(int W, double *slots, int SS, int 
         const double rb = rcp_refine(bet);
         const double g = slow.value ? div_by_refined(clm1, bet, rb) : div_fast(clm1, bet, rb);
         const double yprev = slow.value ? div_by_refined(ynum, bet, rb) : div_fast(ynum, bet, rb);
-        if (sys == 0) betm[(i - 1) * KS] = bet;
+        betp[(i - 1) * KS] = bet;
         y[(i - 1) * KS] = yprev;
         gm[(i) * KS] = g;
         bet = cc + q * g;
         ynum = rhs + q * yprev;
-        rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum)) | __builtin_amdgcn_ballot_w64(bet == 0.);
         dm1 = di; pm1 = p;
       };
+#ifdef T_UTS_TRIP2
+      bool f_in = tiny_nonzero(ynum);   // of the state the next level starts from
+      {   // two levels per trip; each half's operands are fetched while the other half runs
+        int i = 2;
+        double a_d = d[(2) * KS], a_t0 = c_t0[(2) * CS], a_t1 = c_t1[(2) * CS], a_r = y[(2) * KS];
+        for (; i + 1 <= nz; i += 2) {
+          const double b_d = d[(i + 1) * KS], b_t0 = c_t0[(i + 1) * CS], b_t1 = c_t1[(i + 1) * CS], b_r = y[(i + 1) * KS];
+          const double s_dm1 = dm1, s_pm1 = pm1, s_bet = bet, s_ynum = ynum;
+          level(i, a_d, a_t0, a_t1, a_r, std::false_type{});
+          const bool f_mid = tiny_nonzero(ynum) || bet == 0.;
+          level(i + 1, b_d, b_t0, b_t1, b_r, std::false_type{});
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(f_in || f_mid) != 0ull, 0)) {
+            dm1 = s_dm1; pm1 = s_pm1; bet = s_bet; ynum = s_ynum;
+            level(i, a_d, a_t0, a_t1, a_r, std::true_type{});
+            level(i + 1, b_d, b_t0, b_t1, b_r, std::true_type{});
+          }
+          f_in = tiny_nonzero(ynum) || bet == 0.;
+          if (i + 2 <= nz) { a_d = d[(i + 2) * KS]; a_t0 = c_t0[(i + 2) * CS]; a_t1 = c_t1[(i + 2) * CS]; a_r = y[(i + 2) * KS]; }
+        }
+        if (i <= nz) {
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(f_in) != 0ull, 0)) level(i, a_d, a_t0, a_t1, a_r, std::true_type{});
+          else level(i, a_d, a_t0, a_t1, a_r, std::false_type{});
+        }
+      }
+#else
+      // wave mask of the lanes whose current state (bet, ynum) needs the slow step; formed when the state is, used
+      // a level later
+      unsigned long long rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum));
       auto step = [&](int i, double di, double t0, double t1, double rhs) {
-        if (__builtin_expect(rare != 0ull, 0)) level(i, di, t0, t1, rhs, std::true_type{});
-        else level(i, di, t0, t1, rhs, std::false_type{});
+        const double s_dm1 = dm1, s_pm1 = pm1, s_bet = bet, s_ynum = ynum;
+        const unsigned long long r_in = rare;
+        level(i, di, t0, t1, rhs, std::false_type{});
+        if (__builtin_expect(r_in != 0ull, 0)) {
+          dm1 = s_dm1; pm1 = s_pm1; bet = s_bet; ynum = s_ynum;
+          level(i, di, t0, t1, rhs, std::true_type{});
+        }
+        rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum) || bet == 0.);
       };
       {   // two levels per trip; each half's operands are fetched while the other half runs
         int i = 2;
@@ -177,90 +293,75 @@ __device__ __forceinline__ void ps_thomas_uts(int W, double *slots, int SS, int 
         }
         if (i <= nz) step(i, a_d, a_t0, a_t1, a_r);
       }
+#endif
       if (bet == 0.) { bad = 1; bet = 1.E-12; }
-      double yy = div_by_refined(ynum, bet, rcp_refine(bet));
-      y[(nz) * KS] = yy;
-      if (sys == 0) betm[(nz) * KS] = bet;
-      int i = nz - 1;   // back substitution, operands fetched four levels ahead
-      for (; i >= 4; i -= 4) {
-        const double y0 = y[(i) * KS], y1 = y[(i - 1) * KS], y2 = y[(i - 2) * KS], y3 = y[(i - 3) * KS];
-        const double g0 = gm[(i + 1) * KS], g1 = gm[(i) * KS], g2 = gm[(i - 1) * KS], g3 = gm[(i - 2) * KS];
-        yy = y0 - g0 * yy; const double r0 = yy;
-        yy = y1 - g1 * yy; const double r1 = yy;
-        yy = y2 - g2 * yy; const double r2 = yy;
-        yy = y3 - g3 * yy;
-        y[(i) * KS] = r0; y[(i - 1) * KS] = r1; y[(i - 2) * KS] = r2; y[(i - 3) * KS] = yy;
-      }
-      for (; i >= 1; --i) {
-        yy = y[(i) * KS] - gm[(i + 1) * KS] * yy;
-        y[(i) * KS] = yy;
-      }
+      y[(nz) * KS] = div_by_refined(ynum, bet, rcp_refine(bet));
+      betp[(nz) * KS] = bet;
       if (bad) sbad[sl * sbad_stride] = 1;
     }
   }
 }
 
-// V on the stored momentum factorisation (pivots, gam); lane = slot.  The refined reciprocal of a pivot is
-// formed again from the pivot (the same value the U sweep used: rcp_refine is a function of its argument),
-// off the dependent chain, when the level's operands are fetched.
-__device__ __forceinline__ void ps_thomas_v(int W, double *slots, int SS, int KS, int CS, int nz, const double *c_t0,
-                                            const int *sact, int sact_stride, int lane)
+template <int XV>
+__device__ __forceinline__ void ps_thomas_uts_back(int W, double *slots, int SS, int nz, const int *sact, int sact_stride, int lane)
+{
+  constexpr int KS = XV == 2 ? (int)Q_COUNT_EXT_DD : XV == 1 ? (int)Q_COUNT_EXT : (int)Q_COUNT;
+  if (lane < 3 * W) {
+    const int sl = lane / 3, sys = lane - 3 * sl;
+    if (sact[sl * sact_stride]) {
+      double *base = slots + sl * SS;
+      ps_backsub(base + (Q_YU + sys), base + ps_sysrows<XV>::gam(sys), KS, nz);
+    }
+  }
+}
+
+// V on the stored momentum factorisation, forward part; lane = slot.  L7 (all threads) has left beside the pivots
+// (Q_BET) their refined reciprocals (row Q_DS) and q(i) = tri(i,0) difm(i-1) = -cu(i) (row Q_DT) - the values the U
+// sweep formed (same functions of the same arguments), in two rows that are dead once T and S are solved - so a
+// level is n = rhs + q y (= rhs - cu y, ocnint / solvers.F90:153) and one div_fast.  A tiny non-zero numerator
+// (which div_fast must not see) is looked for once per trip of two levels, after the fact; the trip is then
+// redone from the value it started with, with IEEE divisions.
+__device__ __forceinline__ void ps_thomas_v_fwd(int W, double *slots, int SS, int KS, int nz, const int *sact,
+                                                int sact_stride, int lane)
 {
   if (lane < W && sact[lane * sact_stride]) {
     double *base = slots + lane * SS;
-    const double *d = base + Q_DM, *gm = base + Q_GM, *betm = base + Q_BET;
+    const double *betm = base + Q_BET, *rbm = base + Q_DS, *qm = base + Q_DT;
     double *y = base + Q_YV;
     const double b1 = betm[(1) * KS];
-    double yy = div_by_refined(y[(1) * KS], b1, rcp_refine(b1));
+    double yy = div_by_refined(y[(1) * KS], b1, rbm[(1) * KS]);
     y[(1) * KS] = yy;
-    double dm1 = d[(1) * KS];
-    // Here the quotient is the dependent chain itself, so it takes div_fast unconditionally; a tiny
-    // non-zero numerator is noticed at the end of its level and the quotient is redone (IEEE
-    // sequence) at the top of the next one, before anything has used it.  Two levels per trip.
-    double nprev = 0.0, bprev = 1.0;
-    unsigned long long rare = 0ull;   // wave mask of lanes whose last numerator was tiny
-    auto vstep = [&](int i, double rhs, double t0, double b, double r, double di) {
-      if (__builtin_expect(rare != 0ull, 0)) {
-        if (tiny_nonzero(nprev)) { yy = nprev / bprev; y[(i - 1) * KS] = yy; }
+    int i = 2;
+    double a_rhs = y[(2) * KS], a_q = qm[(2) * KS], a_b = betm[(2) * KS], a_r = rbm[(2) * KS];
+    for (; i + 1 <= nz; i += 2) {
+      const double b_rhs = y[(i + 1) * KS], b_q = qm[(i + 1) * KS], b_b = betm[(i + 1) * KS], b_r = rbm[(i + 1) * KS];
+      const double y_in = yy;
+      const double n0 = a_rhs + a_q * yy;
+      double y0 = div_fast(n0, a_b, a_r);
+      const double n1 = b_rhs + b_q * y0;
+      double y1 = div_fast(n1, b_b, b_r);
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(tiny_nonzero(n0) || tiny_nonzero(n1)) != 0ull, 0)) {
+        y0 = (a_rhs + a_q * y_in) / a_b;
+        y1 = (b_rhs + b_q * y0) / b_b;
       }
-      const double cu = -t0 * dm1;
-      const double n = rhs - cu * yy;
-      yy = div_fast(n, b, r);
-      rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(n));
-      y[(i) * KS] = yy;
-      nprev = n; bprev = b;
-      dm1 = di;
-    };
-    {
-      int i = 2;
-      double a_rhs = y[(2) * KS], a_t0 = c_t0[(2) * CS], a_b = betm[(2) * KS], a_d = d[(2) * KS];
-      double a_r = rcp_refine(a_b);
-      for (; i + 1 <= nz; i += 2) {
-        const double b_rhs = y[(i + 1) * KS], b_t0 = c_t0[(i + 1) * CS], b_b = betm[(i + 1) * KS], b_d = d[(i + 1) * KS];
-        const double b_r = rcp_refine(b_b);
-        vstep(i, a_rhs, a_t0, a_b, a_r, a_d);
-        if (i + 2 <= nz) { a_rhs = y[(i + 2) * KS]; a_t0 = c_t0[(i + 2) * CS]; a_b = betm[(i + 2) * KS]; a_d = d[(i + 2) * KS]; a_r = rcp_refine(a_b); }
-        vstep(i + 1, b_rhs, b_t0, b_b, b_r, b_d);
-      }
-      if (i <= nz) vstep(i, a_rhs, a_t0, a_b, a_r, a_d);
+      yy = y1;
+      y[(i) * KS] = y0; y[(i + 1) * KS] = y1;
+      if (i + 2 <= nz) { a_rhs = y[(i + 2) * KS]; a_q = qm[(i + 2) * KS]; a_b = betm[(i + 2) * KS]; a_r = rbm[(i + 2) * KS]; }
     }
-    if (__builtin_expect(rare != 0ull, 0)) {
-      if (tiny_nonzero(nprev)) { yy = nprev / bprev; y[(nz) * KS] = yy; }
-    }
-    int i = nz - 1;
-    for (; i >= 4; i -= 4) {
-      const double y0 = y[(i) * KS], y1 = y[(i - 1) * KS], y2 = y[(i - 2) * KS], y3 = y[(i - 3) * KS];
-      const double g0 = gm[(i + 1) * KS], g1 = gm[(i) * KS], g2 = gm[(i - 1) * KS], g3 = gm[(i - 2) * KS];
-      yy = y0 - g0 * yy; const double r0 = yy;
-      yy = y1 - g1 * yy; const double r1 = yy;
-      yy = y2 - g2 * yy; const double r2 = yy;
-      yy = y3 - g3 * yy;
-      y[(i) * KS] = r0; y[(i - 1) * KS] = r1; y[(i - 2) * KS] = r2; y[(i - 3) * KS] = yy;
-    }
-    for (; i >= 1; --i) {
-      yy = y[(i) * KS] - gm[(i + 1) * KS] * yy;
+    if (i <= nz) {
+      const double n0 = a_rhs + a_q * yy;
+      yy = div_fast_guarded(n0, a_b, a_r);
       y[(i) * KS] = yy;
     }
+  }
+}
+
+__device__ __forceinline__ void ps_thomas_v_back(int W, double *slots, int SS, int KS, int nz, const int *sact,
+                                                 int sact_stride, int lane)
+{
+  if (lane < W && sact[lane * sact_stride]) {
+    double *base = slots + lane * SS;
+    ps_backsub(base + Q_YV, base + Q_GM, KS, nz);
   }
 }
 
@@ -480,10 +581,19 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         const double caseA = 0.5 + dsign(0.5, -c_zm[kbl] - 0.5 * c_hm[kbl] - hbl);
         double gat1[3], dat1[3];
         const double r_hbl = rcp_refine(hbl);
+        // the two look-ups of this phase (blmix_mod.F90:64-66 at sigma = 1 | epsilon, :136-141 at the grid level
+        // above kbl) depend on hbl only: both sets of table entries are requested before either is used
+        const double sig_k = div_fast(-c_zm[kbl - 1], hbl, r_hbl);
+        const wscale_t wt1 = wscale_fetch(p, wu, stable * 1.0 + (1. - stable) * eps01, hbl, bfsfc);
+        const wscale_t wt2 = wscale_fetch(p, wu, stable * sig_k + (1. - stable) * dmin2(sig_k, eps01), hbl, bfsfc);
+        double wm_1, ws_1, wm_k, ws_k;
+        wscale_finish(p, wu, wt1, wm_1, ws_1);
+        wscale_finish(p, wu, wt2, wm_k, ws_k);
+        // without double diffusion the interior difs and dift are the same numbers, and so is everything formed
+        // from them here (index 1: salinity, 2: temperature)
+        constexpr int MS = DD ? 1 : 2;   // first of the scalar systems to evaluate
         {
-          double wm, ws;
-          double sigma = stable * 1.0 + (1. - stable) * eps01;
-          wscale_dev(p, wu, sigma, hbl, bfsfc, wm, ws);
+          const double wm = wm_1, ws = ws_1;
           int ifx = (int)(caseA + epsln20);
           int kn = ifx * (kbl - 1) + (1 - ifx) * kbl;
           double hmkn = c_hm[kn], hmkn1 = c_hm[kn + 1];
@@ -494,6 +604,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           double dp[3], dh[3];
 #pragma unroll
           for (int m = 0; m < 3; ++m) {
+            if (m != 0 && m < MS) continue;
             double dvdzup = div_fast(dd[m][kn - 1] - dd[m][kn], hmkn, r_hmkn);
             double dvdzdn = div_fast(dd[m][kn] - dd[m][kn + 1], hmkn1, r_hmkn1);
             dp[m] = 0.5 * ((1. - R) * (dvdzup + __builtin_fabs(dvdzup)) + R * (dvdzdn + __builtin_fabs(dvdzdn)));
@@ -506,27 +617,31 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           gat1[0] = div_fast(div_fast(dh[0], hbl, r_hbl), wme, r_wme);
           dat1[0] = div_fast(-dp[0], wme, r_wme) + f1 * dh[0];
           dat1[0] = dmin2(dat1[0], 0.);
-          gat1[1] = div_fast(div_fast(dh[1], hbl, r_hbl), wse, r_wse);
-          dat1[1] = div_fast(-dp[1], wse, r_wse) + f1 * dh[1];
-          dat1[1] = dmin2(dat1[1], 0.);
-          gat1[2] = div_fast(div_fast(dh[2], hbl, r_hbl), wse, r_wse);
-          dat1[2] = div_fast(-dp[2], wse, r_wse) + f1 * dh[2];
-          dat1[2] = dmin2(dat1[2], 0.);
+#pragma unroll
+          for (int m = MS; m < 3; ++m) {
+            gat1[m] = div_fast(div_fast(dh[m], hbl, r_hbl), wse, r_wse);
+            dat1[m] = div_fast(-dp[m], wse, r_wse) + f1 * dh[m];
+            dat1[m] = dmin2(dat1[m], 0.);
+          }
+          if (!DD) { gat1[1] = gat1[2]; dat1[1] = dat1[2]; }
         }
         {
-          double wm, ws;
-          double sig = div_fast(-c_zm[kbl - 1], hbl, r_hbl);
-          double sigma = stable * sig + (1. - stable) * dmin2(sig, eps01);
-          wscale_dev(p, wu, sigma, hbl, bfsfc, wm, ws);
+          const double wm = wm_k, ws = ws_k;
+          const double sig = sig_k;
           double a1 = sig - 2.;
           double a2 = 3. - 2. * sig;
           double a3 = sig - 1.;
           double Gm = a1 + a2 * gat1[0] + a3 * dat1[0];
-          double Gs = a1 + a2 * gat1[1] + a3 * dat1[1];
           double Gt = a1 + a2 * gat1[2] + a3 * dat1[2];
           msc[C_DKM1 + 0] = hbl * wm * sig * (1. + sig * Gm);
-          msc[C_DKM1 + 1] = hbl * ws * sig * (1. + sig * Gs);
-          msc[C_DKM1 + 2] = hbl * ws * sig * (1. + sig * Gt);
+          const double dkm1_t = hbl * ws * sig * (1. + sig * Gt);
+          msc[C_DKM1 + 2] = dkm1_t;
+          if (DD) {
+            double Gs = a1 + a2 * gat1[1] + a3 * dat1[1];
+            msc[C_DKM1 + 1] = hbl * ws * sig * (1. + sig * Gs);
+          } else {
+            msc[C_DKM1 + 1] = dkm1_t;
+          }
         }
         msc[C_RHBL] = r_hbl; msc[C_STABLE] = stable; msc[C_BFSFC] = bfsfc; msc[C_CASEA] = caseA;
 #pragma unroll
@@ -846,9 +961,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 
   // =========================== persistent pass loop ===========================
 #ifdef MCKPP_PS_STAMPS   // profiling build: per-segment cycle sums kept in registers by the manager wave
-  unsigned long long tacc[24];
+  unsigned long long tacc[27];
 #pragma unroll
-  for (int i = 0; i < 24; ++i) tacc[i] = 0;
+  for (int i = 0; i < 27; ++i) tacc[i] = 0;
   unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #define STAMP(i)                                              \
   do {                                                        \
@@ -956,9 +1071,10 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       double dmo = div_fast(div_fast(cmonob * ustar * ustar * ustar, p.vonk, c_misc[1]), bfa, rcp_refine(bfa));
       dmo = st * dmo - (1. - st) * zm_kmp1;
       // interior diffusivities (after the reads of Ritop / dVsq, which share their rows)
-      if (actz) { row(Q_DM)[k] = dm_i; row(Q_DS)[k] = ds_i; row(Q_DT)[k] = dt_i; }
-      if (isnz) { row(Q_DM)[k + 1] = dm_i; row(Q_DS)[k + 1] = ds_i; row(Q_DT)[k + 1] = dt_i; }   // kppmix_mod.F90:82-84
-      if (is1) { row(Q_DM)[0] = 0.0; row(Q_DS)[0] = 0.0; row(Q_DT)[0] = 0.0; }
+      // (without double diffusion difs = dift bit for bit: one row, Q_DT, serves both from here on)
+      if (actz) { row(Q_DM)[k] = dm_i; if (DD) row(Q_DS)[k] = ds_i; row(Q_DT)[k] = dt_i; }
+      if (isnz) { row(Q_DM)[k + 1] = dm_i; if (DD) row(Q_DS)[k + 1] = ds_i; row(Q_DT)[k + 1] = dt_i; }   // kppmix_mod.F90:82-84
+      if (is1) { row(Q_DM)[0] = 0.0; if (DD) row(Q_DS)[0] = 0.0; row(Q_DT)[0] = 0.0; }
       if (k >= 2 && actz) { row(Q_YV)[k] = raw; row(Q_YU)[k] = dmo; }
       if (is1) { row(Q_YV)[1] = 0.0; row(Q_YU)[1] = -zm_kmp1; }
     END_ITEMS
@@ -1013,7 +1129,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(9);
 
     // ---- M3: hbl, kbl, slot-uniform part of blmix
+#ifndef T_NO_M3
     if (wv == mgr) { M3(); G_early(); }
+#endif
     STAMP(10);
     __syncthreads();
     STAMP(11);
@@ -1024,7 +1142,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       if (!act) continue;
       const int kbl = si[I_KBL];
       const double zmk = c_zm[k];
-      const double dm_i = row(Q_DM)[k], ds_i = row(Q_DS)[k], dt_l = row(Q_DT)[k];   // interior values of L3
+      const double dm_i = row(Q_DM)[k], dt_l = row(Q_DT)[k], ds_i = DD ? row(Q_DS)[k] : dt_l;   // interior values of L3
       double difm = dm_i, difs = ds_i, dift = dt_l, ghat = 0.;
       if (k < kbl) {
         const double hbl = sc[C_HBL], r_hbl = sc[C_RHBL], stable = sc[C_STABLE], bfsfc = sc[C_BFSFC];
@@ -1039,11 +1157,14 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         double a2 = 3. - 2. * sig;
         double a3 = sig - 1.;
         double Gm = a1 + a2 * sc[C_GAT1 + 0] + a3 * sc[C_DAT1 + 0];
-        double Gs = a1 + a2 * sc[C_GAT1 + 1] + a3 * sc[C_DAT1 + 1];
         double Gt = a1 + a2 * sc[C_GAT1 + 2] + a3 * sc[C_DAT1 + 2];
         double b0 = hbl * wm * sig * (1. + sig * Gm);
-        double b1 = hbl * ws * sig * (1. + sig * Gs);
         double b2 = hbl * ws * sig * (1. + sig * Gt);
+        double b1 = b2;   // same operands, same operations unless double diffusion separates difs from dift
+        if (DD) {
+          double Gs = a1 + a2 * sc[C_GAT1 + 1] + a3 * sc[C_DAT1 + 1];
+          b1 = hbl * ws * sig * (1. + sig * Gs);
+        }
         const double ghd = ws * hbl + epsln20;
         double gh = div_fast((1. - stable) * p.cg, ghd, rcp_refine(ghd));
         if (k == kbl - 1 && k <= nz - 1) {
@@ -1053,18 +1174,21 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           double dkmp5 = caseA * dm_i + (1. - caseA) * b0;
           double dstar = (omd * omd) * sc[C_DKM1 + 0] + (delta * delta) * dkmp5;
           b0 = omd * dm_i + delta * dstar;
-          dkmp5 = caseA * ds_i + (1. - caseA) * b1;
-          dstar = (omd * omd) * sc[C_DKM1 + 1] + (delta * delta) * dkmp5;
-          b1 = omd * ds_i + delta * dstar;
+          if (DD) {
+            dkmp5 = caseA * ds_i + (1. - caseA) * b1;
+            dstar = (omd * omd) * sc[C_DKM1 + 1] + (delta * delta) * dkmp5;
+            b1 = omd * ds_i + delta * dstar;
+          }
           dkmp5 = caseA * dt_l + (1. - caseA) * b2;
           dstar = (omd * omd) * sc[C_DKM1 + 2] + (delta * delta) * dkmp5;
           b2 = omd * dt_l + delta * dstar;
+          if (!DD) b1 = b2;
           gh = (1. - caseA) * gh;
         }
         difm = b0; difs = b1; dift = b2; ghat = gh;
       }
       if (k >= nz) { difm = 0.0001; difs = 0.00001; dift = 0.00001; ghat = 0.0; }
-      row(Q_DM)[k] = difm; row(Q_DS)[k] = difs; row(Q_DT)[k] = dift; row(Q_YV)[k] = ghat;
+      row(Q_DM)[k] = difm; if (DD) row(Q_DS)[k] = difs; row(Q_DT)[k] = dift; row(Q_YV)[k] = ghat;
       if (p.diag && si[I_MAYBE]) {   // the sweeps reuse these rows: what the last vmix leaves behind goes out now
         const size_t od = ro + k;
         p.difm[od] = difm; p.difs[od] = difs; p.dift[od] = dift;
@@ -1079,7 +1203,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     if (do_ocnint) {
       FOR_ITEMS
         if (!act) continue;
-        const strided<ROWS> aDt = row(Q_DT), aDs = row(Q_DS), aGh = row(Q_YV);
+        const strided<ROWS> aDt = row(Q_DT), aDs = row(DD ? (int)Q_DS : (int)Q_DT), aGh = row(Q_YV);
         const double f = sc[C_F];
         const size_t o = ro + (k - 1);
         const double Uo = p.U[o], Vo = p.V[o], To = p.T[o], So = p.S[o];
@@ -1125,10 +1249,14 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(15);
 
     // ---- M4: Thomas factorise + sweep for U, T, S (solvers.F90:14-44, 112-161)
+#ifndef T_NO_M4
     if (wv == mgr && do_ocnint) {
-      ps_thomas_uts(W, slots, SS, ROWS, K_STRIDE, nz, cst + K_T0, cst + K_T1, sirec + I_ACT, I_COUNT, sirec + I_BAD,
-                    I_COUNT, lane);
+      ps_thomas_uts_fwd<XV>(W, slots, SS, K_STRIDE, nz, cst + K_T0, cst + K_T1, sirec + I_ACT, I_COUNT, sirec + I_BAD,
+                            I_COUNT, lane);
+      STAMP(24);
+      ps_thomas_uts_back<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, lane);
     }
+#endif
     STAMP(16);
     __syncthreads();
     STAMP(17);
@@ -1142,6 +1270,11 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         const double dto = p.dto, f = sc[C_F];
         const strided<ROWS> yU = row(Q_YU), yV = row(Q_YV);
         if (actz) {
+          // beside the right-hand side, what the V sweep needs of the momentum factorisation apart from the
+          // recurrence itself: the refined reciprocal of the pivot and q = tri(k,0) difm(k-1) = -cu(k), exactly the
+          // values the U sweep formed, into the two rows the T and S systems are done with
+          row(Q_DS)[k] = rcp_refine(row(Q_BET)[k]);
+          row(Q_DT)[k] = c_t0[k] * row(Q_DM)[k - 1];
           const double un = yU[k];
           double rhsV;
           if (k == 1) rhsV = Vo - dto * (f * .5 * (Uo + un) + div_fast(sc[C_WU02], c_hm[1], c_misc[0]));
@@ -1159,7 +1292,13 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 
     // ---- M5: Thomas sweep for V on the stored momentum factorisation | the next pass's L1 but for V
     if (wv == mgr) {
-      if (do_ocnint) ps_thomas_v(W, slots, SS, ROWS, K_STRIDE, nz, cst + K_T0, sirec + I_ACT, I_COUNT, lane);
+#ifndef T_NO_M5
+      if (do_ocnint) {
+        ps_thomas_v_fwd(W, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane);
+        STAMP(25);
+        ps_thomas_v_back(W, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane);
+      }
+#endif
       G_late();
     } else if (l1_ahead) {   // meanwhile: the next pass's L1, all but V, for the items of slots that go on iterating
       FOR_ITEMS
@@ -1438,6 +1577,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 #ifdef MCKPP_PS_STAMPS
   if (p.dbg && wv == mgr && lane == 0) {
     for (int i = 0; i < 23; ++i) atomicAdd((unsigned long long *)p.dbg + i, tacc[i]);
+    atomicAdd((unsigned long long *)p.dbg + 24, tacc[24]);   // of M4: its forward part
+    atomicAdd((unsigned long long *)p.dbg + 25, tacc[25]);   // of M5: its forward part
     atomicAdd((unsigned long long *)p.dbg + 31, tacc[23]);
   }
 #endif

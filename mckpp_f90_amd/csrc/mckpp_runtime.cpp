@@ -717,10 +717,17 @@ int mckpp_hip_synchronize(mckpp_hip_handle h)
     HIPCHK(hipMemset(h->d_dbg, 0, sizeof t));
     if (t[31]) {
       const char *nm[23] = {"L1", "w", "M1L2", "w", "L3", "w", "M2", "w", "L4", "w", "M3", "w", "L5", "w", "L6", "w",
-                            "M4", "w", "L7", "w", "M5", "w", "finish"};
+                            "M4back", "w", "L7", "w", "M5back", "w", "finish"};
       fprintf(stderr, "[mckpp stamps ps] wave-passes %llu; cycles per wave-pass:", t[31]);
       double tot = 0;
-      for (int i = 0; i < 23; ++i) { fprintf(stderr, " %s=%.0f", nm[i], (double)t[i] / (double)t[31]); tot += (double)t[i]; }
+      for (int i = 0; i < 23; ++i) {
+        if (i == 16 || i == 20) {   // the forward parts of the two sweeps have their own accumulators
+          fprintf(stderr, " %s=%.0f", i == 16 ? "M4fwd" : "M5fwd", (double)t[i == 16 ? 24 : 25] / (double)t[31]);
+          tot += (double)t[i == 16 ? 24 : 25];
+        }
+        fprintf(stderr, " %s=%.0f", nm[i], (double)t[i] / (double)t[31]);
+        tot += (double)t[i];
+      }
       fprintf(stderr, " total=%.0f\n", tot / (double)t[31]);
     }
   }
