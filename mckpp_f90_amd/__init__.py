@@ -10,7 +10,9 @@ import ctypes as _C
 import os as _os
 
 _HERE = _os.path.dirname(_os.path.abspath(__file__))
-LIB_PATH = _os.path.join(_HERE, "libmckpp_hip.so")
+# MCKPP_HIP_LIBRARY names another build of the same library (a profiling or A/B build made by tools/); the
+# default is the in-tree product library
+LIB_PATH = _os.environ.get("MCKPP_HIP_LIBRARY") or _os.path.join(_HERE, "libmckpp_hip.so")
 INCLUDE_DIR = _os.path.join(_os.path.dirname(_HERE), "include")
 
 _lib = None

@@ -92,10 +92,59 @@ __host__ __device__ inline size_t ps_lds_bytes(int L, int W, int xv)
 
 // ---- the manager wave's serial sweeps, one lane per slot (x system) over the slots' level-interleaved rows
 // (element (row a, level i) of slot s at slots[s*SS + i*KS + a]; grid constants with stride CS).
-// One wave issues an instruction every 6-10 cycles whether or not it depends on the one before, so a sweep costs
-// its instruction count: everything that is not on a recurrence is done elsewhere (by all threads, in a level
-// phase), operands are fetched a trip ahead, and the conditions that need other arithmetic are tested once per
-// trip of two levels, after the fact (the trip is then redone from the state it started with).
+// What a sweep costs (tools/ubench/sweeps.hip, lds.hip: one wave, any number of active lanes): 6 cycles per fp64
+// instruction whether or not it depends on the one before, 25 for v_rcp_f64, ~8 per LDS read instruction, ~17 per
+// 8-byte LDS store (34 per ds_write2_b64), 35-50 for a scalar branch on a fresh vector compare - plus the full LDS
+// latency (64-100 cycles) wherever a read is waited for right after it was issued.  So: everything that is not on
+// a recurrence is done elsewhere (by all threads, in a level phase), operands are fetched a trip ahead, a level
+// stores as little as it can, and the conditions that need other arithmetic are tested once per trip of two
+// levels, after the fact (the trip is then redone from the state it started with).  Running the factorisation
+// and the forward solution as two instruction streams on two waves (the solver following the factoriser through
+// a progress word in LDS) was measured and dropped: each stream alone is 220 / 260 cycles per level against 280
+// fused, the pair 305 - both wait on the same LDS stores.
+
+// ---- LDS accesses the compiler does not schedule.  The short recurrences (bulk-Ri scan, back substitution) are
+// bound by the latency of their LDS reads (a trip of four levels is 50 cycles of arithmetic): the operands of the
+// NEXT trip must be in flight while the current one computes.  Written in C++ the compiler's wait-count insertion
+// at the loop header waits for them together with the current ones (measured: slower than no prefetch).  So these
+// loops issue their reads through the helpers below and say themselves when a value is needed: ps_lds_read2
+// starts a read of two doubles at (addr + 8*OFF0, addr + 8*OFF1) bytes; ps_lds_wait<N>(values...) returns once
+// at most N LDS instructions issued after the ones that fetch `values` are still outstanding (LDS returns in
+// order).  The values are tied through the wait statement, so nothing can use them before it.
+typedef double ps_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned ps_lds_addr(const double *p) { return (unsigned)(unsigned long long)p; }   // LDS offset = low half of its flat address
+template <int OFF0, int OFF1>
+__device__ __forceinline__ ps_d2 ps_lds_read2(unsigned addr)
+{
+  ps_d2 v;
+  asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(OFF0), "n"(OFF1) : "memory");
+  return v;
+}
+template <int N> __device__ __forceinline__ void ps_lds_wait(ps_d2 &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+template <int N> __device__ __forceinline__ void ps_lds_wait(ps_d2 &a, ps_d2 &b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+template <int N> __device__ __forceinline__ void ps_lds_wait(ps_d2 &a, ps_d2 &b, ps_d2 &c, ps_d2 &d)
+{
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+// The stores of such a loop go the same way (a compiler-issued LDS store in the loop makes the compiler wait for
+// everything outstanding at the loop header); ps_lds_drain() after the loop: every LDS access issued here has
+// retired (the compiler does not know of them, so nothing else would wait before the next barrier).
+template <int OFF0, int OFF1>
+__device__ __forceinline__ void ps_lds_write2(unsigned addr, double a, double b)
+{
+  asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(addr), "v"(a), "v"(b), "n"(OFF0), "n"(OFF1) : "memory");
+}
+__device__ __forceinline__ void ps_lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// MAX(a, b) as one v_max_f64 where b is never NaN and never -0 (the scan below: b = rb + 1e-16 with rb a previous
+// result, never NaN because a NaN `a` is passed over either way): then it returns what a > b ? a : b returns -
+// compare, two selects - for every a, at a third of the dependent latency.
+__device__ __forceinline__ double ps_max(double a, double b)
+{
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 // bldepth_mod.F90:137: Rib(ku) = MAX(Rib(ku), Rib(ka) + epsln) down the column, four levels per trip, the next
 // trip's values fetched before the current trip's recurrence runs
@@ -107,35 +156,47 @@ __device__ __forceinline__ void ps_scan_rib(int W, int row, double *slots, int S
     double *r = slots + lane * SS + row;
     double rb = 0.0;
     int k = 2;
-#ifdef T_NOPF_SCAN
-    for (; k + 3 <= nz; k += 4) {
-      const double a0 = r[k * KS], a1 = r[(k + 1) * KS], a2 = r[(k + 2) * KS], a3 = r[(k + 3) * KS];
-      rb = dmax2(a0, rb + epsln16); const double b0 = rb;
-      rb = dmax2(a1, rb + epsln16); const double b1 = rb;
-      rb = dmax2(a2, rb + epsln16); const double b2 = rb;
-      rb = dmax2(a3, rb + epsln16);
-      r[k * KS] = b0; r[(k + 1) * KS] = b1; r[(k + 2) * KS] = b2; r[(k + 3) * KS] = rb;
-    }
-#else
-    if (k + 3 <= nz) {
-      double a0 = r[k * KS], a1 = r[(k + 1) * KS], a2 = r[(k + 2) * KS], a3 = r[(k + 3) * KS];
-      for (;;) {
-        const int kn = k + 4;
-        const bool more = kn + 3 <= nz;
-        double n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-        if (more) { n0 = r[kn * KS]; n1 = r[(kn + 1) * KS]; n2 = r[(kn + 2) * KS]; n3 = r[(kn + 3) * KS]; }
-        rb = dmax2(a0, rb + epsln16); const double b0 = rb;
-        rb = dmax2(a1, rb + epsln16); const double b1 = rb;
-        rb = dmax2(a2, rb + epsln16); const double b2 = rb;
-        rb = dmax2(a3, rb + epsln16);
-        r[k * KS] = b0; r[(k + 1) * KS] = b1; r[(k + 2) * KS] = b2; r[(k + 3) * KS] = rb;
-        k = kn;
-        if (!more) break;
-        a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+    if (k + 3 <= nz) {   // a trip: levels k .. k+3; KS = 9, 11 or 15 doubles per level
+      const unsigned step = 4u * (unsigned)KS * 8u;
+      unsigned ad = ps_lds_addr(r + k * KS);
+      auto rd_lo = [&](unsigned a) { return KS == 9 ? ps_lds_read2<0, 9>(a) : KS == 11 ? ps_lds_read2<0, 11>(a) : ps_lds_read2<0, 15>(a); };
+      auto rd_hi = [&](unsigned a) { return KS == 9 ? ps_lds_read2<18, 27>(a) : KS == 11 ? ps_lds_read2<22, 33>(a) : ps_lds_read2<30, 45>(a); };
+      auto body = [&](int kk, const ps_d2 &v01, const ps_d2 &v23) {
+        rb = ps_max(v01.x, rb + epsln16); const double b0 = rb;
+        rb = ps_max(v01.y, rb + epsln16); const double b1 = rb;
+        rb = ps_max(v23.x, rb + epsln16); const double b2 = rb;
+        rb = ps_max(v23.y, rb + epsln16);
+        const unsigned aw = ps_lds_addr(r + kk * KS);
+        if (KS == 9) { ps_lds_write2<0, 9>(aw, b0, b1); ps_lds_write2<18, 27>(aw, b2, rb); }
+        else if (KS == 11) { ps_lds_write2<0, 11>(aw, b0, b1); ps_lds_write2<22, 33>(aw, b2, rb); }
+        else { ps_lds_write2<0, 15>(aw, b0, b1); ps_lds_write2<30, 45>(aw, b2, rb); }
+      };
+      ps_d2 a01 = rd_lo(ad), a23 = rd_hi(ad), b01, b23;
+      while (k + 11 <= nz) {   // this trip, the next, and one more after it
+        b01 = rd_lo(ad + step); b23 = rd_hi(ad + step);
+        ps_lds_wait<2>(a01, a23);
+        body(k, a01, a23);
+        a01 = rd_lo(ad + 2 * step); a23 = rd_hi(ad + 2 * step);
+        ps_lds_wait<2>(b01, b23);
+        body(k + 4, b01, b23);
+        k += 8; ad += 2 * step;
       }
+      if (k + 7 <= nz) {
+        b01 = rd_lo(ad + step); b23 = rd_hi(ad + step);
+        ps_lds_wait<2>(a01, a23);
+        body(k, a01, a23);
+        ps_lds_wait<0>(b01, b23);
+        body(k + 4, b01, b23);
+        k += 8;
+      } else {
+        ps_lds_wait<0>(a01, a23);
+        body(k, a01, a23);
+        k += 4;
+      }
+      ps_lds_drain();
     }
-#endif
-    for (; k <= nz; ++k) {
+#pragma nounroll
+    for (; k <= nz; ++k) {   // the last one to three levels
       rb = dmax2(r[k * KS], rb + epsln16);
       r[k * KS] = rb;
     }
@@ -148,40 +209,49 @@ __device__ __forceinline__ void ps_backsub(double *y, const double *gm, int KS, 
 {
   double yy = y[(nz) * KS];
   int i = nz - 1;
-#ifdef T_NOPF_BACK
-  for (; i >= 4; i -= 4) {
-    const double y0 = y[(i) * KS], y1 = y[(i - 1) * KS], y2 = y[(i - 2) * KS], y3 = y[(i - 3) * KS];
-    const double g0 = gm[(i + 1) * KS], g1 = gm[(i) * KS], g2 = gm[(i - 1) * KS], g3 = gm[(i - 2) * KS];
-    yy = y0 - g0 * yy; const double r0 = yy;
-    yy = y1 - g1 * yy; const double r1 = yy;
-    yy = y2 - g2 * yy; const double r2 = yy;
-    yy = y3 - g3 * yy;
-    y[(i) * KS] = r0; y[(i - 1) * KS] = r1; y[(i - 2) * KS] = r2; y[(i - 3) * KS] = yy;
-  }
-#else
-  if (i >= 4) {
-    double y0 = y[(i) * KS], y1 = y[(i - 1) * KS], y2 = y[(i - 2) * KS], y3 = y[(i - 3) * KS];
-    double g0 = gm[(i + 1) * KS], g1 = gm[(i) * KS], g2 = gm[(i - 1) * KS], g3 = gm[(i - 2) * KS];
-    for (;;) {
-      const int j = i - 4;
-      const bool more = j >= 4;
-      double ny0 = 0, ny1 = 0, ny2 = 0, ny3 = 0, ng0 = 0, ng1 = 0, ng2 = 0, ng3 = 0;
-      if (more) {
-        ny0 = y[(j) * KS]; ny1 = y[(j - 1) * KS]; ny2 = y[(j - 2) * KS]; ny3 = y[(j - 3) * KS];
-        ng0 = gm[(j + 1) * KS]; ng1 = gm[(j) * KS]; ng2 = gm[(j - 1) * KS]; ng3 = gm[(j - 2) * KS];
-      }
-      yy = y0 - g0 * yy; const double r0 = yy;
-      yy = y1 - g1 * yy; const double r1 = yy;
-      yy = y2 - g2 * yy; const double r2 = yy;
-      yy = y3 - g3 * yy;
-      y[(i) * KS] = r0; y[(i - 1) * KS] = r1; y[(i - 2) * KS] = r2; y[(i - 3) * KS] = yy;
-      i = j;
-      if (!more) break;
-      y0 = ny0; y1 = ny1; y2 = ny2; y3 = ny3; g0 = ng0; g1 = ng1; g2 = ng2; g3 = ng3;
+  asm volatile("" : "+v"(yy));   // its wait here, not at the first use inside the loop (where it would wait for the loop's own reads too)
+  if (i >= 4) {   // a trip: levels i, i-1, i-2, i-3; KS = 9, 11 or 15 doubles per level
+    const unsigned step = 4u * (unsigned)KS * 8u;
+    unsigned ay = ps_lds_addr(y + (i - 3) * KS), ag = ps_lds_addr(gm + (i - 2) * KS);
+    auto rd_lo = [&](unsigned a) { return KS == 9 ? ps_lds_read2<0, 9>(a) : KS == 11 ? ps_lds_read2<0, 11>(a) : ps_lds_read2<0, 15>(a); };
+    auto rd_hi = [&](unsigned a) { return KS == 9 ? ps_lds_read2<18, 27>(a) : KS == 11 ? ps_lds_read2<22, 33>(a) : ps_lds_read2<30, 45>(a); };
+    // y10 = (y(i-1), y(i)), y32 = (y(i-3), y(i-2)); g10 = (gam(i), gam(i+1)), g32 = (gam(i-2), gam(i-1))
+    auto body = [&](int ii, const ps_d2 &y32, const ps_d2 &y10, const ps_d2 &g32, const ps_d2 &g10) {
+      yy = y10.y - g10.y * yy; const double r0 = yy;
+      yy = y10.x - g10.x * yy; const double r1 = yy;
+      yy = y32.y - g32.y * yy; const double r2 = yy;
+      yy = y32.x - g32.x * yy;
+      const unsigned aw = ps_lds_addr(y + (ii - 3) * KS);
+      if (KS == 9) { ps_lds_write2<18, 27>(aw, r1, r0); ps_lds_write2<0, 9>(aw, yy, r2); }
+      else if (KS == 11) { ps_lds_write2<22, 33>(aw, r1, r0); ps_lds_write2<0, 11>(aw, yy, r2); }
+      else { ps_lds_write2<30, 45>(aw, r1, r0); ps_lds_write2<0, 15>(aw, yy, r2); }
+    };
+    ps_d2 a0 = rd_lo(ay), a1 = rd_hi(ay), a2 = rd_lo(ag), a3 = rd_hi(ag), b0, b1, b2, b3;
+    while (i >= 12) {   // this trip, the next, and one more after it
+      b0 = rd_lo(ay - step); b1 = rd_hi(ay - step); b2 = rd_lo(ag - step); b3 = rd_hi(ag - step);
+      ps_lds_wait<4>(a0, a1, a2, a3);
+      body(i, a0, a1, a2, a3);
+      a0 = rd_lo(ay - 2 * step); a1 = rd_hi(ay - 2 * step); a2 = rd_lo(ag - 2 * step); a3 = rd_hi(ag - 2 * step);
+      ps_lds_wait<4>(b0, b1, b2, b3);
+      body(i - 4, b0, b1, b2, b3);
+      i -= 8; ay -= 2 * step; ag -= 2 * step;
     }
+    if (i >= 8) {
+      b0 = rd_lo(ay - step); b1 = rd_hi(ay - step); b2 = rd_lo(ag - step); b3 = rd_hi(ag - step);
+      ps_lds_wait<4>(a0, a1, a2, a3);
+      body(i, a0, a1, a2, a3);
+      ps_lds_wait<0>(b0, b1, b2, b3);
+      body(i - 4, b0, b1, b2, b3);
+      i -= 8;
+    } else {
+      ps_lds_wait<0>(a0, a1, a2, a3);
+      body(i, a0, a1, a2, a3);
+      i -= 4;
+    }
+    ps_lds_drain();
   }
-#endif
-  for (; i >= 1; --i) {
+#pragma nounroll
+  for (; i >= 1; --i) {   // the last one to three levels
     yy = y[(i) * KS] - gm[(i + 1) * KS] * yy;
     y[(i) * KS] = yy;
   }
@@ -244,7 +314,6 @@ __device__ __forceinline__ void ps_thomas_uts_fwd(int W, double *slots, int SS, 
         ynum = rhs + q * yprev;
         dm1 = di; pm1 = p;
       };
-#ifdef T_UTS_TRIP2
       bool f_in = tiny_nonzero(ynum);   // of the state the next level starts from
       {   // two levels per trip; each half's operands are fetched while the other half runs
         int i = 2;
@@ -268,32 +337,6 @@ __device__ __forceinline__ void ps_thomas_uts_fwd(int W, double *slots, int SS, 
           else level(i, a_d, a_t0, a_t1, a_r, std::false_type{});
         }
       }
-#else
-      // wave mask of the lanes whose current state (bet, ynum) needs the slow step; formed when the state is, used
-      // a level later
-      unsigned long long rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum));
-      auto step = [&](int i, double di, double t0, double t1, double rhs) {
-        const double s_dm1 = dm1, s_pm1 = pm1, s_bet = bet, s_ynum = ynum;
-        const unsigned long long r_in = rare;
-        level(i, di, t0, t1, rhs, std::false_type{});
-        if (__builtin_expect(r_in != 0ull, 0)) {
-          dm1 = s_dm1; pm1 = s_pm1; bet = s_bet; ynum = s_ynum;
-          level(i, di, t0, t1, rhs, std::true_type{});
-        }
-        rare = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum) || bet == 0.);
-      };
-      {   // two levels per trip; each half's operands are fetched while the other half runs
-        int i = 2;
-        double a_d = d[(2) * KS], a_t0 = c_t0[(2) * CS], a_t1 = c_t1[(2) * CS], a_r = y[(2) * KS];
-        for (; i + 1 <= nz; i += 2) {
-          const double b_d = d[(i + 1) * KS], b_t0 = c_t0[(i + 1) * CS], b_t1 = c_t1[(i + 1) * CS], b_r = y[(i + 1) * KS];
-          step(i, a_d, a_t0, a_t1, a_r);
-          if (i + 2 <= nz) { a_d = d[(i + 2) * KS]; a_t0 = c_t0[(i + 2) * CS]; a_t1 = c_t1[(i + 2) * CS]; a_r = y[(i + 2) * KS]; }
-          step(i + 1, b_d, b_t0, b_t1, b_r);
-        }
-        if (i <= nz) step(i, a_d, a_t0, a_t1, a_r);
-      }
-#endif
       if (bet == 0.) { bad = 1; bet = 1.E-12; }
       y[(nz) * KS] = div_by_refined(ynum, bet, rcp_refine(bet));
       betp[(nz) * KS] = bet;
@@ -1129,9 +1172,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(9);
 
     // ---- M3: hbl, kbl, slot-uniform part of blmix
-#ifndef T_NO_M3
     if (wv == mgr) { M3(); G_early(); }
-#endif
     STAMP(10);
     __syncthreads();
     STAMP(11);
@@ -1249,14 +1290,13 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(15);
 
     // ---- M4: Thomas factorise + sweep for U, T, S (solvers.F90:14-44, 112-161)
-#ifndef T_NO_M4
     if (wv == mgr && do_ocnint) {
       ps_thomas_uts_fwd<XV>(W, slots, SS, K_STRIDE, nz, cst + K_T0, cst + K_T1, sirec + I_ACT, I_COUNT, sirec + I_BAD,
                             I_COUNT, lane);
       STAMP(24);
       ps_thomas_uts_back<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, lane);
+     
     }
-#endif
     STAMP(16);
     __syncthreads();
     STAMP(17);
@@ -1292,14 +1332,13 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 
     // ---- M5: Thomas sweep for V on the stored momentum factorisation | the next pass's L1 but for V
     if (wv == mgr) {
-#ifndef T_NO_M5
       if (do_ocnint) {
         ps_thomas_v_fwd(W, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane);
         STAMP(25);
         ps_thomas_v_back(W, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane);
       }
-#endif
       G_late();
+     
     } else if (l1_ahead) {   // meanwhile: the next pass's L1, all but V, for the items of slots that go on iterating
       FOR_ITEMS
         if (!si[I_L1A]) continue;

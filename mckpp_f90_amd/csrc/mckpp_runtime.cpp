@@ -89,6 +89,11 @@ struct mckpp_hip_ctx {
   int *d_qhead = nullptr;
   unsigned long long *d_dbg = nullptr;
   mckpp_kparams *d_params = nullptr;   // device copy of the kernel parameter block
+  // its source: two pinned host slots used in turn, so a call never waits for its own upload (a slot is reused
+  // only when the copy that read it - two calls back - has completed)
+  mckpp_kparams *h_params = nullptr;
+  hipEvent_t ev_params[2] = {nullptr, nullptr};
+  unsigned params_seq = 0;
   double *d_scratch = nullptr;         // k_column_ps: scratch rows of the iterate, per (workgroup, slot)
   size_t scratch_doubles = 0;
   int num_cu = 256;
@@ -97,6 +102,20 @@ struct mckpp_hip_ctx {
   mckpp_launch_info last_launch{};   // geometry of this context's most recent cooperative launch
   double *d_stage = nullptr;
   size_t stage_elems = 0;
+  // Row transfers (upload / download): two device staging buffers used in turn and a copy stream, so the PCIe
+  // transfer of one field runs while the layout kernel of the next does; the caller's arrays are pinned
+  // (hipHostRegister, once per array) so those transfers are asynchronous and run at the bus rate.
+  hipStream_t copy_stream = nullptr;
+  double *d_xfer[2] = {nullptr, nullptr};
+  size_t xfer_elems[2] = {0, 0};
+  hipEvent_t ev_lay[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};   // layout kernel done / transfer done, per buffer
+  unsigned xfer_seq = 0;
+  std::vector<std::pair<const void *, size_t>> pinned;   // caller arrays this context registered
+  // pinned host images of the column records and of the forcing staging
+  double *h_cs = nullptr, *h_f = nullptr;
+  int *h_ci = nullptr;
+  size_t h_f_elems = 0;
+  hipEvent_t ev_f = nullptr;
   int diag = 1;
   // optional-physics contexts: the relaxation / correction / advection inputs come with upload (or
   // update_ancillaries); load_restart does not carry them, so stepping is refused until they are there
@@ -219,6 +238,14 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   }
   HIPCHK(hipEventCreate(&h->ev0));
   HIPCHK(hipEventCreate(&h->ev1));
+  HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+  for (int b = 0; b < 2; ++b) {
+    HIPCHK(hipEventCreateWithFlags(&h->ev_lay[b], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_copy[b], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_params[b], hipEventDisableTiming));
+  }
+  HIPCHK(hipEventCreateWithFlags(&h->ev_f, hipEventDisableTiming));
+  HIPCHK(hipHostMalloc(&h->h_params, 2 * sizeof(mckpp_kparams), hipHostMallocDefault));
 
   const int ldc = h->ldc, nz = h->nz, n1 = c->nztmax + 1;
   std::vector<double> zm(ldc, 0.0), hm(ldc, 0.0), t0(ldc, 0.0), t1(ldc, 0.0);
@@ -300,7 +327,20 @@ static void free_state(mckpp_hip_ctx *h)
   if (h->d_stage) hipFree(h->d_stage);
   h->d_cs = nullptr; h->d_ci = nullptr; h->d_ipt = nullptr; h->d_stage = nullptr;
   h->stage_elems = 0;
+  for (int b = 0; b < 2; ++b) { if (h->d_xfer[b]) hipFree(h->d_xfer[b]); h->d_xfer[b] = nullptr; h->xfer_elems[b] = 0; }
+  if (h->h_cs) hipHostFree(h->h_cs);
+  if (h->h_ci) hipHostFree(h->h_ci);
+  if (h->h_f) hipHostFree(h->h_f);
+  h->h_cs = nullptr; h->h_ci = nullptr; h->h_f = nullptr; h->h_f_elems = 0;
   h->ncol = 0; h->npts = 0;
+}
+
+// The caller's arrays stay pinned until the context goes (or mckpp_hip_release_host_arrays is called)
+static void unpin_all(mckpp_hip_ctx *h)
+{
+  for (auto &r : h->pinned)
+    if (hipHostUnregister(const_cast<void *>(r.first)) != hipSuccess) (void)hipGetLastError();
+  h->pinned.clear();
 }
 
 int mckpp_hip_finalize(mckpp_hip_handle h)
@@ -308,12 +348,22 @@ int mckpp_hip_finalize(mckpp_hip_handle h)
   if (!h) return 0;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->copy_stream) hipStreamSynchronize(h->copy_stream);
+  unpin_all(h);
   free_state(h);
   hipFree(h->d_zm); hipFree(h->d_hm); hipFree(h->d_tri0); hipFree(h->d_tri1);
   hipFree(h->d_swfrac_tab); hipFree(h->d_swdk_tab); hipFree(h->d_wtab); hipFree(h->d_qhead); hipFree(h->d_params); hipFree(h->d_scratch); hipFree(h->d_dm); hipFree(h->d_hsum);
   if (h->d_dbg) hipFree(h->d_dbg);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
+  for (int b = 0; b < 2; ++b) {
+    if (h->ev_lay[b]) hipEventDestroy(h->ev_lay[b]);
+    if (h->ev_copy[b]) hipEventDestroy(h->ev_copy[b]);
+    if (h->ev_params[b]) hipEventDestroy(h->ev_params[b]);
+  }
+  if (h->ev_f) hipEventDestroy(h->ev_f);
+  if (h->h_params) hipHostFree(h->h_params);
+  if (h->copy_stream) hipStreamDestroy(h->copy_stream);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -332,27 +382,79 @@ static int ensure_stage(mckpp_hip_ctx *h, size_t elems)
   return 0;
 }
 
-// host Fortran slab (npts x nlev, from `src`) -> device rows
-static int up_rows(mckpp_hip_ctx *h, const double *src, int nlev, double *dst, int dst_off)
+// MCKPP_HIP_NO_HOST_REGISTER=1: never pin the caller's arrays (transfers then go through the runtime's own
+// pageable path: correct, several times slower)
+static bool no_host_register()
 {
-  const size_t n = (size_t)h->npts * nlev;
-  if (ensure_stage(h, n)) return -1;
-  HIPCHK(hipMemcpyAsync(h->d_stage, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(mckpp_launch_gather_rows(h->d_stage, h->npts, nlev, 0, h->d_ipt, h->ncol, dst, h->ld, dst_off, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  static const bool v = getenv("MCKPP_HIP_NO_HOST_REGISTER") != nullptr;
+  return v;
+}
+
+// Pin a caller array once (portable: every device's transfers benefit).  Failure is not an error: an array that
+// is already pinned (by another context, or by the caller) or cannot be is simply transferred as it is.
+static void pin_host(mckpp_hip_ctx *h, const void *ptr, size_t bytes)
+{
+  if (!ptr || bytes < ((size_t)1 << 20) || no_host_register()) return;
+  for (auto &r : h->pinned)
+    if (r.first == ptr && r.second >= bytes) return;
+  if (hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterPortable) == hipSuccess) h->pinned.emplace_back(ptr, bytes);
+  else (void)hipGetLastError();
+}
+
+static int ensure_xfer(mckpp_hip_ctx *h, unsigned b, size_t elems)
+{
+  if (elems <= h->xfer_elems[b]) return 0;
+  HIPCHK(hipStreamSynchronize(h->stream));        // nothing in flight may still use the buffer
+  HIPCHK(hipStreamSynchronize(h->copy_stream));
+  if (h->d_xfer[b]) hipFree(h->d_xfer[b]);
+  h->d_xfer[b] = nullptr;
+  h->xfer_elems[b] = 0;
+  HIPCHK(hipMalloc(&h->d_xfer[b], elems * sizeof(double)));
+  h->xfer_elems[b] = elems;
   return 0;
 }
 
-// device rows -> host Fortran slab; entries of non-resident (land) columns keep their host values
-static int down_rows(mckpp_hip_ctx *h, const double *src, int src_off, int nlev, double *dst)
+// host Fortran slab (npts x nlev, from `src`) -> device rows.  Queued: the copy on the copy stream, the layout
+// kernel behind it on the context's stream; the caller waits for the stream before `src` may change.
+static int up_rows(mckpp_hip_ctx *h, const double *src, int nlev, double *dst, int dst_off)
 {
   const size_t n = (size_t)h->npts * nlev;
-  if (ensure_stage(h, n)) return -1;
+  const unsigned b = h->xfer_seq++ & 1u;
+  if (ensure_xfer(h, b, n)) return -1;
+  pin_host(h, src, n * sizeof(double));
+  HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_lay[b], 0));   // the layout kernel that last read this buffer
+  HIPCHK(hipMemcpyAsync(h->d_xfer[b], src, n * sizeof(double), hipMemcpyHostToDevice, h->copy_stream));
+  HIPCHK(hipEventRecord(h->ev_copy[b], h->copy_stream));
+  HIPCHK(hipStreamWaitEvent(h->stream, h->ev_copy[b], 0));
+  HIPCHK(mckpp_launch_gather_rows(h->d_xfer[b], h->npts, nlev, 0, h->d_ipt, h->ncol, dst, h->ld, dst_off, h->stream));
+  HIPCHK(hipEventRecord(h->ev_lay[b], h->stream));
+  return 0;
+}
+
+// device rows -> host Fortran slab; entries of non-resident (land) columns keep their host values.  Queued: the
+// layout kernel on the context's stream, the copy to the host behind it on the copy stream; xfer_finish() before
+// the caller reads `dst`.
+static int down_rows(mckpp_hip_ctx *h, const double *src, int src_ld, int src_off, int nlev, double *dst)
+{
+  const size_t n = (size_t)h->npts * nlev;
+  const unsigned b = h->xfer_seq++ & 1u;
+  if (ensure_xfer(h, b, n)) return -1;
+  pin_host(h, dst, n * sizeof(double));
+  HIPCHK(hipStreamWaitEvent(h->stream, h->ev_copy[b], 0));   // the transfer that last read this buffer
   if (h->ncol < h->npts)
-    HIPCHK(hipMemcpyAsync(h->d_stage, dst, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(mckpp_launch_scatter_rows(src, h->ld, src_off, h->d_ipt, h->ncol, h->d_stage, h->npts, nlev, 0, h->stream));
-  HIPCHK(hipMemcpyAsync(dst, h->d_stage, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_xfer[b], dst, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(mckpp_launch_scatter_rows(src, src_ld, src_off, h->d_ipt, h->ncol, h->d_xfer[b], h->npts, nlev, 0, h->stream));
+  HIPCHK(hipEventRecord(h->ev_lay[b], h->stream));
+  HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_lay[b], 0));
+  HIPCHK(hipMemcpyAsync(dst, h->d_xfer[b], n * sizeof(double), hipMemcpyDeviceToHost, h->copy_stream));
+  HIPCHK(hipEventRecord(h->ev_copy[b], h->copy_stream));
+  return 0;
+}
+
+static int xfer_finish(mckpp_hip_ctx *h)
+{
   HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->copy_stream));
   return 0;
 }
 
@@ -373,6 +475,8 @@ static int alloc_state(mckpp_hip_ctx *h, int64_t npts, int64_t ncol)
   HIPCHK(hipMalloc(&h->d_cs, (size_t)ncol * MCKPP_CS * sizeof(double)));
   HIPCHK(hipMalloc(&h->d_ci, (size_t)ncol * MCKPP_CI * sizeof(int)));
   HIPCHK(hipMalloc(&h->d_ipt, (size_t)ncol * sizeof(int)));
+  HIPCHK(hipHostMalloc(&h->h_cs, (size_t)ncol * MCKPP_CS * sizeof(double), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc(&h->h_ci, (size_t)ncol * MCKPP_CI * sizeof(int), hipHostMallocDefault));
   if (h->ext) {
     for (auto &p : h->d_ext_in) { HIPCHK(hipMalloc(&p, rowbytes)); HIPCHK(hipMemsetAsync(p, 0, rowbytes, h->stream)); }
     for (auto &p : h->d_ext_out) { HIPCHK(hipMalloc(&p, rowbytes)); HIPCHK(hipMemsetAsync(p, 0, rowbytes, h->stream)); }
@@ -523,18 +627,34 @@ int mckpp_hip_upload(mckpp_hip_handle h, const mckpp_state_ptrs_c *s)
   return 0;
 }
 
+static int ensure_host_f(mckpp_hip_ctx *h, size_t elems)
+{
+  if (elems <= h->h_f_elems) return 0;
+  HIPCHK(hipEventSynchronize(h->ev_f));
+  if (h->h_f) hipHostFree(h->h_f);
+  h->h_f = nullptr;
+  h->h_f_elems = 0;
+  HIPCHK(hipHostMalloc(&h->h_f, elems * sizeof(double), hipHostMallocDefault));
+  h->h_f_elems = elems;
+  return 0;
+}
+
 int mckpp_hip_set_forcing(mckpp_hip_handle h, const double *sflux)
 {
   if (!h || !sflux) return fail("mckpp_hip_set_forcing: null argument");
   if (h->ncol == 0) return 0;
   HIPCHK(hipSetDevice(h->device));
-  std::vector<double> f6((size_t)h->ncol * 6);
+  if (ensure_host_f(h, (size_t)h->ncol * 6)) return -1;
+  HIPCHK(hipEventSynchronize(h->ev_f));   // the previous transfer out of the staging array
+  double *f6 = h->h_f;
   const int64_t fl_i = h->npts, fl_5 = h->npts * (int64_t)h->c.nsflxs * 4;
-  for (int64_t c = 0; c < h->ncol; ++c)
-    for (int m = 0; m < 6; ++m) f6[(size_t)c * 6 + m] = sflux[h->ipt[c] + fl_i * m + fl_5];
-  HIPCHK(hipMemcpy2DAsync(h->d_cs + CS_SFLUX1, MCKPP_CS * sizeof(double), f6.data(), 6 * sizeof(double),
+  for (int m = 0; m < 6; ++m) {   // one pass per flux component: each source array is read front to back
+    const double *src = sflux + fl_i * m + fl_5;
+    for (int64_t c = 0; c < h->ncol; ++c) f6[(size_t)c * 6 + m] = src[h->ipt[c]];
+  }
+  HIPCHK(hipMemcpy2DAsync(h->d_cs + CS_SFLUX1, MCKPP_CS * sizeof(double), f6, 6 * sizeof(double),
                           6 * sizeof(double), (size_t)h->ncol, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipEventRecord(h->ev_f, h->stream));   // queued ahead of the next step on the same stream; no host wait
   return 0;
 }
 
@@ -549,15 +669,16 @@ int mckpp_hip_fluxes(mckpp_hip_handle h, int ntime, const double *taux, const do
   if (h->ncol == 0) return 0;
   HIPCHK(hipSetDevice(h->device));
   const double *src[8] = {taux, tauy, swf, lwf, lhf, shf, rain, snow};
-  std::vector<double> f8((size_t)8 * h->ncol);
+  const size_t n8 = (size_t)8 * h->ncol;
+  if (ensure_host_f(h, n8) || ensure_stage(h, n8)) return -1;
+  HIPCHK(hipEventSynchronize(h->ev_f));
   for (int m = 0; m < 8; ++m)
-    for (int64_t c = 0; c < h->ncol; ++c) f8[(size_t)m * h->ncol + c] = src[m][h->ipt[c]];
-  if (ensure_stage(h, f8.size())) return -1;
-  HIPCHK(hipMemcpyAsync(h->d_stage, f8.data(), f8.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    for (int64_t c = 0; c < h->ncol; ++c) h->h_f[(size_t)m * h->ncol + c] = src[m][h->ipt[c]];
+  HIPCHK(hipMemcpyAsync(h->d_stage, h->h_f, n8 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipEventRecord(h->ev_f, h->stream));
   mckpp_kparams p;
   fill_params(h, p, ntime, MCKPP_MODE_STEP);
   HIPCHK(mckpp_launch_fluxes(p, ntime, h->d_stage, l_rest, flsn, el, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 
@@ -634,11 +755,12 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode, const forced_r
     return fail("optional-physics context: the relaxation / correction / advection inputs are not resident "
                 "(after mckpp_hip_load_restart call mckpp_hip_update_ancillaries before stepping)");
   HIPCHK(hipSetDevice(h->device));
-  {   // parameter block (identical for every launch of this call but ntime)
-    mckpp_kparams p0;
-    fill_params(h, p0, ntime, mode);
-    HIPCHK(hipMemcpyAsync(h->d_params, &p0, sizeof p0, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));   // p0 is a stack object
+  {   // parameter block (identical for every launch of this call but ntime), from a pinned slot: no host wait
+    const unsigned slot = h->params_seq++ & 1u;
+    HIPCHK(hipEventSynchronize(h->ev_params[slot]));
+    fill_params(h, h->h_params[slot], ntime, mode);
+    HIPCHK(hipMemcpyAsync(h->d_params, &h->h_params[slot], sizeof(mckpp_kparams), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipEventRecord(h->ev_params[slot], h->stream));
   }
   HIPCHK(hipEventRecord(h->ev0, h->stream));
   for (int i = 0; i < nsteps; ++i) {
@@ -766,115 +888,122 @@ int mckpp_hip_last_kernel_ms(mckpp_hip_handle h, double *ms, int32_t *nlaunch)
   return 0;
 }
 
+// What a download moves, as a list: every row field of `mask` whose host pointer is set - the device rows it
+// comes from (of THIS context), the offset of its first element in them, its number of levels, and where it goes
+// in the caller's arrays.  The list depends on the mask and the pointers only, so the contexts of a multi-device
+// handle produce lists that correspond entry by entry.
+namespace {
+struct row_xfer { const double *dev; int src_off, nlev; double *host; };
+}
+
+static void download_plan(mckpp_hip_ctx *h, const mckpp_state_ptrs_c *s, uint32_t mask, std::vector<row_xfer> &plan)
+{
+  const int nzp1 = h->nzp1, nz = h->nz;
+  const size_t slab = (size_t)h->npts * nzp1;
+  auto add = [&](const double *dev, int off, int nlev, double *host) { plan.push_back({dev, off, nlev, host}); };
+  if ((mask & MCKPP_F_PROFILES)) {
+    if (s->U) { add(h->d_prof[P_U], 0, nzp1, s->U); add(h->d_prof[P_V], 0, nzp1, s->U + slab); }
+    if (s->X) { add(h->d_prof[P_T], 0, nzp1, s->X); add(h->d_prof[P_S], 0, nzp1, s->X + slab); }
+  }
+  if ((mask & MCKPP_F_SAVED)) {
+    if (s->Us) {
+      add(h->d_prof[P_US0], 0, nzp1, s->Us + 0 * slab); add(h->d_prof[P_VS0], 0, nzp1, s->Us + 1 * slab);
+      add(h->d_prof[P_US1], 0, nzp1, s->Us + 2 * slab); add(h->d_prof[P_VS1], 0, nzp1, s->Us + 3 * slab);
+    }
+    if (s->Xs) {
+      add(h->d_prof[P_TS0], 0, nzp1, s->Xs + 0 * slab); add(h->d_prof[P_SS0], 0, nzp1, s->Xs + 1 * slab);
+      add(h->d_prof[P_TS1], 0, nzp1, s->Xs + 2 * slab); add(h->d_prof[P_SS1], 0, nzp1, s->Xs + 3 * slab);
+    }
+  }
+  if ((mask & MCKPP_F_DIAG)) {
+    const int n1 = h->c.nztmax + 1;        // extent of (0:nztmax)
+    const size_t s1 = (size_t)h->npts * n1;
+    if (s->rho) add(h->d_diag[D_RHO], 0, nzp1 + 1, s->rho);
+    if (s->cp) add(h->d_diag[D_CP], 0, nzp1 + 1, s->cp);
+    if (s->buoy) add(h->d_diag[D_BUOY], 1, nzp1, s->buoy);
+    if (s->difm) add(h->d_diag[D_DIFM], 0, nzp1 + 1, s->difm);
+    if (s->difs) add(h->d_diag[D_DIFS], 0, nzp1 + 1, s->difs);
+    if (s->dift) add(h->d_diag[D_DIFT], 0, nzp1 + 1, s->dift);
+    if (s->ghat) add(h->d_diag[D_GHAT], 1, nz, s->ghat);
+    if (s->wU) { add(h->d_diag[D_WU1], 0, nz + 1, s->wU); add(h->d_diag[D_WU2], 0, nz + 1, s->wU + s1); }
+    if (s->wX) {
+      add(h->d_diag[D_WX1], 0, nz + 1, s->wX); add(h->d_diag[D_WX2], 0, nz + 1, s->wX + s1);
+      add(h->d_diag[D_WX3], 0, nz + 1, s->wX + 2 * s1);
+    }
+    if (s->wXNT) add(h->d_diag[D_WXNT1], 0, nz + 1, s->wXNT);
+    if (s->Rig) add(h->d_diag[D_RIG], 1, nz, s->Rig);
+    if (s->Shsq) add(h->d_diag[D_SHSQ], 1, nz, s->Shsq);
+    if (s->dbloc) add(h->d_diag[D_DBLOC], 1, nz, s->dbloc);
+    if (h->d_ext_out[O_TINC]) {
+      if (s->tinc_fcorr) add(h->d_ext_out[O_TINC], 1, nzp1, s->tinc_fcorr);
+      if (s->sinc_fcorr) add(h->d_ext_out[O_SINC], 1, nzp1, s->sinc_fcorr);
+      if (s->ocnTcorr) add(h->d_ext_out[O_OCNTCORR], 1, nzp1, s->ocnTcorr);
+      if (s->scorr) add(h->d_ext_out[O_SCORR], 1, nzp1, s->scorr);
+    }
+  }
+}
+
+// The per-column records of one context -> the caller's (npts) arrays: one transfer of each record array into
+// pinned memory, then a host loop over the context's columns.
+static int download_records(mckpp_hip_ctx *h, mckpp_state_ptrs_c *s, uint32_t mask)
+{
+  const int nzp1 = h->nzp1, nz = h->nz;
+  const int64_t npts = h->npts, ncol = h->ncol;
+  const bool want_tabs = (mask & MCKPP_F_DIAG) && (s->swfrac || s->swdk_opt);
+  if (!(mask & (MCKPP_F_SAVED | MCKPP_F_SCALARS)) && !want_tabs) return 0;
+  if (mask & (MCKPP_F_SAVED | MCKPP_F_SCALARS))
+    HIPCHK(hipMemcpyAsync(h->h_cs, h->d_cs, (size_t)ncol * MCKPP_CS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(h->h_ci, h->d_ci, (size_t)ncol * MCKPP_CI * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const double *cs = h->h_cs;
+  const int *ci = h->h_ci;
+  if (mask & MCKPP_F_SAVED) {
+    for (int64_t c = 0; c < ncol; ++c) {
+      const int64_t i = h->ipt[c];
+      const double *r = &cs[(size_t)c * MCKPP_CS];
+      const int *q = &ci[(size_t)c * MCKPP_CI];
+      if (s->hmixd) { s->hmixd[i] = r[CS_HMIXD0]; s->hmixd[i + npts] = r[CS_HMIXD1]; }
+      if (s->old) s->old[i] = q[CI_OLD];
+      if (s->new_) s->new_[i] = q[CI_NEW];
+    }
+  }
+  if (mask & MCKPP_F_SCALARS) {
+    // one pass per destination array: each is written front to back
+    auto put = [&](double *dst, int slot) {
+      if (!dst) return;
+      for (int64_t c = 0; c < ncol; ++c) dst[h->ipt[c]] = cs[(size_t)c * MCKPP_CS + slot];
+    };
+    put(s->hmix, CS_HMIX); put(s->kmix, CS_KMIX); put(s->Tref, CS_TREF); put(s->uref, CS_UREF); put(s->vref, CS_VREF);
+    put(s->Ssurf, CS_SSURF); put(s->reset_flag, CS_RESET); put(s->dampu_flag, CS_DAMPU); put(s->dampv_flag, CS_DAMPV);
+    put(s->freeze_flag, CS_FREEZE);
+    if (h->ext) put(s->fcorr, CS_FCORR);
+    if (s->l_initflag) for (int64_t c = 0; c < ncol; ++c) s->l_initflag[h->ipt[c]] = ci[(size_t)c * MCKPP_CI + CI_INITFLAG];
+    if (s->sflux)   // sflux(:,1:6,5,0) as assembled by mckpp_hip_fluxes / set_forcing
+      for (int m = 0; m < 6; ++m) put(s->sflux + npts * m + npts * (int64_t)h->c.nsflxs * 4, CS_SFLUX1 + m);
+  }
+  if (want_tabs) {
+    for (int64_t c = 0; c < ncol; ++c) {
+      const int64_t i = h->ipt[c];
+      const int jw = ci[(size_t)c * MCKPP_CI + CI_JERLOV];
+      if (s->swfrac) for (int l = 1; l <= nzp1; ++l) s->swfrac[i + npts * (l - 1)] = h->h_swfrac_tab[(size_t)jw * h->ldc + l];
+      if (s->swdk_opt) for (int k = 0; k <= nz; ++k) s->swdk_opt[i + npts * k] = h->h_swdk_tab[(size_t)jw * h->ldc + k];
+    }
+  }
+  return 0;
+}
+
 int mckpp_hip_download(mckpp_hip_handle h, mckpp_state_ptrs_c *s, uint32_t mask)
 {
   if (!h || !s) return fail("mckpp_hip_download: null argument");
   if (s->npts != h->npts) return fail("mckpp_hip_download: npts=%lld but %lld were uploaded", (long long)s->npts, (long long)h->npts);
   if (h->ncol == 0) return 0;
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  const int nzp1 = h->nzp1, nz = h->nz;
-  const int64_t npts = h->npts, ncol = h->ncol;
-  const size_t slab = (size_t)npts * nzp1;
-  if ((mask & MCKPP_F_PROFILES)) {
-    if (s->U) {
-      if (down_rows(h, h->d_prof[P_U], 0, nzp1, s->U)) return -1;
-      if (down_rows(h, h->d_prof[P_V], 0, nzp1, s->U + slab)) return -1;
-    }
-    if (s->X) {
-      if (down_rows(h, h->d_prof[P_T], 0, nzp1, s->X)) return -1;
-      if (down_rows(h, h->d_prof[P_S], 0, nzp1, s->X + slab)) return -1;
-    }
-  }
-  if ((mask & MCKPP_F_SAVED)) {
-    if (s->Us) {
-      if (down_rows(h, h->d_prof[P_US0], 0, nzp1, s->Us + 0 * slab)) return -1;
-      if (down_rows(h, h->d_prof[P_VS0], 0, nzp1, s->Us + 1 * slab)) return -1;
-      if (down_rows(h, h->d_prof[P_US1], 0, nzp1, s->Us + 2 * slab)) return -1;
-      if (down_rows(h, h->d_prof[P_VS1], 0, nzp1, s->Us + 3 * slab)) return -1;
-    }
-    if (s->Xs) {
-      if (down_rows(h, h->d_prof[P_TS0], 0, nzp1, s->Xs + 0 * slab)) return -1;
-      if (down_rows(h, h->d_prof[P_SS0], 0, nzp1, s->Xs + 1 * slab)) return -1;
-      if (down_rows(h, h->d_prof[P_TS1], 0, nzp1, s->Xs + 2 * slab)) return -1;
-      if (down_rows(h, h->d_prof[P_SS1], 0, nzp1, s->Xs + 3 * slab)) return -1;
-    }
-  }
-  if (mask & (MCKPP_F_SAVED | MCKPP_F_SCALARS)) {
-    std::vector<double> cs((size_t)ncol * MCKPP_CS);
-    std::vector<int> ci((size_t)ncol * MCKPP_CI);
-    HIPCHK(hipMemcpy(cs.data(), h->d_cs, cs.size() * sizeof(double), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ci.data(), h->d_ci, ci.size() * sizeof(int), hipMemcpyDeviceToHost));
-    for (int64_t c = 0; c < ncol; ++c) {
-      const int64_t i = h->ipt[c];
-      const double *r = &cs[(size_t)c * MCKPP_CS];
-      const int *q = &ci[(size_t)c * MCKPP_CI];
-      if (mask & MCKPP_F_SAVED) {
-        if (s->hmixd) { s->hmixd[i] = r[CS_HMIXD0]; s->hmixd[i + npts] = r[CS_HMIXD1]; }
-        if (s->old) s->old[i] = q[CI_OLD];
-        if (s->new_) s->new_[i] = q[CI_NEW];
-      }
-      if (mask & MCKPP_F_SCALARS) {
-        if (s->hmix) s->hmix[i] = r[CS_HMIX];
-        if (s->kmix) s->kmix[i] = r[CS_KMIX];
-        if (s->Tref) s->Tref[i] = r[CS_TREF];
-        if (s->uref) s->uref[i] = r[CS_UREF];
-        if (s->vref) s->vref[i] = r[CS_VREF];
-        if (s->Ssurf) s->Ssurf[i] = r[CS_SSURF];
-        if (s->reset_flag) s->reset_flag[i] = r[CS_RESET];
-        if (s->dampu_flag) s->dampu_flag[i] = r[CS_DAMPU];
-        if (s->dampv_flag) s->dampv_flag[i] = r[CS_DAMPV];
-        if (s->freeze_flag) s->freeze_flag[i] = r[CS_FREEZE];
-        if (s->l_initflag) s->l_initflag[i] = q[CI_INITFLAG];
-        if (s->fcorr && h->ext) s->fcorr[i] = r[CS_FCORR];
-        if (s->sflux)   // sflux(:,1:6,5,0) as assembled by mckpp_hip_fluxes / set_forcing
-          for (int m = 0; m < 6; ++m) s->sflux[i + npts * m + npts * (int64_t)h->c.nsflxs * 4] = r[CS_SFLUX1 + m];
-      }
-    }
-  }
-  if ((mask & MCKPP_F_DIAG)) {
-    const int n1 = h->c.nztmax + 1;        // extent of (0:nztmax)
-    const int n2 = h->c.nztmax + 2;        // extent of (0:nzp1tmax)
-    const size_t s1 = (size_t)npts * n1;
-    if (s->rho && down_rows(h, h->d_diag[D_RHO], 0, nzp1 + 1, s->rho)) return -1;
-    if (s->cp && down_rows(h, h->d_diag[D_CP], 0, nzp1 + 1, s->cp)) return -1;
-    (void)n2;
-    if (s->buoy && down_rows(h, h->d_diag[D_BUOY], 1, nzp1, s->buoy)) return -1;
-    if (s->difm && down_rows(h, h->d_diag[D_DIFM], 0, nzp1 + 1, s->difm)) return -1;
-    if (s->difs && down_rows(h, h->d_diag[D_DIFS], 0, nzp1 + 1, s->difs)) return -1;
-    if (s->dift && down_rows(h, h->d_diag[D_DIFT], 0, nzp1 + 1, s->dift)) return -1;
-    if (s->ghat && down_rows(h, h->d_diag[D_GHAT], 1, nz, s->ghat)) return -1;
-    if (s->wU) {
-      if (down_rows(h, h->d_diag[D_WU1], 0, nz + 1, s->wU)) return -1;
-      if (down_rows(h, h->d_diag[D_WU2], 0, nz + 1, s->wU + s1)) return -1;
-    }
-    if (s->wX) {
-      if (down_rows(h, h->d_diag[D_WX1], 0, nz + 1, s->wX)) return -1;
-      if (down_rows(h, h->d_diag[D_WX2], 0, nz + 1, s->wX + s1)) return -1;
-      if (down_rows(h, h->d_diag[D_WX3], 0, nz + 1, s->wX + 2 * s1)) return -1;
-    }
-    if (s->wXNT && down_rows(h, h->d_diag[D_WXNT1], 0, nz + 1, s->wXNT)) return -1;
-    if (s->Rig && down_rows(h, h->d_diag[D_RIG], 1, nz, s->Rig)) return -1;
-    if (s->Shsq && down_rows(h, h->d_diag[D_SHSQ], 1, nz, s->Shsq)) return -1;
-    if (s->dbloc && down_rows(h, h->d_diag[D_DBLOC], 1, nz, s->dbloc)) return -1;
-    if (h->d_ext_out[O_TINC]) {
-      if (s->tinc_fcorr && down_rows(h, h->d_ext_out[O_TINC], 1, nzp1, s->tinc_fcorr)) return -1;
-      if (s->sinc_fcorr && down_rows(h, h->d_ext_out[O_SINC], 1, nzp1, s->sinc_fcorr)) return -1;
-      if (s->ocnTcorr && down_rows(h, h->d_ext_out[O_OCNTCORR], 1, nzp1, s->ocnTcorr)) return -1;
-      if (s->scorr && down_rows(h, h->d_ext_out[O_SCORR], 1, nzp1, s->scorr)) return -1;
-    }
-    if (s->swfrac || s->swdk_opt) {
-      std::vector<int> ci((size_t)ncol * MCKPP_CI);
-      HIPCHK(hipMemcpy(ci.data(), h->d_ci, ci.size() * sizeof(int), hipMemcpyDeviceToHost));
-      for (int64_t c = 0; c < ncol; ++c) {
-        const int64_t i = h->ipt[c];
-        const int jw = ci[(size_t)c * MCKPP_CI + CI_JERLOV];
-        if (s->swfrac) for (int l = 1; l <= nzp1; ++l) s->swfrac[i + npts * (l - 1)] = h->h_swfrac_tab[(size_t)jw * h->ldc + l];
-        if (s->swdk_opt) for (int k = 0; k <= nz; ++k) s->swdk_opt[i + npts * k] = h->h_swdk_tab[(size_t)jw * h->ldc + k];
-      }
-    }
-  }
-  return 0;
+  std::vector<row_xfer> plan;
+  download_plan(h, s, mask, plan);
+  for (const row_xfer &x : plan)
+    if (down_rows(h, x.dev, h->ld, x.src_off, x.nlev, x.host)) return -1;
+  if (download_records(h, s, mask)) return -1;   // (waits for the context's stream: the last step has finished)
+  return xfer_finish(h);
 }
 
 // ---------------------------------------------------------------------------
@@ -1093,18 +1222,22 @@ int mckpp_hip_window_accumulate(mckpp_hip_handle h)
   return 0;
 }
 
-int mckpp_hip_window_fetch(mckpp_hip_handle h, int field, int op, double *out)
+// The reduced (or sampled) field of this context's columns, compacted, left in device memory: `src` rows of
+// `ld_out` doubles, `nlev` of them meaningful.  (The mean is formed into the context's staging buffer.)
+static int window_prepare(mckpp_hip_ctx *h, int field, int op, const double **src_out, int *ld_out_, int *nlev_)
 {
-  if (!h || !out) return fail("mckpp_hip_window_fetch: null argument");
   if (op < 0 || op > 3) return fail("mckpp_hip_window_fetch: op %d (0 mean, 1 min, 2 max, 3 instant)", op);
   out_desc d;
   if (out_field(h, field, d)) return -1;
+  const int ld_out = d.nlev == 1 ? 1 : h->ld;
+  *ld_out_ = ld_out;
+  *nlev_ = d.nlev;
+  *src_out = nullptr;
   if (h->ncol == 0) return 0;
   HIPCHK(hipSetDevice(h->device));
-  const int ld_out = d.nlev == 1 ? 1 : h->ld;
-  const size_t n = (size_t)h->ncol * ld_out, n3d = (size_t)h->npts * d.nlev;
-  if (ensure_stage(h, n3d + n)) return -1;
-  double *tmp = h->d_stage + n3d;   // behind the region the row scatter stages into
+  const size_t n = (size_t)h->ncol * ld_out;
+  if (ensure_stage(h, n)) return -1;
+  double *tmp = h->d_stage;
   const double *src = nullptr;
   if (op == 3) {   // the field as it stands (XIOS operation "instant" at the output step)
     HIPCHK(mckpp_launch_out_sample(d.src, d.ld, d.off, h->d_cs, d.add_sref, h->ncol, d.nlev, ld_out, nullptr, nullptr,
@@ -1121,11 +1254,19 @@ int mckpp_hip_window_fetch(mckpp_hip_handle h, int field, int op, double *out)
       src = tmp;
     }
   }
-  if (h->ncol < h->npts) HIPCHK(hipMemcpyAsync(h->d_stage, out, n3d * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(mckpp_launch_scatter_rows(src, ld_out, 0, h->d_ipt, h->ncol, h->d_stage, h->npts, d.nlev, 0, h->stream));
-  HIPCHK(hipMemcpyAsync(out, h->d_stage, n3d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  *src_out = src;
   return 0;
+}
+
+int mckpp_hip_window_fetch(mckpp_hip_handle h, int field, int op, double *out)
+{
+  if (!h || !out) return fail("mckpp_hip_window_fetch: null argument");
+  const double *src = nullptr;
+  int ld_out = 0, nlev = 0;
+  if (window_prepare(h, field, op, &src, &ld_out, &nlev)) return -1;
+  if (h->ncol == 0) return 0;
+  if (down_rows(h, src, ld_out, 0, nlev, out)) return -1;
+  return xfer_finish(h);
 }
 
 int mckpp_hip_status(mckpp_hip_handle h, int32_t *per_col, int64_t *n_flagged, int32_t *npasses)

@@ -1,0 +1,11 @@
+# A/B of library builds on one box: .ab/lib<name>.so (tools/r03_build_variants.sh) are loaded through
+# MCKPP_HIP_LIBRARY, the product library is not touched.  LIBS="A B", CFGS="<levels> ...", ROUNDS (default 2),
+# STEPS (default 20), BENCH_ARGS (e.g. "--grid stretched --dto 1200 --land 0.35").
+cd $GRAFT_REPO_ROOT
+for r in $(seq 1 ${ROUNDS:-2}); do
+  for v in ${LIBS:-A B}; do
+    for nz in ${CFGS:-60}; do
+      MCKPP_HIP_LIBRARY=$PWD/.ab/lib$v.so python bench.py --no-cpu-baseline --no-extras --steps ${STEPS:-20} --warmup 3 --nz $nz $BENCH_ARGS 2>/dev/null | sed -e "s/.*\"value\": \([0-9.e+]*\).*\"ms_per_step\": \([0-9.]*\).*/$v nz=$nz rate \1 column-steps\/s, \2 ms per step/"
+    done
+  done
+done

@@ -51,6 +51,32 @@ __global__ void k(double *out, unsigned long long *cyc, double a, double b, int 
       x = __builtin_amdgcn_div_fixup(res, x, y) + z;
     }
   }
+  else if (KIND == 9) {   // back-substitution chain with every operand in its own VGPR pair: x = a_i - g_i * x
+    double a0 = lds[lane], a1 = lds[lane + 64], a2 = lds[lane + 128], a3 = lds[lane + 192];
+    double g0 = lds[lane + 256] * 1e-3, g1 = lds[lane + 320] * 1e-3, g2 = lds[lane + 384] * 1e-3, g3 = lds[lane + 448] * 1e-3;
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3));
+    t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 4
+    for (int i = 0; i < N / 8; ++i) {
+      x = a0 - g0 * x; x = a1 - g1 * x; x = a2 - g2 * x; x = a3 - g3 * x;
+    }
+  } else if (KIND == 10) {   // the same chain, results also stored to LDS (one ds_write_b64 per level)
+    double a0 = lds[lane], a1 = lds[lane + 64], a2 = lds[lane + 128], a3 = lds[lane + 192];
+    double g0 = lds[lane + 256] * 1e-3, g1 = lds[lane + 320] * 1e-3, g2 = lds[lane + 384] * 1e-3, g3 = lds[lane + 448] * 1e-3;
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3));
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < N / 8; ++i) {
+      x = a0 - g0 * x; lds[1024 + lane] = x; x = a1 - g1 * x; lds[1100 + lane] = x; x = a2 - g2 * x; lds[1200 + lane] = x; x = a3 - g3 * x; lds[1300 + lane] = x;
+    }
+  } else if (KIND == 11) {   // the same chain, operands re-read from LDS every trip (read latency exposed once per 4 levels)
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < N / 8; ++i) {
+      const int o = (i & 7) * 64;
+      double a0 = lds[lane + o], a1 = lds[lane + 64 + o], a2 = lds[lane + 128 + o], a3 = lds[lane + 192 + o];
+      double g0 = lds[lane + 2048 + o], g1 = lds[lane + 2112 + o], g2 = lds[lane + 2176 + o], g3 = lds[lane + 2240 + o];
+      x = a0 - g0 * x; x = a1 - g1 * x; x = a2 - g2 * x; x = a3 - g3 * x;
+    }
+  }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if (lane == 0) cyc[0] = t1 - t0;
   out[lane] = x;
@@ -76,6 +102,9 @@ int main()
     run<6>("fma + frexp/cmp/ballot/scalar branch (per iteration)", N, nact, d, c);
     run<7>("LDS write + dependent LDS read + add (per iteration)", N, nact, d, c);
     run<8>("rcp_refine + div_fast + add, dependent (per iteration)", N / 8, nact, d, c);
+    run<9>("x = a_i - g_i*x, all operands VGPRs (per level)", N / 2, nact, d, c);
+    run<10>("  + one ds_write_b64 per level (per level)", N / 2, nact, d, c);
+    run<11>("  operands from LDS each trip of 4, no prefetch (per level)", N / 2, nact, d, c);
   }
   // clock calibration: s_memtime ticks per microsecond
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
