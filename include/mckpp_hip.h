@@ -218,8 +218,17 @@ int mckpp_hip_vmix_only(mckpp_hip_handle h, int ntime);
 int mckpp_hip_synchronize(mckpp_hip_handle h);
 
 /* device -> 3D: scatter half of mckpp_fields_1dto3d
- * (src/mckpp_types_transfer.F90:199-327) for the fields selected. */
+ * (src/mckpp_types_transfer.F90:199-327) for the fields selected.  The row
+ * fields are re-laid on the device into the Fortran order and cross PCIe once
+ * each, the transfer of one field running under the layout kernel of the next;
+ * the per-column records come as one array.  The arrays `s` points to (and
+ * those of mckpp_hip_upload, _update_ancillaries, _window_fetch) are pinned on
+ * first use (hipHostRegister) so the transfers run at the bus rate; they stay
+ * pinned until the context is finalised - call mckpp_hip_release_host_arrays
+ * before freeing them earlier.  MCKPP_HIP_NO_HOST_REGISTER=1 in the environment
+ * switches the pinning off. */
 int mckpp_hip_download(mckpp_hip_handle h, mckpp_state_ptrs_c *s, uint32_t field_mask);
+int mckpp_hip_release_host_arrays(mckpp_hip_handle h);
 
 /* Restart set (reference: XIOS restart context, src/mckpp_xios_io.F90:368-387
  * write list, :436-465 read path, cadence src/mckpp_xios_control.F90:61-83):
@@ -338,11 +347,33 @@ int mckpp_hip_multi_fluxes(mckpp_hip_multi_handle m, int ntime, const double *ta
 int mckpp_hip_multi_init_ocean(mckpp_hip_multi_handle m, int ntime);
 int mckpp_hip_multi_step(mckpp_hip_multi_handle m, int ntime, int nsteps);
 int mckpp_hip_multi_synchronize(mckpp_hip_multi_handle m);
+/* mckpp_hip_download over all shards (scatter half of src/mckpp_types_transfer.F90:199-327): every row
+ * field goes through the gather (shards -> shard 0 -> host: one PCIe transfer per field whatever the number of
+ * devices), the per-column records of each shard come to the host on their own. */
 int mckpp_hip_multi_download(mckpp_hip_multi_handle m, mckpp_state_ptrs_c *s, uint32_t field_mask);
+int mckpp_hip_multi_release_host_arrays(mckpp_hip_multi_handle m);
 int mckpp_hip_multi_status(mckpp_hip_multi_handle m, int32_t *per_col, int64_t *n_flagged, int32_t *npasses);
 int64_t mckpp_hip_multi_ncolumns(mckpp_hip_multi_handle m);
-/* field: 0 U, 1 V, 2 T, 3 S -> out(npts,nzp1); 4 hmix -> out(npts); root: shard index that collects. */
+/* field: 0 U, 1 V, 2 T, 3 S -> out(npts,nzp1); 4 hmix -> out(npts); root: shard index that collects.  All
+ * shards' peer copies are in flight at once (one stream per shard on the root device). */
 int mckpp_hip_multi_gather(mckpp_hip_multi_handle m, int32_t field, int32_t root, double *out);
+/* The reference's forced time loop (src/mckpp_ocean_model_3D.F90:38-58) over all shards: every shard keeps its
+ * columns of the flux records (mckpp_hip_set_flux_series) and runs mckpp_hip_run_forced on its own stream;
+ * returns once all shards are launched. */
+int mckpp_hip_multi_set_flux_series(mckpp_hip_multi_handle m, int rec0, int nrec, const double *fields);
+int mckpp_hip_multi_run_forced(mckpp_hip_multi_handle m, int nt_first, int nsteps, int ndtocn, int l_rest,
+                               double flsn, double el);
+/* Output windows (src/mckpp_xios_io.F90:74-210, run/iodef.xml:88-157) over all shards: each shard reduces
+ * its own columns, window_fetch gathers the reduced rows like any other field. */
+int mckpp_hip_multi_window_select(mckpp_hip_multi_handle m, const int32_t *fields, int32_t nfields);
+int mckpp_hip_multi_window_reset(mckpp_hip_multi_handle m);
+int mckpp_hip_multi_window_accumulate(mckpp_hip_multi_handle m);
+int mckpp_hip_multi_window_fetch(mckpp_hip_multi_handle m, int field, int op, double *out);
+/* Restart set (src/mckpp_xios_io.F90:368-465) of all shards: one file per shard, <path>.<shard>of<ndev>.
+ * load needs the state uploaded first (it gives the shards their column maps) and refuses files written for
+ * another number of shards or another land mask, before anything resident is replaced. */
+int mckpp_hip_multi_save_restart(mckpp_hip_multi_handle m, const char *path);
+int mckpp_hip_multi_load_restart(mckpp_hip_multi_handle m, const char *path);
 
 #ifdef __cplusplus
 }

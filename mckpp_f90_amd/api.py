@@ -146,6 +146,19 @@ def _bind(lib):
     lib.mckpp_hip_multi_ncolumns.argtypes = [C.c_void_p]
     lib.mckpp_hip_multi_ncolumns.restype = C.c_int64
     lib.mckpp_hip_multi_gather.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp]
+    lib.mckpp_hip_release_host_arrays.argtypes = [C.c_void_p]
+    lib.mckpp_hip_multi_release_host_arrays.argtypes = [C.c_void_p]
+    lib.mckpp_hip_multi_set_flux_series.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
+    lib.mckpp_hip_multi_run_forced.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
+    lib.mckpp_hip_multi_window_select.argtypes = [C.c_void_p, _ip, C.c_int32]
+    lib.mckpp_hip_multi_window_reset.argtypes = [C.c_void_p]
+    lib.mckpp_hip_multi_window_accumulate.argtypes = [C.c_void_p]
+    lib.mckpp_hip_multi_window_fetch.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
+    lib.mckpp_hip_multi_save_restart.argtypes = [C.c_void_p, C.c_char_p]
+    lib.mckpp_hip_multi_load_restart.argtypes = [C.c_void_p, C.c_char_p]
+    lib.mckpp_hip_multi_update_ancillaries.argtypes = [C.c_void_p, C.POINTER(_StateC)]
+    lib.mckpp_hip_multi_bottomtemp.argtypes = [C.c_void_p, _dp]
+    lib.mckpp_hip_multi_fluxes.argtypes = [C.c_void_p, C.c_int] + [_dp] * 8 + [C.c_int, C.c_double, C.c_double]
     lib._mckpp_bound = True
     return lib
 
@@ -366,6 +379,10 @@ class MckppHip:
     def set_diagnostics(self, on):
         _chk(_lib().mckpp_hip_set_diagnostics(self._h, int(on)))
 
+    def release_host_arrays(self):
+        """Un-pin the caller's arrays this context registered (before they are freed while the context lives)."""
+        _chk(_lib().mckpp_hip_release_host_arrays(self._h))
+
     def init_ocean(self, ntime=0):
         _chk(_lib().mckpp_hip_init_ocean(self._h, int(ntime)))
 
@@ -490,6 +507,43 @@ class MckppHipMulti:
         """field 0 U, 1 V, 2 T, 3 S -> out(npts, nzp1) Fortran order; 4 hmix -> out(npts)."""
         assert out.flags["F_CONTIGUOUS"] and out.dtype == np.float64
         _chk(_lib().mckpp_hip_multi_gather(self._h, int(field), int(root), out.ctypes.data_as(_dp)))
+
+    def set_diagnostics(self, on):
+        _chk(_lib().mckpp_hip_multi_set_diagnostics(self._h, int(on)))
+
+    def set_flux_series(self, rec0, fields):
+        """fields[nrec][8][npts] (taux,tauy,swf,lwf,lhf,shf,rain,snow); record 0 is flux update rec0."""
+        f = np.ascontiguousarray(fields, dtype=np.float64)
+        assert f.ndim == 3 and f.shape[1] == 8 and f.shape[2] == self._npts
+        _chk(_lib().mckpp_hip_multi_set_flux_series(self._h, int(rec0), f.shape[0], f.ctypes.data_as(_dp)))
+
+    def run_forced(self, nt_first, nsteps, ndtocn, l_rest=0, flsn=334000.0, el=2.5e6):
+        _chk(_lib().mckpp_hip_multi_run_forced(self._h, int(nt_first), int(nsteps), int(ndtocn), int(l_rest),
+                                               float(flsn), float(el)))
+
+    def window_select(self, fields):
+        f = np.ascontiguousarray(fields, dtype=np.int32)
+        _chk(_lib().mckpp_hip_multi_window_select(self._h, f.ctypes.data_as(_ip), len(f)))
+
+    def window_reset(self):
+        _chk(_lib().mckpp_hip_multi_window_reset(self._h))
+
+    def window_accumulate(self):
+        _chk(_lib().mckpp_hip_multi_window_accumulate(self._h))
+
+    def window_fetch(self, field, op, out):
+        assert out.flags["F_CONTIGUOUS"] and out.dtype == np.float64
+        _chk(_lib().mckpp_hip_multi_window_fetch(self._h, int(field), int(op), out.ctypes.data_as(_dp)))
+        return out
+
+    def save_restart(self, path):
+        _chk(_lib().mckpp_hip_multi_save_restart(self._h, str(path).encode()))
+
+    def load_restart(self, path):
+        _chk(_lib().mckpp_hip_multi_load_restart(self._h, str(path).encode()))
+
+    def release_host_arrays(self):
+        _chk(_lib().mckpp_hip_multi_release_host_arrays(self._h))
 
 
 def host_shard_mask(run_physics, ndev, dev):

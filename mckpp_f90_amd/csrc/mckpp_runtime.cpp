@@ -703,6 +703,16 @@ int mckpp_hip_bottomtemp(mckpp_hip_handle h, const double *bottom_temp)
   return 0;
 }
 
+// the caller's arrays pinned on behalf of this context go back to pageable memory (before the caller frees them)
+int mckpp_hip_release_host_arrays(mckpp_hip_handle h)
+{
+  if (!h) return fail("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (xfer_finish(h)) return -1;
+  unpin_all(h);
+  return 0;
+}
+
 int mckpp_hip_set_diagnostics(mckpp_hip_handle h, int on)
 {
   if (!h) return fail("null handle");
@@ -1361,11 +1371,18 @@ struct mckpp_hip_multi {
   std::vector<mckpp_hip_ctx *> ctx;
   int64_t npts = 0;
   std::vector<std::vector<int32_t>> mask;   // run_physics of each shard
-  // root-side buffers of the gather (owned by the root device of the last gather)
+  // root-side resources of the gather (owned by the root device of the last gather): the 3-D image, the staging
+  // area the shards' rows arrive in, every shard's column map, one stream per shard and the events that order
+  // a shard's copy behind its owner's stream and the final transfer behind all shards
   int root = -1;
   double *d_out = nullptr, *d_stage = nullptr;
   int *d_gipt = nullptr;
   size_t out_elems = 0, stage_elems = 0, gipt_elems = 0;
+  bool gipt_valid = false;                  // d_gipt holds the maps of the current upload
+  std::vector<hipStream_t> gstream;         // [ndev], on the root device
+  std::vector<hipEvent_t> ev_owner;         // [ndev], each on its shard's device
+  std::vector<hipEvent_t> ev_done;          // [ndev], on the root device
+  hipEvent_t ev_init = nullptr, ev_gcopy = nullptr;   // on the root device: 3-D image ready for the shards / delivered to the host
 };
 
 // run_physics mask of shard `dev` of `ndev`: the j-th ocean point (in ipt order) goes to shard j mod ndev
@@ -1379,6 +1396,27 @@ int64_t mckpp_host_shard_mask(int64_t npts, const int32_t *run_physics, int32_t 
     if (ocean) { mine += mask_out[i]; ++j; }
   }
   return mine;
+}
+
+int mckpp_hip_multi_finalize(mckpp_hip_multi_handle m);
+
+// the root-side buffers, streams and events go with the root device they were created on
+static void multi_release_root(mckpp_hip_multi *m)
+{
+  if (m->root < 0) return;
+  hipSetDevice(m->ctx[m->root]->device);
+  for (auto &st : m->gstream) if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+  for (auto &e : m->ev_done) if (e) hipEventDestroy(e);
+  if (m->ev_init) hipEventDestroy(m->ev_init);
+  if (m->ev_gcopy) hipEventDestroy(m->ev_gcopy);
+  m->gstream.clear(); m->ev_done.clear(); m->ev_init = nullptr; m->ev_gcopy = nullptr;
+  if (m->d_out) hipFree(m->d_out);
+  if (m->d_stage) hipFree(m->d_stage);
+  if (m->d_gipt) hipFree(m->d_gipt);
+  m->d_out = m->d_stage = nullptr; m->d_gipt = nullptr;
+  m->out_elems = m->stage_elems = m->gipt_elems = 0;
+  m->gipt_valid = false;
+  m->root = -1;
 }
 
 int mckpp_hip_multi_init(const mckpp_const_c *c, int32_t ndev, const int32_t *devices, mckpp_hip_multi_handle *out)
@@ -1395,6 +1433,14 @@ int mckpp_hip_multi_init(const mckpp_const_c *c, int32_t ndev, const int32_t *de
     m->ctx.push_back(h);
   }
   m->mask.resize(ndev);
+  m->ev_owner.assign(ndev, nullptr);
+  for (int d = 0; d < ndev; ++d) {
+    if (hipSetDevice(m->ctx[d]->device) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_owner[d], hipEventDisableTiming) != hipSuccess) {
+      mckpp_hip_multi_finalize(m);
+      return fail("mckpp_hip_multi_init: cannot create the events of shard %d", d);
+    }
+  }
   *out = m;
   return 0;
 }
@@ -1402,12 +1448,9 @@ int mckpp_hip_multi_init(const mckpp_const_c *c, int32_t ndev, const int32_t *de
 int mckpp_hip_multi_finalize(mckpp_hip_multi_handle m)
 {
   if (!m) return 0;
-  if (m->root >= 0) {
-    hipSetDevice(m->ctx[m->root]->device);
-    if (m->d_out) hipFree(m->d_out);
-    if (m->d_stage) hipFree(m->d_stage);
-    if (m->d_gipt) hipFree(m->d_gipt);
-  }
+  multi_release_root(m);
+  for (size_t d = 0; d < m->ev_owner.size(); ++d)
+    if (m->ev_owner[d]) { hipSetDevice(m->ctx[d]->device); hipEventDestroy(m->ev_owner[d]); }
   for (auto *x : m->ctx) mckpp_hip_finalize(x);
   delete m;
   return 0;
@@ -1433,6 +1476,7 @@ int mckpp_hip_multi_upload(mckpp_hip_multi_handle m, const mckpp_state_ptrs_c *s
     sd.run_physics = m->mask[d].data();
     if (mckpp_hip_upload(m->ctx[d], &sd) != 0) return -1;
   }
+  m->gipt_valid = false;   // the root's copy of the column maps is of the previous upload
   return 0;
 }
 
@@ -1457,9 +1501,6 @@ int mckpp_hip_multi_fluxes(mckpp_hip_multi_handle m, int ntime, const double *ta
 {
   MULTI_EACH(mckpp_hip_fluxes(x, ntime, taux, tauy, swf, lwf, lhf, shf, rain, snow, l_rest, flsn, el));
 }
-// every shard scatters its own columns into the same Fortran arrays
-int mckpp_hip_multi_download(mckpp_hip_multi_handle m, mckpp_state_ptrs_c *s, uint32_t mask) { MULTI_EACH(mckpp_hip_download(x, s, mask)); }
-
 int64_t mckpp_hip_multi_ncolumns(mckpp_hip_multi_handle m)
 {
   if (!m) return -1;
@@ -1489,10 +1530,113 @@ int mckpp_hip_multi_status(mckpp_hip_multi_handle m, int32_t *per_col, int64_t *
   return 0;
 }
 
-// Output gather: `field` 0 U, 1 V, 2 T, 3 S -> out(npts,nzp1), 4 hmix -> out(npts), in the Fortran
-// layout.  Every shard's rows travel device-to-device to shard `root` (peer copies behind an event on the
-// owner's stream, so a gather queued behind a step overlaps the other shards' tail), are re-laid there
-// into the 3D order, and cross PCIe once.  Land points keep what `out` held.
+// ---- The gather.  One row field of every shard -> the caller's (npts, nlev) array in the Fortran
+// layout: the shards' rows travel device to device to shard `root` (peer copies over the GPU interconnect, each on
+// its own stream of the root device behind an event on its owner's stream - so all of them are in flight at once,
+// and a gather queued behind a step overlaps the other shards' tail), are re-laid there into the 3-D order by one
+// kernel per shard (disjoint points), and cross PCIe once.  Land points keep what `out` held.  `src[d]` are the
+// shards' device rows (ld doubles each), src_off the first element taken from a row.
+static int multi_prepare_root(mckpp_hip_multi *m, int root, size_t nout, size_t nstage)
+{
+  const int ndev = (int)m->ctx.size();
+  mckpp_hip_ctx *r = m->ctx[root];
+  if (m->root != root) {
+    multi_release_root(m);
+    HIPCHK(hipSetDevice(r->device));
+    m->root = root;
+    m->gstream.assign(ndev, nullptr);
+    m->ev_done.assign(ndev, nullptr);
+    for (int d = 0; d < ndev; ++d) {
+      HIPCHK(hipStreamCreateWithFlags(&m->gstream[d], hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&m->ev_done[d], hipEventDisableTiming));
+      if (d != root && m->ctx[d]->device != r->device) {
+        hipError_t e = hipDeviceEnablePeerAccess(m->ctx[d]->device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // staged copies still work
+      }
+    }
+    HIPCHK(hipEventCreateWithFlags(&m->ev_init, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_gcopy, hipEventDisableTiming));
+  }
+  HIPCHK(hipSetDevice(r->device));
+  size_t ngipt = 0;
+  for (auto *x : m->ctx) ngipt += (size_t)x->ncol;
+  const bool grow = nout > m->out_elems || nstage > m->stage_elems || ngipt > m->gipt_elems;
+  if (grow) {   // nothing of an earlier gather may still be using the buffers
+    for (auto &st : m->gstream) HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipStreamSynchronize(r->stream));
+    HIPCHK(hipStreamSynchronize(r->copy_stream));
+  }
+  if (nout > m->out_elems) { if (m->d_out) hipFree(m->d_out); m->d_out = nullptr; HIPCHK(hipMalloc(&m->d_out, nout * sizeof(double))); m->out_elems = nout; }
+  if (nstage > m->stage_elems) { if (m->d_stage) hipFree(m->d_stage); m->d_stage = nullptr; HIPCHK(hipMalloc(&m->d_stage, nstage * sizeof(double))); m->stage_elems = nstage; }
+  if (ngipt > m->gipt_elems) { if (m->d_gipt) hipFree(m->d_gipt); m->d_gipt = nullptr; HIPCHK(hipMalloc(&m->d_gipt, ngipt * sizeof(int))); m->gipt_elems = ngipt; m->gipt_valid = false; }
+  if (!m->gipt_valid) {   // the shards' column maps, once per upload
+    size_t go = 0;
+    for (auto *x : m->ctx) {
+      if (x->ncol) HIPCHK(hipMemcpy(m->d_gipt + go, x->ipt.data(), (size_t)x->ncol * sizeof(int), hipMemcpyHostToDevice));
+      go += (size_t)x->ncol;
+    }
+    m->gipt_valid = true;
+  }
+  return 0;
+}
+
+static int multi_gather_rows(mckpp_hip_multi *m, int root, const std::vector<const double *> &src, int ld, int src_off,
+                             int nlev, double *out)
+{
+  const int ndev = (int)m->ctx.size();
+  mckpp_hip_ctx *r = m->ctx[root];
+  const size_t nout = (size_t)m->npts * nlev;
+  size_t nstage = 0, ncols = 0;
+  for (int d = 0; d < ndev; ++d) {
+    ncols += (size_t)m->ctx[d]->ncol;
+    if (d != root) nstage += (size_t)m->ctx[d]->ncol * ld;   // the root's own rows are read where they are
+  }
+  if (multi_prepare_root(m, root, nout, nstage ? nstage : 1)) return -1;
+  pin_host(r, out, nout * sizeof(double));
+  // the 3-D image: behind the transfer of the previous gather; land points keep the caller's values
+  HIPCHK(hipStreamWaitEvent(r->stream, m->ev_gcopy, 0));
+  if (ncols < (size_t)m->npts) HIPCHK(hipMemcpyAsync(m->d_out, out, nout * sizeof(double), hipMemcpyHostToDevice, r->stream));
+  HIPCHK(hipEventRecord(m->ev_init, r->stream));
+  size_t so = 0, go = 0;
+  for (int d = 0; d < ndev; ++d) {
+    mckpp_hip_ctx *x = m->ctx[d];
+    if (x->ncol == 0) continue;
+    const size_t n = (size_t)x->ncol * ld;
+    hipStream_t gs = m->gstream[d];
+    HIPCHK(hipSetDevice(x->device));
+    HIPCHK(hipEventRecord(m->ev_owner[d], x->stream));   // whatever the owner's stream still has queued
+    HIPCHK(hipSetDevice(r->device));
+    HIPCHK(hipStreamWaitEvent(gs, m->ev_owner[d], 0));
+    HIPCHK(hipStreamWaitEvent(gs, m->ev_init, 0));
+    const double *rows = src[d];
+    if (d != root) {
+      if (x->device == r->device) HIPCHK(hipMemcpyAsync(m->d_stage + so, src[d], n * sizeof(double), hipMemcpyDeviceToDevice, gs));
+      else HIPCHK(hipMemcpyPeerAsync(m->d_stage + so, r->device, src[d], x->device, n * sizeof(double), gs));
+      rows = m->d_stage + so;
+      so += n;
+    }
+    HIPCHK(mckpp_launch_scatter_rows(rows, ld, src_off, m->d_gipt + go, x->ncol, m->d_out, m->npts, nlev, 0, gs));
+    HIPCHK(hipEventRecord(m->ev_done[d], gs));
+    HIPCHK(hipStreamWaitEvent(r->copy_stream, m->ev_done[d], 0));
+    go += (size_t)x->ncol;
+  }
+  HIPCHK(hipStreamWaitEvent(r->copy_stream, m->ev_init, 0));
+  HIPCHK(hipMemcpyAsync(out, m->d_out, nout * sizeof(double), hipMemcpyDeviceToHost, r->copy_stream));
+  HIPCHK(hipEventRecord(m->ev_gcopy, r->copy_stream));
+  return 0;
+}
+
+// the gathers queued so far have delivered
+static int multi_gather_finish(mckpp_hip_multi *m)
+{
+  if (m->root < 0) return 0;
+  mckpp_hip_ctx *r = m->ctx[m->root];
+  HIPCHK(hipSetDevice(r->device));
+  HIPCHK(hipStreamSynchronize(r->copy_stream));
+  return 0;
+}
+
+// `field` 0 U, 1 V, 2 T, 3 S -> out(npts,nzp1), 4 hmix -> out(npts)
 int mckpp_hip_multi_gather(mckpp_hip_multi_handle m, int32_t field, int32_t root, double *out)
 {
   if (!m || !out) return fail("mckpp_hip_multi_gather: null argument");
@@ -1500,64 +1644,113 @@ int mckpp_hip_multi_gather(mckpp_hip_multi_handle m, int32_t field, int32_t root
   if (root < 0 || root >= ndev) return fail("mckpp_hip_multi_gather: root %d of %d", root, ndev);
   if (field < 0 || field > 4) return fail("mckpp_hip_multi_gather: field %d", field);
   if (m->npts <= 0) return fail("mckpp_hip_multi_gather: nothing uploaded");
-  mckpp_hip_ctx *r = m->ctx[root];
-  const int nlev = field < 4 ? r->nzp1 : 1;
-  const size_t nout = (size_t)m->npts * nlev;
-  size_t nstage = 0, ngipt = 0;
-  for (auto *x : m->ctx) {
-    nstage += (size_t)x->ncol * (field < 4 ? (size_t)x->ld : (size_t)MCKPP_CS);
-    ngipt += (size_t)x->ncol;
-  }
-  HIPCHK(hipSetDevice(r->device));
-  if (m->root != root) {   // buffers live on the root device
-    if (m->root >= 0) {
-      hipSetDevice(m->ctx[m->root]->device);
-      if (m->d_out) hipFree(m->d_out);
-      if (m->d_stage) hipFree(m->d_stage);
-      if (m->d_gipt) hipFree(m->d_gipt);
-      hipSetDevice(r->device);
-    }
-    m->d_out = m->d_stage = nullptr; m->d_gipt = nullptr;
-    m->out_elems = m->stage_elems = m->gipt_elems = 0;
-    m->root = root;
-    for (int d = 0; d < ndev; ++d)
-      if (d != root && m->ctx[d]->device != r->device) {
-        hipError_t e = hipDeviceEnablePeerAccess(m->ctx[d]->device, 0);
-        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // staged copies still work
-      }
-  }
-  if (nout > m->out_elems) { if (m->d_out) hipFree(m->d_out); HIPCHK(hipMalloc(&m->d_out, nout * sizeof(double))); m->out_elems = nout; }
-  if (nstage > m->stage_elems) { if (m->d_stage) hipFree(m->d_stage); HIPCHK(hipMalloc(&m->d_stage, nstage * sizeof(double))); m->stage_elems = nstage; }
-  if (ngipt > m->gipt_elems) { if (m->d_gipt) hipFree(m->d_gipt); HIPCHK(hipMalloc(&m->d_gipt, ngipt * sizeof(int))); m->gipt_elems = ngipt; }
-  if (ngipt < (size_t)m->npts)   // land points: keep the caller's values
-    HIPCHK(hipMemcpyAsync(m->d_out, out, nout * sizeof(double), hipMemcpyHostToDevice, r->stream));
-  size_t so = 0, go = 0;
+  std::vector<const double *> src(ndev);
   for (int d = 0; d < ndev; ++d) {
     mckpp_hip_ctx *x = m->ctx[d];
-    if (x->ncol == 0) continue;
-    const int ld = field < 4 ? x->ld : MCKPP_CS;
-    const double *src = field == 0 ? x->d_prof[P_U] : field == 1 ? x->d_prof[P_V] : field == 2 ? x->d_prof[P_T]
-                      : field == 3 ? x->d_prof[P_S] : x->d_cs;
-    const size_t n = (size_t)x->ncol * ld;
-    // order the copy behind whatever the owner's stream still has queued
-    HIPCHK(hipSetDevice(x->device));
-    hipEvent_t ev;
-    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(ev, x->stream));
-    HIPCHK(hipSetDevice(r->device));
-    HIPCHK(hipStreamWaitEvent(r->stream, ev, 0));
-    if (x->device == r->device) HIPCHK(hipMemcpyAsync(m->d_stage + so, src, n * sizeof(double), hipMemcpyDeviceToDevice, r->stream));
-    else HIPCHK(hipMemcpyPeerAsync(m->d_stage + so, r->device, src, x->device, n * sizeof(double), r->stream));
-    HIPCHK(hipMemcpyAsync(m->d_gipt + go, x->ipt.data(), (size_t)x->ncol * sizeof(int), hipMemcpyHostToDevice, r->stream));
-    HIPCHK(mckpp_launch_scatter_rows(m->d_stage + so, ld, field < 4 ? 0 : CS_HMIX, m->d_gipt + go, x->ncol, m->d_out,
-                                     m->npts, nlev, 0, r->stream));
-    HIPCHK(hipStreamSynchronize(r->stream));   // x->ipt is pageable host memory; also lets the event go
-    HIPCHK(hipEventDestroy(ev));
-    so += n;
-    go += (size_t)x->ncol;
+    src[d] = field == 0 ? x->d_prof[P_U] : field == 1 ? x->d_prof[P_V] : field == 2 ? x->d_prof[P_T]
+           : field == 3 ? x->d_prof[P_S] : x->d_cs;
   }
-  HIPCHK(hipMemcpyAsync(out, m->d_out, nout * sizeof(double), hipMemcpyDeviceToHost, r->stream));
-  HIPCHK(hipStreamSynchronize(r->stream));
+  mckpp_hip_ctx *r = m->ctx[root];
+  if (multi_gather_rows(m, root, src, field < 4 ? r->ld : MCKPP_CS, field < 4 ? 0 : CS_HMIX, field < 4 ? r->nzp1 : 1, out))
+    return -1;
+  return multi_gather_finish(m);
+}
+
+// mckpp_hip_download for all shards: the per-column records of every shard come to the host on their own (each
+// crosses PCIe once), every row field goes through the gather - one transfer per field, whatever the number
+// of devices.
+int mckpp_hip_multi_download(mckpp_hip_multi_handle m, mckpp_state_ptrs_c *s, uint32_t mask)
+{
+  if (!m || !s) return fail("mckpp_hip_multi_download: null argument");
+  if (s->npts != m->npts) return fail("mckpp_hip_multi_download: npts=%lld but %lld were uploaded", (long long)s->npts, (long long)m->npts);
+  const int ndev = (int)m->ctx.size();
+  std::vector<std::vector<row_xfer>> plans(ndev);
+  for (int d = 0; d < ndev; ++d) download_plan(m->ctx[d], s, mask, plans[d]);
+  std::vector<const double *> src(ndev);
+  for (size_t e = 0; e < plans[0].size(); ++e) {
+    for (int d = 0; d < ndev; ++d) src[d] = plans[d][e].dev;
+    const row_xfer &x = plans[0][e];
+    if (multi_gather_rows(m, 0, src, m->ctx[0]->ld, x.src_off, x.nlev, x.host)) return -1;
+  }
+  for (auto *x : m->ctx) {
+    if (x->ncol == 0) continue;
+    HIPCHK(hipSetDevice(x->device));
+    if (download_records(x, s, mask)) return -1;
+  }
+  return multi_gather_finish(m);
+}
+
+// ---- the forced time loop, the output windows and the restart set for all shards
+int mckpp_hip_multi_set_flux_series(mckpp_hip_multi_handle m, int rec0, int nrec, const double *fields)
+{
+  MULTI_EACH(mckpp_hip_set_flux_series(x, rec0, nrec, fields));
+}
+// asynchronous on every device, like mckpp_hip_multi_step
+int mckpp_hip_multi_run_forced(mckpp_hip_multi_handle m, int nt_first, int nsteps, int ndtocn, int l_rest, double flsn, double el)
+{
+  MULTI_EACH(mckpp_hip_run_forced(x, nt_first, nsteps, ndtocn, l_rest, flsn, el));
+}
+int mckpp_hip_multi_window_select(mckpp_hip_multi_handle m, const int32_t *fields, int32_t nfields) { MULTI_EACH(mckpp_hip_window_select(x, fields, nfields)); }
+int mckpp_hip_multi_window_reset(mckpp_hip_multi_handle m) { MULTI_EACH(mckpp_hip_window_reset(x)); }
+int mckpp_hip_multi_window_accumulate(mckpp_hip_multi_handle m) { MULTI_EACH(mckpp_hip_window_accumulate(x)); }
+
+// every shard reduces its own columns; the reduced rows are gathered like any other field
+int mckpp_hip_multi_window_fetch(mckpp_hip_multi_handle m, int field, int op, double *out)
+{
+  if (!m || !out) return fail("mckpp_hip_multi_window_fetch: null argument");
+  if (m->npts <= 0) return fail("mckpp_hip_multi_window_fetch: nothing uploaded");
+  const int ndev = (int)m->ctx.size();
+  std::vector<const double *> src(ndev, nullptr);
+  int ld_out = 0, nlev = 0;
+  for (int d = 0; d < ndev; ++d)
+    if (window_prepare(m->ctx[d], field, op, &src[d], &ld_out, &nlev)) return -1;
+  if (multi_gather_rows(m, 0, src, ld_out, 0, nlev, out)) return -1;
+  return multi_gather_finish(m);
+}
+
+// one file per shard: <path>.<d>of<ndev>
+static std::string shard_path(const char *path, int d, int ndev)
+{
+  return std::string(path) + "." + std::to_string(d) + "of" + std::to_string(ndev);
+}
+int mckpp_hip_multi_save_restart(mckpp_hip_multi_handle m, const char *path)
+{
+  if (!m || !path) return fail("mckpp_hip_multi_save_restart: null argument");
+  const int ndev = (int)m->ctx.size();
+  for (int d = 0; d < ndev; ++d)
+    if (m->ctx[d]->ncol > 0 && mckpp_hip_save_restart(m->ctx[d], shard_path(path, d, ndev).c_str()) != 0) return -1;
+  return 0;
+}
+// the files must have been written by a handle with the same number of shards over the same land mask: every
+// shard's column map is checked against the one the current upload gave it before anything is replaced
+int mckpp_hip_multi_load_restart(mckpp_hip_multi_handle m, const char *path)
+{
+  if (!m || !path) return fail("mckpp_hip_multi_load_restart: null argument");
+  if (m->npts <= 0) return fail("mckpp_hip_multi_load_restart: upload the state first (the shards' column maps come from it)");
+  const int ndev = (int)m->ctx.size();
+  for (int d = 0; d < ndev; ++d) {   // pass 1: headers and column maps only
+    mckpp_hip_ctx *x = m->ctx[d];
+    if (x->ncol == 0) continue;
+    const std::string sp = shard_path(path, d, ndev);
+    FILE *f = fopen(sp.c_str(), "rb");
+    if (!f) return fail("mckpp_hip_multi_load_restart: cannot open %s", sp.c_str());
+    restart_header hd{};
+    std::vector<int> ipt;
+    bool ok = fread(&hd, sizeof hd, 1, f) == 1 && memcmp(hd.magic, kRestartMagic, 8) == 0 && hd.ncol == x->ncol && hd.npts == x->npts;
+    if (ok) { ipt.resize((size_t)hd.ncol); ok = fread(ipt.data(), sizeof(int), ipt.size(), f) == ipt.size() && ipt == x->ipt; }
+    fclose(f);
+    if (!ok) return fail("mckpp_hip_multi_load_restart: %s does not belong to shard %d of %d of the uploaded columns", sp.c_str(), d, ndev);
+  }
+  for (int d = 0; d < ndev; ++d)
+    if (m->ctx[d]->ncol > 0 && mckpp_hip_load_restart(m->ctx[d], shard_path(path, d, ndev).c_str()) != 0) return -1;
+  return 0;
+}
+
+// the caller's arrays pinned on behalf of this handle go back to pageable memory (before the caller frees them)
+int mckpp_hip_multi_release_host_arrays(mckpp_hip_multi_handle m)
+{
+  if (!m) return fail("null multi handle");
+  for (auto *x : m->ctx) { HIPCHK(hipSetDevice(x->device)); if (xfer_finish(x)) return -1; unpin_all(x); }
   return 0;
 }
 

@@ -1075,8 +1075,9 @@ def test_config4_full_length_1000_steps(mk):
     hourly steps of the diurnal bench forcing through mckpp_hip_run_forced (the reference's time loop,
     src/mckpp_ocean_model_3D.F90:38-58), state never leaving HBM, flux records uploaded per 100-step
     window.  A strided sample of 250 columns is compared bit for bit with the oracle at steps 24, 240 and
-    1000 (status words included); flagged columns must be the oracle's; a second, independent run must
-    end bitwise identical (the column queue assigns columns to workgroups differently every launch)."""
+    1000 (status words included); flagged columns must be the oracle's; a second, independent run - through
+    the multi-device handle with four shards - must end bitwise identical (the column queue assigns columns
+    to workgroups differently every launch, and the shards see different subsets)."""
     import hashlib
 
     from oracle import orc
@@ -1086,9 +1087,9 @@ def test_config4_full_length_1000_steps(mk):
     sample = np.arange(37, ncol, 400)
     assert len(sample) >= 200
 
-    def gpu_run(snapshots):
+    def gpu_run(snapshots, shards=0):
         kc, k3 = cm.make_hip_case(ncol, nz)
-        ctx = mk.MckppHip(kc)
+        ctx = mk.MckppHipMulti(kc, [0] * shards) if shards else mk.MckppHip(kc)
         ctx.upload(k3)
         ctx.set_diagnostics(0)
         ctx.init_ocean(0)
@@ -1135,8 +1136,10 @@ def test_config4_full_length_1000_steps(mk):
             assert np.array_equal(npass, ob["npasses"]), f"pass counts at step {nt}"
             _assert_bitexact(cm.compare(sub, ob, nz, cm.PROFILE_FIELDS + cm.SCALAR_FIELDS + ["hmixd0", "hmixd1"]),
                              f"config4 sample at step {nt}")
-    digest2, _ = gpu_run(None)
-    assert digest1 == digest2, "two runs of 1000 steps differ"
+    # the second run through the multi-device handle, four shards (all on this GPU): mckpp_hip_multi_set_flux_series
+    # + multi_run_forced + multi_download must end on the same bits
+    digest2, _ = gpu_run(None, shards=4)
+    assert digest1 == digest2, "two runs of 1000 steps (one context / four shards behind one handle) differ"
 
 
 @pytest.mark.parametrize("nz,shards", [(60, 1), (60, 3), (69, 4)])
