@@ -16,12 +16,14 @@ program kpp_driver
   use mckpp_physics_ocnstep_mod, only: mckpp_physics_ocnstep
   use mckpp_physics_verticalmixing_mod, only: mckpp_physics_verticalmixing
   use mckpp_fluxes_mod, only: mckpp_fluxes
-  use mckpp_hip_session, only: mckpp_hip_ndevices, mckpp_hip_device_list, mckpp_hip_gather_field
+  use mckpp_hip_session, only: mckpp_hip_ndevices, mckpp_hip_device_list, mckpp_hip_gather_field, mckpp_hip_sync_host, &
+                               mckpp_hip_all_set_flux_series, mckpp_hip_all_run_forced, mckpp_hip_all_window_select, &
+                               mckpp_hip_all_window_reset, mckpp_hip_all_window_accumulate, mckpp_hip_all_window_fetch
   implicit none
   character(len=512) :: fin, fout
   integer :: u, nt, nsteps, ncol, nlev, use_1d, ipt, flags
   integer(c_int) :: hdr(8)
-  real(c_double), allocatable :: sf6(:,:), mask(:)
+  real(c_double), allocatable :: sf6(:,:), mask(:), series(:,:,:)
   type(kpp_1d_type) :: q
   real(c_double) :: t0, t1
   real(c_double), allocatable :: vm_h(:), vm_k(:), vm_difm(:,:), vm_difs(:,:), vm_dift(:,:), vm_ghat(:,:)
@@ -35,6 +37,9 @@ program kpp_driver
   ncol = hdr(1); nlev = hdr(2); nsteps = hdr(3); use_1d = hdr(4)
   ! flags: 1 forcing through mckpp_fluxes (constant forcing, L_FLUXDATA=.F.) every step; 2 L_VARY_BOTTOM_TEMP;
   !        4 after the run, mckpp_physics_verticalmixing on every column of the final state (appended to the output)
+  !        8 hmix and T also through the output gather (appended); 16 the time loop as ONE forced run from flux
+  !        records resident on the devices (constant forcing, the records mckpp_fluxes would assemble each step);
+  !        32 the same step by step with an output window: mean hmix and maximum T of the run (appended)
   flags = hdr(6)
   ! hdr(7) > 0: that many device shards; hdr(8) = 1 puts them all on HIP device 0 (one-GPU rehearsal of the
   ! multi-device path), otherwise devices 0 .. hdr(7)-1
@@ -74,6 +79,23 @@ program kpp_driver
 
   kpp_3d_fields%sflux(:, 1:6, 5, 0) = sf6
   call cpu_time(t0)
+  if (iand(flags, 48) /= 0) then   ! the reference's loop (src/mckpp_ocean_model_3D.F90:38-58) on the devices
+    allocate (series(ncol, 8, 1))
+    series(:, 1, 1) = 0.01_c_double; series(:, 2, 1) = 0; series(:, 3, 1) = 200; series(:, 4, 1) = 0
+    series(:, 5, 1) = -150; series(:, 6, 1) = 0; series(:, 7, 1) = 6e-5_c_double; series(:, 8, 1) = 0
+    call mckpp_hip_all_set_flux_series(0, 1, series)
+    if (iand(flags, 32) /= 0) then
+      call mckpp_hip_all_window_select([4_c_int32_t, 2_c_int32_t])   ! MCKPP_OUT_HMIX, MCKPP_OUT_T
+      call mckpp_hip_all_window_reset()
+      do nt = 1, nsteps
+        call mckpp_hip_all_run_forced(nt, 1, nsteps + 1)
+        call mckpp_hip_all_window_accumulate()
+      end do
+    else
+      call mckpp_hip_all_run_forced(1, nsteps, nsteps + 1)   ! one flux update (step 1), as ndtocn > nsteps
+    end if
+    nsteps = 0
+  end if
   do nt = 1, nsteps
     call mckpp_update_time(nt)
     if (iand(flags, 1) /= 0) call mckpp_fluxes()      ! ndtocn = 1 (src/mckpp_ocean_model_3D.F90:44-48)
@@ -95,6 +117,7 @@ program kpp_driver
   write (*, '(a,3es14.6)') 'kpp_driver: hmix min/mean/max ', minval(kpp_3d_fields%hmix, kpp_3d_fields%run_physics), &
         sum(kpp_3d_fields%hmix)/max(1, count(kpp_3d_fields%run_physics)), maxval(kpp_3d_fields%hmix)
 
+  call mckpp_hip_sync_host()   ! the per-step download brings the scalar group only
   open (newunit=u, file=trim(fout), access='stream', form='unformatted', status='replace')
   write (u) kpp_3d_fields%U, kpp_3d_fields%X, kpp_3d_fields%Us, kpp_3d_fields%Xs
   write (u) kpp_3d_fields%hmix, kpp_3d_fields%kmix, kpp_3d_fields%hmixd, kpp_3d_fields%Tref, kpp_3d_fields%Ssurf
@@ -105,6 +128,14 @@ program kpp_driver
     vm_h = -1; vm_difm = -1
     call mckpp_hip_gather_field(4, max(0, mckpp_hip_ndevices - 1), vm_h)
     call mckpp_hip_gather_field(2, 0, vm_difm)
+    write (u) vm_h, vm_difm
+    deallocate (vm_h, vm_difm)
+  end if
+  if (iand(flags, 32) /= 0) then
+    allocate (vm_h(ncol), vm_difm(ncol, nzp1))
+    vm_h = -1; vm_difm = -1
+    call mckpp_hip_all_window_fetch(4, 0, vm_h)
+    call mckpp_hip_all_window_fetch(2, 2, vm_difm)
     write (u) vm_h, vm_difm
     deallocate (vm_h, vm_difm)
   end if

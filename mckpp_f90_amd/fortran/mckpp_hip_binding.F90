@@ -242,6 +242,63 @@ module mckpp_hip_binding
       real(c_double), intent(inout) :: out(*)
       integer(c_int) :: rc
     end function
+    ! ---- the forced time loop, the output windows and the restart set for all shards ----
+    function mckpp_hip_multi_set_flux_series(handle, rec0, nrec, fields) bind(C, name="mckpp_hip_multi_set_flux_series") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: handle
+      integer(c_int), value :: rec0, nrec
+      real(c_double), intent(in) :: fields(*)
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_run_forced(handle, nt_first, nsteps, ndtocn, l_rest, flsn, el) &
+        bind(C, name="mckpp_hip_multi_run_forced") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: handle
+      integer(c_int), value :: nt_first, nsteps, ndtocn, l_rest
+      real(c_double), value :: flsn, el
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_window_select(handle, fields, nfields) bind(C, name="mckpp_hip_multi_window_select") result(rc)
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int32_t), intent(in) :: fields(*)
+      integer(c_int32_t), value :: nfields
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_window_reset(handle) bind(C, name="mckpp_hip_multi_window_reset") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_window_accumulate(handle) bind(C, name="mckpp_hip_multi_window_accumulate") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_window_fetch(handle, field, op, out) bind(C, name="mckpp_hip_multi_window_fetch") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: handle
+      integer(c_int), value :: field, op
+      real(c_double), intent(inout) :: out(*)
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_save_restart(handle, path) bind(C, name="mckpp_hip_multi_save_restart") result(rc)
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value :: handle
+      character(kind=c_char), intent(in) :: path(*)
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_load_restart(handle, path) bind(C, name="mckpp_hip_multi_load_restart") result(rc)
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value :: handle
+      character(kind=c_char), intent(in) :: path(*)
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_release_host_arrays(handle) bind(C, name="mckpp_hip_multi_release_host_arrays") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int) :: rc
+    end function
     ! ---- output fields with XIOS' temporal operations on the device (MCKPP_OUT_* of include/mckpp_hip.h) ----
     function mckpp_hip_window_select(handle, fields, nfields) bind(C, name="mckpp_hip_window_select") result(rc)
       import :: c_int, c_int32_t, c_ptr

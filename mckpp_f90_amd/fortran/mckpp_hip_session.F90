@@ -15,20 +15,32 @@ module mckpp_hip_session
   public :: mckpp_hip_push_ancillaries, mckpp_hip_ancillaries_every_step
   public :: mckpp_hip_multi_handle, mckpp_hip_ndevices, mckpp_hip_device_list, mckpp_hip_gather_field
   public :: mckpp_hip_const_view, mckpp_hip_state_view, l2i
+  public :: mckpp_hip_all_set_flux_series, mckpp_hip_all_run_forced, mckpp_hip_all_window_select
+  public :: mckpp_hip_all_window_reset, mckpp_hip_all_window_accumulate, mckpp_hip_all_window_fetch
+  public :: mckpp_hip_all_save_restart, mckpp_hip_all_load_restart, mckpp_hip_sync_host, mckpp_hip_device_advanced
 
   !> All devices of the run behind one handle (include/mckpp_hip.h, mckpp_hip_multi_*): the columns of
   !! kpp_3d_fields are dealt round-robin over mckpp_hip_ndevices GPUs, HIP devices mckpp_hip_device,
   !! mckpp_hip_device+1, ... unless mckpp_hip_device_list names them.  One Fortran process drives them
   !! all - no MPI - exactly as the reference's single mckpp_physics_driver call covers all npts
   !! (src/mckpp_physics_driver_mod.F90:27-65).  mckpp_hip_handle is shard 0 (the whole run when
-  !! mckpp_hip_ndevices = 1).
+  !! mckpp_hip_ndevices = 1).  Whatever covers all npts - the forced run, the output windows, the restart set,
+  !! status - must go through the mckpp_hip_all_* wrappers below (the multi handle), never through shard 0 alone.
   type(c_ptr), save :: mckpp_hip_multi_handle = c_null_ptr
   integer(c_int), save :: mckpp_hip_ndevices = 1
   integer(c_int32_t), allocatable, save :: mckpp_hip_device_list(:)
   type(c_ptr), save :: mckpp_hip_handle = c_null_ptr
-  integer(c_int), save :: mckpp_hip_output_mask = MCKPP_F_ALL   !< fields copied back after each driver call
+  !> Field groups mckpp_physics_driver copies back into kpp_3d_fields after every call.  Default: the scalar group
+  !! (hmix, kmix, Tref, uref, vref, Ssurf, flags, sflux) - 192 bytes per column.  The reference leaves ALL of
+  !! kpp_3d_fields current after every call (src/mckpp_types_transfer.F90:199-327); a host that reads profiles or
+  !! diagnostics between steps sets this to MCKPP_F_ALL (48 ms per step at 1e5 x 60 against 3.4 ms for the step
+  !! itself), or - cheaper - calls mckpp_hip_sync_host(groups) at its output steps, or fetches reduced output
+  !! fields (mckpp_hip_all_window_fetch).  mckpp_physics_finalize brings everything back before it detaches.
+  integer(c_int), save :: mckpp_hip_output_mask = MCKPP_F_SCALARS
   integer(c_int), save :: mckpp_hip_device = 0
   logical, save :: resident = .false.
+  !> field groups of kpp_3d_fields that are older than the device state (a step ran and did not bring them back)
+  integer(c_int), save :: host_behind = 0
   !> The reference's time loop lets mckpp_boundary_update rewrite SST0, the climatologies and the flux
   !! corrections on the host between steps (src/mckpp_ocean_model_3D.F90:51-55).  With this flag on
   !! (default) mckpp_physics_driver re-sends those inputs before every step when an optional switch
@@ -158,22 +170,30 @@ contains
     if (.not. doit) return
     call mckpp_hip_attach()
     if (resident) then
-      missing = iand(MCKPP_F_ALL, not(mckpp_hip_output_mask))
+      missing = host_behind
       if (missing /= 0) call mckpp_hip_pull_state(missing)
     end if
     call mckpp_hip_state_view(kpp_3d_fields, npts, s)
     call mckpp_hip_check(mckpp_hip_multi_upload(mckpp_hip_multi_handle, s), 'mckpp_hip_upload')
     resident = .true.
+    host_behind = 0
   end subroutine mckpp_hip_push_state
 
   !> HBM -> kpp_3d_fields for the selected field groups.
   subroutine mckpp_hip_pull_state(mask)
     integer(c_int), intent(in) :: mask
     type(mckpp_state_ptrs_c) :: s
-    if (mask == 0) return
+    if (mask == 0 .or. .not. resident) return
     call mckpp_hip_state_view(kpp_3d_fields, npts, s)
     call mckpp_hip_check(mckpp_hip_multi_download(mckpp_hip_multi_handle, s, int(mask, c_int32_t)), 'mckpp_hip_download')
+    host_behind = iand(host_behind, not(mask))
   end subroutine mckpp_hip_pull_state
+
+  !> the device state has moved on (a step, a forced run, a restart load): every field group of kpp_3d_fields is
+  !! now older than it until a download brings it back
+  subroutine mckpp_hip_device_advanced()
+    host_behind = MCKPP_F_ALL
+  end subroutine mckpp_hip_device_advanced
 
   !> Output gather without a full download: field 0 U, 1 V, 2 T, 3 S -> out(npts,nzp1), 4 hmix -> out(npts);
   !! the shards' rows travel over the GPU interconnect to device `root` (0-based shard index) and cross
@@ -185,12 +205,81 @@ contains
                          'mckpp_hip_multi_gather')
   end subroutine mckpp_hip_gather_field
 
+  !> kpp_3d_fields brought up to date with the device for the field groups the per-step download leaves there
+  !! (all of them by default): what a host does before it reads profiles or diagnostics, e.g. at an output step.
+  subroutine mckpp_hip_sync_host(groups)
+    integer(c_int), intent(in), optional :: groups
+    integer(c_int) :: g
+    g = MCKPP_F_ALL
+    if (present(groups)) g = groups
+    call mckpp_hip_pull_state(iand(g, host_behind))
+  end subroutine mckpp_hip_sync_host
+
+  !> The reference's forced time loop without per-step host traffic (src/mckpp_ocean_model_3D.F90:38-58) on all
+  !! devices: `nrec` records of the eight forcing fields, fields(npts, 8, nrec) in the order taux, tauy, swf, lwf,
+  !! lhf, shf, rain, snow (record 1 is flux update number rec0 of the run), kept on the devices; then steps
+  !! nt_first .. nt_first+nsteps-1 with mckpp_fluxes every ndtocn steps, one launch sequence per device.
+  subroutine mckpp_hip_all_set_flux_series(rec0, nrec, fields)
+    integer, intent(in) :: rec0, nrec
+    real(c_double), intent(in) :: fields(*)
+    call mckpp_hip_push_state()
+    call mckpp_hip_check(mckpp_hip_multi_set_flux_series(mckpp_hip_multi_handle, int(rec0, c_int), int(nrec, c_int), fields), &
+                         'mckpp_hip_multi_set_flux_series')
+  end subroutine mckpp_hip_all_set_flux_series
+
+  subroutine mckpp_hip_all_run_forced(nt_first, nsteps, ndtocn)
+    integer, intent(in) :: nt_first, nsteps, ndtocn
+    call mckpp_hip_push_state()
+    call mckpp_hip_check(mckpp_hip_multi_run_forced(mckpp_hip_multi_handle, int(nt_first, c_int), int(nsteps, c_int), &
+                         int(ndtocn, c_int), l2i(kpp_const_fields%L_REST), kpp_const_fields%FLSN, kpp_const_fields%EL), &
+                         'mckpp_hip_multi_run_forced')
+    call mckpp_hip_device_advanced()
+  end subroutine mckpp_hip_all_run_forced
+
+  !> Output windows on the devices (what XIOS does with the fields mckpp_xios_output_control sends,
+  !! src/mckpp_xios_io.F90:74-210, run/iodef.xml:88-157): select the MCKPP_OUT_* fields, accumulate once after
+  !! each step, fetch op 0 mean / 1 min / 2 max / 3 instant into out(npts[,nzp1]).
+  subroutine mckpp_hip_all_window_select(fields)
+    integer(c_int32_t), intent(in) :: fields(:)
+    call mckpp_hip_attach()
+    call mckpp_hip_check(mckpp_hip_multi_window_select(mckpp_hip_multi_handle, fields, int(size(fields), c_int32_t)), &
+                         'mckpp_hip_multi_window_select')
+  end subroutine mckpp_hip_all_window_select
+  subroutine mckpp_hip_all_window_reset()
+    call mckpp_hip_check(mckpp_hip_multi_window_reset(mckpp_hip_multi_handle), 'mckpp_hip_multi_window_reset')
+  end subroutine mckpp_hip_all_window_reset
+  subroutine mckpp_hip_all_window_accumulate()
+    call mckpp_hip_check(mckpp_hip_multi_window_accumulate(mckpp_hip_multi_handle), 'mckpp_hip_multi_window_accumulate')
+  end subroutine mckpp_hip_all_window_accumulate
+  subroutine mckpp_hip_all_window_fetch(field, op, out)
+    integer, intent(in) :: field, op
+    real(c_double), intent(inout) :: out(*)
+    call mckpp_hip_check(mckpp_hip_multi_window_fetch(mckpp_hip_multi_handle, int(field, c_int), int(op, c_int), out), &
+                         'mckpp_hip_multi_window_fetch')
+  end subroutine mckpp_hip_all_window_fetch
+
+  !> Restart set of all devices (src/mckpp_xios_io.F90:368-465): one file per shard, <path>.<shard>of<ndevices>
+  subroutine mckpp_hip_all_save_restart(path)
+    character(len=*), intent(in) :: path
+    call mckpp_hip_check(mckpp_hip_multi_save_restart(mckpp_hip_multi_handle, trim(path)//c_null_char), 'mckpp_hip_multi_save_restart')
+  end subroutine mckpp_hip_all_save_restart
+  subroutine mckpp_hip_all_load_restart(path)
+    character(len=*), intent(in) :: path
+    call mckpp_hip_push_state()   ! the shards' column maps come from the upload
+    call mckpp_hip_check(mckpp_hip_multi_load_restart(mckpp_hip_multi_handle, trim(path)//c_null_char), 'mckpp_hip_multi_load_restart')
+    call mckpp_hip_device_advanced()
+  end subroutine mckpp_hip_all_load_restart
+
+  !> Everything the per-step download left on the devices comes back first, then the handle goes (the arrays of
+  !! kpp_3d_fields the library pinned are released with it).
   subroutine mckpp_hip_detach()
     integer(c_int) :: rc
+    if (resident) call mckpp_hip_sync_host()
     if (c_associated(mckpp_hip_multi_handle)) rc = mckpp_hip_multi_finalize(mckpp_hip_multi_handle)
     mckpp_hip_multi_handle = c_null_ptr
     mckpp_hip_handle = c_null_ptr
     resident = .false.
+    host_behind = 0
   end subroutine mckpp_hip_detach
 
 end module mckpp_hip_session

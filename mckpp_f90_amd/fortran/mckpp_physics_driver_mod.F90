@@ -3,7 +3,8 @@
 !! (src/mckpp_physics_driver_mod.F90:15-73).  The OpenMP column loop with its
 !! per-column 3D<->1D copies is replaced by one kernel launch per GPU over its
 !! share of the run_physics columns (mckpp_hip_session: mckpp_hip_ndevices); state stays in HBM between calls and only the field
-!! groups in mckpp_hip_output_mask come back each step.
+!! groups in mckpp_hip_output_mask come back each step (default: the scalar group; mckpp_hip_sync_host brings the
+!! rest back when the host wants to read it, mckpp_physics_finalize does so before it lets the devices go).
 module mckpp_physics_driver_mod
   use iso_c_binding, only: c_int
   use mckpp_data_fields, only: kpp_3d_fields, kpp_const_fields
@@ -28,6 +29,7 @@ contains
       end if
       call mckpp_hip_check(mckpp_hip_multi_bottomtemp(mckpp_hip_multi_handle, kpp_3d_fields%bottom_temp), 'mckpp_hip_bottomtemp')
     end if
+    call mckpp_hip_device_advanced()
     call mckpp_hip_pull_state(mckpp_hip_output_mask)
   end subroutine mckpp_physics_driver
 

@@ -168,3 +168,37 @@ def test_fortran_driver_on_several_device_shards(built, tmp_path, ncol, nz, shar
     ocean = k3.run_physics != 0
     assert np.array_equal(got["g_hmix"][ocean], k3.hmix[ocean]) and np.all(got["g_hmix"][~ocean] == -1)
     assert np.array_equal(got["g_T"][ocean], k3.X[ocean, :, 0]) and np.all(got["g_T"][~ocean] == -1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags,shards,nz", [(16, 0, 40), (16, 3, 60), (32, 2, 69)])
+def test_fortran_forced_run_and_output_windows_on_all_devices(built, tmp_path, flags, shards, nz):
+    """kpp_driver with its time loop on the devices: mckpp_hip_all_set_flux_series + mckpp_hip_all_run_forced
+    (the reference's loop, src/mckpp_ocean_model_3D.F90:38-58, one call for all steps and all shards), and - flag
+    32 - step by step with an output window on every shard (mean hmix, maximum T fetched through the gather).
+    The per-step download is the scalar group only (the session's default); mckpp_hip_sync_host brings the rest
+    back before the driver writes its output.  Against mckpp_fluxes + mckpp_physics_driver per step on the C-ABI."""
+    import mckpp_f90_amd as mk
+
+    ncol, nsteps = 211, 4
+    kc, k3 = cm.make_hip_case(ncol, nz, land_every=6)
+    sf = cm.synth.forcing(ncol, "bench")
+    _write_case(tmp_path / "case.bin", kc, k3, sf, nsteps, 0, flags=flags, shards=shards)
+    r = subprocess.run([DRIVER, str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = _read_out(tmp_path / "out.bin", kc, ncol, gather=bool(flags & 32))
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    cm.set_forcing_3d(k3, sf)
+    one = np.ones(ncol)
+    hm, tmax = np.zeros(ncol), None
+    for nt in range(1, nsteps + 1):
+        ctx.fluxes(nt, 0.01 * one, 0 * one, 200 * one, 0 * one, -150 * one, 0 * one, 6e-5 * one, 0 * one)
+        mk.mckpp_physics_driver(k3, kc, nt, new_forcing=False)
+        hm = hm + k3.hmix
+        tmax = k3.X[:, :, 0].copy() if tmax is None else np.maximum(tmax, k3.X[:, :, 0])
+    for n in ("U", "X", "Us", "Xs", "hmix", "kmix", "hmixd", "Tref", "Ssurf", "old", "new_", "difm", "ghat", "rho"):
+        assert np.array_equal(got[n], getattr(k3, n)), n
+    if flags & 32:
+        ocean = k3.run_physics != 0
+        assert np.array_equal(got["g_hmix"][ocean], (hm / nsteps)[ocean]) and np.all(got["g_hmix"][~ocean] == -1)
+        assert np.array_equal(got["g_T"][ocean], tmax[ocean]) and np.all(got["g_T"][~ocean] == -1)
