@@ -9,8 +9,22 @@ collective (weak scaling: 1e5 columns per GPU); a torch.distributed (RCCL)
 gather of hmix to rank 0 runs after the timed region only, as the diagnostics
 gather the path has.
 
+`python bench.py --gpus N` with N > 1 and no launcher around it starts its own N ranks
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...`, rendezvous on 127.0.0.1) before this
+process has touched torch or the GPU, and relays rank 0's line and exit code; under a launcher (RANK /
+WORLD_SIZE set) it is one of the ranks.  `--total-ncol T` divides T columns over the ranks instead
+(strong scaling, e.g. `--total-ncol 100000 --nz 100` = BASELINE configs[3]).  The N > 1 line also carries the
+per-rank step times, the RCCL world size seen by a device all-reduce, the time of the diagnostics gather (hmix,
+T) and a `single_process` block: the same shards behind ONE handle of the C-ABI (mckpp_hip_multi_*), all N GPUs
+driven from rank 0's process while the other ranks wait.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`,
 plus (N=1 only, never part of `value`):
+  sustained            400 more steps of the headline workload in one call (the headline's 40 steps are a
+                       0.14 s burst)
+  drop_in              the reference-shaped host loop through the C-ABI, per step: mckpp_hip_set_forcing +
+                       mckpp_hip_step + mckpp_hip_download of the scalar group / the restart set / every
+                       field (PCIe-inclusive; never `value`)
   diurnal              the same columns through mckpp_hip_run_forced for 48 hourly steps of the
                        SURVEY 8(d) diurnal short-wave cycle (pass counts vary, kbl moves), GPU and CPU port
   other_shapes         1e5 x 69 levels on the stretched grid with 35 % land at dto = 1200 s (configs[4] shape)
@@ -22,6 +36,8 @@ import argparse
 import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -229,6 +245,107 @@ def committed_counters(ncol, nz, kernel_name, build_id):
     return None, None, "no record for this workload in profiles/counters.json"
 
 
+def launch_ranks(ngpus, argv, dry_run=False):
+    """`bench.py --gpus N` started plainly: run the N ranks under torch.distributed.run as a child process and relay
+    rank 0's JSON line and the exit code.  Nothing here imports torch or loads the library - a process that has
+    initialised the GPU must not be the one that starts the ranks."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    if dry_run:
+        print(json.dumps({"cmd": cmd, "torch_imported": "torch" in sys.modules,
+                          "library_loaded": "mckpp_f90_amd" in sys.modules}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if r.returncode == 0 and line is None:
+        print("bench.py: the ranks finished without printing a result line", file=sys.stderr)
+        return 1
+    return r.returncode
+
+
+def drop_in_block(mk, ctx, k3, nt0, nocean, masks):
+    """The reference-shaped host loop on the C-ABI, one model step at a time: new forcing up
+    (mckpp_hip_set_forcing: 6 doubles per column), mckpp_hip_step, the field groups of `mask` back into the
+    Fortran-ordered host arrays (mckpp_hip_download)."""
+    out = {}
+    nt = nt0
+    for name, mask, steps in masks:
+        ctx.download(k3, mask)      # first use pins the arrays; not timed
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            nt += 1
+            ctx.set_forcing(k3.sflux)
+            ctx.step(nt, 1)
+            ctx.download(k3, mask)
+        dt = time.perf_counter() - t0
+        out[name] = {"value": nocean * steps / dt, "unit": "column-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps}
+    return out, nt
+
+
+def single_process_block(mk, cm, sharding, kc_args, ncol_per_gpu, world, devices, steps, warmup, diag, strong_total):
+    """The same shards behind one handle of the C-ABI (mckpp_hip_multi_*): all GPUs driven from this process."""
+    import psutil
+
+    ntotal = strong_total if strong_total else ncol_per_gpu * world
+    note = None
+    need = ntotal * (kc_args["nz"] + 1) * 8 * 60          # host arrays of Kpp3dFields, generously
+    avail = psutil.virtual_memory().available
+    if need > 0.4 * avail:
+        scale = max(1, int(need / (0.4 * avail)) + 1)
+        ntotal = max(world, ntotal // scale)
+        note = f"host memory: {ntotal} columns in all instead of the ranks' total"
+    kc, k3 = cm.make_hip_case(ntotal, kc_args["nz"], grid=kc_args["grid"], dto=kc_args["dto"])
+    m = mk.MckppHipMulti(kc, devices)
+    m.upload(k3)
+    m.set_diagnostics(diag)
+    m.init_ocean(0)
+    cm.set_forcing_3d(k3, cm.synth.forcing(ntotal, "bench"))
+    m.set_forcing(k3.sflux)
+    m.step(1, SPINUP + warmup)
+    m.synchronize()
+    t0 = time.perf_counter()
+    m.step(1 + SPINUP + warmup, steps)
+    m.synchronize()
+    dt = time.perf_counter() - t0
+    hm = np.zeros(ntotal, order="F")
+    T = np.zeros((ntotal, kc_args["nz"] + 1), order="F")
+    m.gather(4, 0, hm)          # first use pins the arrays and builds the root's buffers; not timed
+    m.gather(2, 0, T)
+    t0 = time.perf_counter()
+    m.gather(4, 0, hm)
+    t_h = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    m.gather(2, 0, T)
+    t_T = time.perf_counter() - t0
+    ok = bool(np.isfinite(hm).all() and (hm > 0).all() and np.isfinite(T).all())
+    out = {
+        "what": "mckpp_hip_multi_step on all shards from one process (rank 0's), then mckpp_hip_multi_gather of hmix and T "
+                "to shard 0 (peer copies over the GPU interconnect, all in flight at once) and to the host",
+        "devices": [int(d) for d in devices], "columns": int(ntotal), "value": ntotal * steps / dt, "unit": "column-steps/s",
+        "ms_per_step": dt / steps * 1e3, "gather_hmix_ms": t_h * 1e3, "gather_T_ms": t_T * 1e3,
+        "gather_T_GBps_to_host": T.nbytes / t_T / 1e9, "finite": ok,
+    }
+    if note:
+        out["note"] = note
+    m.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,14 +361,19 @@ def main():
     ap.add_argument("--grid", default="uniform")
     ap.add_argument("--dto", type=float, default=3600.0)
     ap.add_argument("--land", type=float, default=0.0, help="fraction of land points (run_physics = .F.)")
+    ap.add_argument("--total-ncol", type=int, default=0,
+                    help="strong scaling: this many columns in all, divided over the GPUs (overrides --ncol)")
+    ap.add_argument("--sustained-steps", type=int, default=400)
+    ap.add_argument("--print-launch", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:   # started plainly: become the launcher of the N ranks
+        argv = [x for x in sys.argv[1:] if x != "--print-launch"]
+        raise SystemExit(launch_ranks(a.gpus, argv, dry_run=a.print_launch))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {a.gpus}")
 
     import torch
@@ -279,11 +401,13 @@ def main():
     import mckpp_f90_amd as mk
     from mckpp_f90_amd import api as mkapi
 
-    ncol, nz = a.ncol, a.nz
-    ntotal = ncol * world
     from mckpp_f90_amd import sharding
 
+    nz = a.nz
+    strong = a.total_ncol > 0
+    ntotal = a.total_ncol if strong else a.ncol * world
     idx = sharding.shard_indices(ntotal, rank, world)   # round-robin shard of one global closed-form set
+    ncol = len(idx)
     kc, k3 = cm.make_hip_case(ncol, nz, grid=a.grid, dto=a.dto, index=idx, ntotal=ntotal)
     if a.land > 0:
         land = (np.arange(ncol) * 7) % 20 < int(round(20 * a.land))
@@ -311,19 +435,53 @@ def main():
     st, nflag, npass = ctx.status()
     ocean = k3.run_physics != 0
     ncols_all = nocean
+    multi = None
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev if coll_dev is not None else "cpu")
+        cdev = coll_dev if coll_dev is not None else "cpu"
+        mine = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(x.item()) / a.steps * 1e3 for x in every]
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        c = torch.tensor([float(nocean)], dtype=torch.float64, device=coll_dev if coll_dev is not None else "cpu")
+        c = torch.tensor([float(nocean)], dtype=torch.float64, device=cdev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         ncols_all = int(c.item())
-        # diagnostics gather (not timed): hmix of every rank's columns to rank 0 over RCCL
-        ctx.download(k3, mk.api.F_SCALARS)
+        ones = torch.ones(1, dtype=torch.float64, device=cdev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)     # ranks that took part in a collective on `cdev` tensors
+        # diagnostics gather (not timed into `value`): hmix and T of every rank's columns to rank 0
+        barrier()
+        t0 = time.perf_counter()
+        ctx.download(k3, mk.api.F_SCALARS | mk.api.F_PROFILES)
+        t_down = time.perf_counter() - t0
+        barrier()
+        t0 = time.perf_counter()
         parts = sharding.gather_to_root(k3.hmix, dist, device=coll_dev)
+        if coll_dev is not None:
+            torch.cuda.synchronize()
+        t_h = time.perf_counter() - t0
+        barrier()
+        t0 = time.perf_counter()
+        tparts = sharding.gather_to_root(np.ascontiguousarray(k3.X[:, :, 0]), dist, device=coll_dev)
+        if coll_dev is not None:
+            torch.cuda.synchronize()
+        t_T = time.perf_counter() - t0
+        multi = {
+            "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
+            "backend": dist.get_backend(), "rccl_ranks": int(round(float(ones.item()))) if backend == "nccl" else None,
+            "collective_ranks": int(round(float(ones.item()))), "world_size": dist.get_world_size(),
+            "gather": {"what": "hmix (8 B/column) and T (8 (nz+1) B/column) of every rank to rank 0, torch.distributed.gather on "
+                               + ("device tensors (RCCL over xGMI)" if backend == "nccl" else "host tensors (gloo rehearsal)"),
+                       "download_scalars_and_profiles_ms": t_down * 1e3, "hmix_ms": t_h * 1e3, "T_ms": t_T * 1e3,
+                       "T_bytes_per_rank": int(ncol * (nz + 1) * 8)},
+        }
         if rank == 0:
             hmix_all = sharding.unshard(parts, ntotal)
+            T_all = sharding.unshard(tparts, ntotal)
             assert np.isfinite(hmix_all).all() and hmix_all.shape == (ntotal,)
+            assert np.isfinite(T_all).all() and T_all.shape == (ntotal, nz + 1)
+            multi["gather"]["checked"] = "hmix and T of all ranks finite and complete on rank 0"
 
     out = None
     if rank == 0:
@@ -337,12 +495,14 @@ def main():
             "unit": "column-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"{ncol} columns x {nz} levels per GPU, full ocnstep (kppmix stack + swfrac + "
+                "workload": (f"{ntotal} columns x {nz} levels in all, {ncol} per GPU" if strong else
+                             f"{ncol} columns x {nz} levels per GPU") + ", full ocnstep (kppmix stack + swfrac + "
                             "state equation + tridiagonal solves), bench forcing mix (1/3 stable, 1/3 convective, "
-                            f"1/3 windy), dto={a.dto:.0f} s, BASELINE configs[2]",
+                            f"1/3 windy), dto={a.dto:.0f} s, "
+                            + ("BASELINE configs[3] shape" if strong and nz == 100 else "BASELINE configs[2]"),
                 "columns_per_gpu": ncol, "ocean_columns_per_gpu": nocean, "levels": nz,
                 "diagnostics_written": bool(a.diag), "spin_up_steps": SPINUP,
                 "sharding": f"columns round-robin over {world} GPU(s), no data-path collective",
@@ -362,11 +522,31 @@ def main():
         }
         if why_not:
             out["roofline"]["counters_note"] = why_not
+        if multi is not None:
+            out["multi_gpu"] = multi
+
+    if dist is not None:   # the same shards behind one handle, from rank 0's process; the other ranks wait
+        barrier()
+        if rank == 0:
+            devs = [0] * world if os.environ.get("MCKPP_BENCH_SHARE_GPU") else list(range(world))
+            try:
+                out["multi_gpu"]["single_process"] = single_process_block(
+                    mk, cm, sharding, {"nz": nz, "grid": a.grid, "dto": a.dto}, a.ncol, world, devs, a.steps, a.warmup,
+                    a.diag, a.total_ncol)
+            except Exception as e:   # noqa: BLE001 - the ranks' own result stands without it
+                out["multi_gpu"]["single_process"] = {"error": f"{type(e).__name__}: {e}"}
+        barrier()
 
     extras = world == 1 and not a.no_extras
     if extras:
+        nt_s = SPINUP + a.warmup + a.steps
+        # ---- drop-in host loop: forcing up, one step, field groups down, every step ----
+        out["drop_in"], nt_s = drop_in_block(mk, ctx, k3, nt_s, nocean, (
+            ("scalars", mk.api.F_SCALARS, 20), ("restart_set", mk.api.F_RESTART, 6), ("all_fields", mk.api.F_ALL, 3)))
+        out["drop_in"]["what"] = ("per model step mckpp_hip_set_forcing + mckpp_hip_step + mckpp_hip_download(mask) into "
+                                  "Fortran-ordered host arrays (pinned on first use); PCIe-inclusive, never `value`")
         # ---- diurnal leg: the reference's forced time loop from resident flux records ----
-        nt0 = SPINUP + a.warmup + a.steps
+        nt0 = nt_s
         series = diurnal_series(ncol, nt0 + 1, DIURNAL_STEPS, a.dto, index=idx)
         ctx.set_flux_series(nt0, series)
         del series
@@ -405,9 +585,35 @@ def main():
             "nz60": {"value": small60["value"], "ms_per_step": small60["ms_per_step"],
                      "ratio_to_1e5": small60["value"] / out["value"]},
         }
+    if extras and a.sustained_steps > 0:
+        # ---- sustained: the headline workload again, many steps in one call.  Last of the GPU legs: after ~1 s of
+        # continuous fp64 work the device settles on a lower clock, which would colour every leg run after it.
+        kc, k3 = cm.make_hip_case(ncol, nz, grid=a.grid, dto=a.dto, index=idx, ntotal=ntotal)
+        ctx = mk.MckppHip(kc, device=dev_index)
+        ctx.upload(k3)
+        ctx.set_diagnostics(a.diag)
+        ctx.init_ocean(0)
+        cm.set_forcing_3d(k3, cm.synth.forcing(ncol, "bench", index=idx))
+        ctx.set_forcing(k3.sflux)
+        ctx.step(1, SPINUP + a.warmup)
+        ctx.synchronize()
+        dts, kern_ss = time_steps(ctx, 1 + SPINUP + a.warmup, a.sustained_steps, barrier)
+        quarter = max(1, a.sustained_steps // 4)
+        dtq, _ = time_steps(ctx, 1 + SPINUP + a.warmup + a.sustained_steps, quarter, barrier)
+        out["sustained"] = {"steps": a.sustained_steps, "value": nocean * a.sustained_steps / dts, "unit": "column-steps/s",
+                            "ms_per_step": dts / a.sustained_steps * 1e3, "kernel_avg_ms": kern_ss * 1e3,
+                            "ms_per_step_of_the_next_%d_steps" % quarter: dtq / quarter * 1e3,
+                            "note": "same workload and state as the headline, one call; the difference to the headline is the "
+                                    "device's clock under sustained fp64 load, not the work (6 passes per column-step either way)"}
+        ctx.close()
+        del ctx, k3, kc
+        gc.collect()
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             cb = cpu_baseline(ncol, nz, a.warmup, a.cpu_steps, a.cpu_stride, 4, SPINUP + a.warmup + a.steps, a.dto)
+            if extras:
+                cb["diurnal"]["note"] = ("the CPU leg runs the diurnal steps right after the headline's; the GPU leg after its "
+                                         "sustained and drop-in legs (later model steps of the same cycle)")
             if extras:
                 out["diurnal"]["cpu_port"] = cb.pop("diurnal")
             else:

@@ -100,6 +100,11 @@ hipError_t mckpp_launch_exp_batch(int64_t n, const double *x, double *y, hipStre
 hipError_t mckpp_launch_bottomtemp(const mckpp_kparams &p, const double *bt, hipStream_t stream);
 hipError_t mckpp_launch_fluxes(const mckpp_kparams &p, int ntime, const double *f8, int l_rest, double flsn,
                                double el, hipStream_t stream);
+// record slots a download wants as (npts) slabs: doubles of cs[], ints of ci[]
+struct mckpp_pack_list { int nd, ni; int dslot[MCKPP_CS]; int islot[MCKPP_CI]; };
+hipError_t mckpp_launch_unpack_sflux(const double *slabs, const int *ipt, double *cs, int64_t ncol, int64_t npts, hipStream_t stream);
+hipError_t mckpp_launch_pack_records(const double *cs, const int *ci, const int *ipt, int64_t ncol, int64_t npts,
+                                     const mckpp_pack_list &l, double *dout, int *iout, hipStream_t stream);
 hipError_t mckpp_launch_out_sample(const double *src, int src_ld, int src_off, const double *cs, int add_sref,
                                    int64_t ncol, int nlev, int ld_out, double *sum, double *mn, double *mx, int first,
                                    double *inst, hipStream_t stream);

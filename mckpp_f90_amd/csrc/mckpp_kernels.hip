@@ -250,6 +250,45 @@ hipError_t mckpp_launch_bottomtemp(const mckpp_kparams &p, const double *bt, hip
   return hipGetLastError();
 }
 
+// The per-column records <-> the caller's (npts) arrays without a host loop, for a context whose columns are all of
+// the grid's points or not: forcing slabs sflux(:,1:6,5,0) (six contiguous (npts) slabs) into the records' flux
+// slots, and selected record slots out into (npts) slabs in 3-D order (land points of the slabs are not written).
+__global__ __launch_bounds__(256) void k_unpack_sflux(const double *__restrict__ slabs, const int *__restrict__ ipt,
+                                                      double *__restrict__ cs, int64_t ncol, int64_t npts)
+{
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncol) return;
+  const int64_t i = ipt[c];
+#pragma unroll
+  for (int m = 0; m < 6; ++m) cs[c * MCKPP_CS + CS_SFLUX1 + m] = slabs[i + npts * m];
+}
+
+__global__ __launch_bounds__(256) void k_pack_records(const double *__restrict__ cs, const int *__restrict__ ci,
+                                                      const int *__restrict__ ipt, int64_t ncol, int64_t npts,
+                                                      mckpp_pack_list l, double *__restrict__ dout, int *__restrict__ iout)
+{
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncol) return;
+  const int64_t i = ipt[c];
+  for (int j = 0; j < l.nd; ++j) dout[i + npts * j] = cs[c * MCKPP_CS + l.dslot[j]];
+  for (int j = 0; j < l.ni; ++j) iout[i + npts * j] = ci[c * MCKPP_CI + l.islot[j]];
+}
+
+hipError_t mckpp_launch_unpack_sflux(const double *slabs, const int *ipt, double *cs, int64_t ncol, int64_t npts, hipStream_t stream)
+{
+  if (ncol <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_unpack_sflux, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, stream, slabs, ipt, cs, ncol, npts);
+  return hipGetLastError();
+}
+
+hipError_t mckpp_launch_pack_records(const double *cs, const int *ci, const int *ipt, int64_t ncol, int64_t npts,
+                                     const mckpp_pack_list &l, double *dout, int *iout, hipStream_t stream)
+{
+  if (ncol <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pack_records, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, stream, cs, ci, ipt, ncol, npts, l, dout, iout);
+  return hipGetLastError();
+}
+
 hipError_t mckpp_launch_out_sample(const double *src, int src_ld, int src_off, const double *cs, int add_sref,
                                    int64_t ncol, int nlev, int ld_out, double *sum, double *mn, double *mx, int first,
                                    double *inst, hipStream_t stream)

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -37,6 +38,29 @@ int fail(const char *fmt, ...)
     hipError_t e_ = (expr);                                                              \
     if (e_ != hipSuccess) return fail("%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
+
+// The host loops over the columns (compaction of the forcing, scatter of the per-column records) on a few
+// threads: at 1e5 columns they are milliseconds of a 3.4 ms step otherwise.  MCKPP_HIP_HOST_THREADS sets the count
+// (default: the machine's, at most 8).
+template <class F>
+void for_columns(int64_t n, F &&body)
+{
+  static const int want = [] {
+    const char *e = getenv("MCKPP_HIP_HOST_THREADS");
+    int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    return t < 1 ? 1 : t > 8 ? 8 : t;
+  }();
+  const int nt = n < 32768 ? 1 : want;
+  if (nt == 1) { body((int64_t)0, n); return; }
+  std::vector<std::thread> th;
+  const int64_t chunk = (n + nt - 1) / nt;
+  for (int t = 1; t < nt; ++t) {
+    const int64_t a = t * chunk, b = a + chunk < n ? a + chunk : n;
+    if (a < b) th.emplace_back([&body, a, b] { body(a, b); });
+  }
+  body((int64_t)0, chunk < n ? chunk : n);
+  for (auto &x : th) x.join();
+}
 
 // profile rows (element j <-> level j+1)
 enum { P_U = 0, P_V, P_T, P_S, P_US0, P_US1, P_VS0, P_VS1, P_TS0, P_TS1, P_SS0, P_SS1, P_UINIT, P_VINIT, P_COUNT };
@@ -111,11 +135,15 @@ struct mckpp_hip_ctx {
   hipEvent_t ev_lay[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};   // layout kernel done / transfer done, per buffer
   unsigned xfer_seq = 0;
   std::vector<std::pair<const void *, size_t>> pinned;   // caller arrays this context registered
+  std::vector<std::pair<const void *, size_t>> unpinnable;   // ... and those it could not (not tried again)
   // pinned host images of the column records and of the forcing staging
   double *h_cs = nullptr, *h_f = nullptr;
   int *h_ci = nullptr;
   size_t h_f_elems = 0;
   hipEvent_t ev_f = nullptr;
+  // record slots as (npts) slabs in 3-D order, packed on the device (a context that holds every grid point)
+  double *d_pack = nullptr;
+  int *d_ipack = nullptr;
   int diag = 1;
   // optional-physics contexts: the relaxation / correction / advection inputs come with upload (or
   // update_ancillaries); load_restart does not carry them, so stepping is refused until they are there
@@ -328,6 +356,9 @@ static void free_state(mckpp_hip_ctx *h)
   h->d_cs = nullptr; h->d_ci = nullptr; h->d_ipt = nullptr; h->d_stage = nullptr;
   h->stage_elems = 0;
   for (int b = 0; b < 2; ++b) { if (h->d_xfer[b]) hipFree(h->d_xfer[b]); h->d_xfer[b] = nullptr; h->xfer_elems[b] = 0; }
+  if (h->d_pack) hipFree(h->d_pack);
+  if (h->d_ipack) hipFree(h->d_ipack);
+  h->d_pack = nullptr; h->d_ipack = nullptr;
   if (h->h_cs) hipHostFree(h->h_cs);
   if (h->h_ci) hipHostFree(h->h_ci);
   if (h->h_f) hipHostFree(h->h_f);
@@ -341,6 +372,7 @@ static void unpin_all(mckpp_hip_ctx *h)
   for (auto &r : h->pinned)
     if (hipHostUnregister(const_cast<void *>(r.first)) != hipSuccess) (void)hipGetLastError();
   h->pinned.clear();
+  h->unpinnable.clear();
 }
 
 int mckpp_hip_finalize(mckpp_hip_handle h)
@@ -394,11 +426,14 @@ static bool no_host_register()
 // is already pinned (by another context, or by the caller) or cannot be is simply transferred as it is.
 static void pin_host(mckpp_hip_ctx *h, const void *ptr, size_t bytes)
 {
-  if (!ptr || bytes < ((size_t)1 << 20) || no_host_register()) return;
-  for (auto &r : h->pinned)
-    if (r.first == ptr && r.second >= bytes) return;
+  if (!ptr || bytes < ((size_t)1 << 18) || no_host_register()) return;
+  const char *b = static_cast<const char *>(ptr);
+  for (auto &r : h->pinned)        // inside a range this context pinned
+    if (b >= static_cast<const char *>(r.first) && b + bytes <= static_cast<const char *>(r.first) + r.second) return;
+  for (auto &r : h->unpinnable)    // tried before: pinned by someone else, or cannot be
+    if (r.first == ptr && r.second == bytes) return;
   if (hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterPortable) == hipSuccess) h->pinned.emplace_back(ptr, bytes);
-  else (void)hipGetLastError();
+  else { (void)hipGetLastError(); h->unpinnable.emplace_back(ptr, bytes); }
 }
 
 static int ensure_xfer(mckpp_hip_ctx *h, unsigned b, size_t elems)
@@ -416,12 +451,15 @@ static int ensure_xfer(mckpp_hip_ctx *h, unsigned b, size_t elems)
 
 // host Fortran slab (npts x nlev, from `src`) -> device rows.  Queued: the copy on the copy stream, the layout
 // kernel behind it on the context's stream; the caller waits for the stream before `src` may change.
-static int up_rows(mckpp_hip_ctx *h, const double *src, int nlev, double *dst, int dst_off)
+static int up_rows(mckpp_hip_ctx *h, const double *src, int nlev, double *dst, int dst_off, const double *whole = nullptr,
+                   size_t whole_elems = 0)
 {
   const size_t n = (size_t)h->npts * nlev;
   const unsigned b = h->xfer_seq++ & 1u;
   if (ensure_xfer(h, b, n)) return -1;
-  pin_host(h, src, n * sizeof(double));
+  // the array the slab belongs to is pinned as a whole (slabs of one array share pages at their boundaries)
+  if (whole) pin_host(h, whole, whole_elems * sizeof(double));
+  else pin_host(h, src, n * sizeof(double));
   HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_lay[b], 0));   // the layout kernel that last read this buffer
   HIPCHK(hipMemcpyAsync(h->d_xfer[b], src, n * sizeof(double), hipMemcpyHostToDevice, h->copy_stream));
   HIPCHK(hipEventRecord(h->ev_copy[b], h->copy_stream));
@@ -434,12 +472,14 @@ static int up_rows(mckpp_hip_ctx *h, const double *src, int nlev, double *dst, i
 // device rows -> host Fortran slab; entries of non-resident (land) columns keep their host values.  Queued: the
 // layout kernel on the context's stream, the copy to the host behind it on the copy stream; xfer_finish() before
 // the caller reads `dst`.
-static int down_rows(mckpp_hip_ctx *h, const double *src, int src_ld, int src_off, int nlev, double *dst)
+static int down_rows(mckpp_hip_ctx *h, const double *src, int src_ld, int src_off, int nlev, double *dst,
+                     const double *whole = nullptr, size_t whole_elems = 0)
 {
   const size_t n = (size_t)h->npts * nlev;
   const unsigned b = h->xfer_seq++ & 1u;
   if (ensure_xfer(h, b, n)) return -1;
-  pin_host(h, dst, n * sizeof(double));
+  if (whole) pin_host(h, whole, whole_elems * sizeof(double));
+  else pin_host(h, dst, n * sizeof(double));
   HIPCHK(hipStreamWaitEvent(h->stream, h->ev_copy[b], 0));   // the transfer that last read this buffer
   if (h->ncol < h->npts)
     HIPCHK(hipMemcpyAsync(h->d_xfer[b], dst, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -565,25 +605,25 @@ int mckpp_hip_upload(mckpp_hip_handle h, const mckpp_state_ptrs_c *s)
   if (ncol == 0) return 0;
   HIPCHK(hipMemcpyAsync(h->d_ipt, ipt.data(), (size_t)ncol * sizeof(int), hipMemcpyHostToDevice, h->stream));
   const size_t slab = (size_t)npts * nzp1;
-  if (up_rows(h, s->U, nzp1, h->d_prof[P_U], 0)) return -1;
-  if (up_rows(h, s->U + slab, nzp1, h->d_prof[P_V], 0)) return -1;
-  if (up_rows(h, s->X, nzp1, h->d_prof[P_T], 0)) return -1;
-  if (up_rows(h, s->X + slab, nzp1, h->d_prof[P_S], 0)) return -1;
+  if (up_rows(h, s->U, nzp1, h->d_prof[P_U], 0, s->U, 2 * slab)) return -1;
+  if (up_rows(h, s->U + slab, nzp1, h->d_prof[P_V], 0, s->U, 2 * slab)) return -1;
+  if (up_rows(h, s->X, nzp1, h->d_prof[P_T], 0, s->X, 2 * slab)) return -1;
+  if (up_rows(h, s->X + slab, nzp1, h->d_prof[P_S], 0, s->X, 2 * slab)) return -1;
   if (s->Us) {   // Us(npts,nzp1,nvel,0:1)
-    if (up_rows(h, s->Us + 0 * slab, nzp1, h->d_prof[P_US0], 0)) return -1;
-    if (up_rows(h, s->Us + 1 * slab, nzp1, h->d_prof[P_VS0], 0)) return -1;
-    if (up_rows(h, s->Us + 2 * slab, nzp1, h->d_prof[P_US1], 0)) return -1;
-    if (up_rows(h, s->Us + 3 * slab, nzp1, h->d_prof[P_VS1], 0)) return -1;
+    if (up_rows(h, s->Us + 0 * slab, nzp1, h->d_prof[P_US0], 0, s->Us, 4 * slab)) return -1;
+    if (up_rows(h, s->Us + 1 * slab, nzp1, h->d_prof[P_VS0], 0, s->Us, 4 * slab)) return -1;
+    if (up_rows(h, s->Us + 2 * slab, nzp1, h->d_prof[P_US1], 0, s->Us, 4 * slab)) return -1;
+    if (up_rows(h, s->Us + 3 * slab, nzp1, h->d_prof[P_VS1], 0, s->Us, 4 * slab)) return -1;
   }
   if (s->Xs) {
-    if (up_rows(h, s->Xs + 0 * slab, nzp1, h->d_prof[P_TS0], 0)) return -1;
-    if (up_rows(h, s->Xs + 1 * slab, nzp1, h->d_prof[P_SS0], 0)) return -1;
-    if (up_rows(h, s->Xs + 2 * slab, nzp1, h->d_prof[P_TS1], 0)) return -1;
-    if (up_rows(h, s->Xs + 3 * slab, nzp1, h->d_prof[P_SS1], 0)) return -1;
+    if (up_rows(h, s->Xs + 0 * slab, nzp1, h->d_prof[P_TS0], 0, s->Xs, 4 * slab)) return -1;
+    if (up_rows(h, s->Xs + 1 * slab, nzp1, h->d_prof[P_SS0], 0, s->Xs, 4 * slab)) return -1;
+    if (up_rows(h, s->Xs + 2 * slab, nzp1, h->d_prof[P_TS1], 0, s->Xs, 4 * slab)) return -1;
+    if (up_rows(h, s->Xs + 3 * slab, nzp1, h->d_prof[P_SS1], 0, s->Xs, 4 * slab)) return -1;
   }
   if (s->U_init) {
-    if (up_rows(h, s->U_init, nzp1, h->d_prof[P_UINIT], 0)) return -1;
-    if (up_rows(h, s->U_init + slab, nzp1, h->d_prof[P_VINIT], 0)) return -1;
+    if (up_rows(h, s->U_init, nzp1, h->d_prof[P_UINIT], 0, s->U_init, 2 * slab)) return -1;
+    if (up_rows(h, s->U_init + slab, nzp1, h->d_prof[P_VINIT], 0, s->U_init, 2 * slab)) return -1;
   }
   if (h->ext && upload_ancillaries(h, s)) return -1;
   std::vector<double> cs((size_t)ncol * MCKPP_CS, 0.0);
@@ -644,17 +684,17 @@ int mckpp_hip_set_forcing(mckpp_hip_handle h, const double *sflux)
   if (!h || !sflux) return fail("mckpp_hip_set_forcing: null argument");
   if (h->ncol == 0) return 0;
   HIPCHK(hipSetDevice(h->device));
-  if (ensure_host_f(h, (size_t)h->ncol * 6)) return -1;
-  HIPCHK(hipEventSynchronize(h->ev_f));   // the previous transfer out of the staging array
-  double *f6 = h->h_f;
-  const int64_t fl_i = h->npts, fl_5 = h->npts * (int64_t)h->c.nsflxs * 4;
-  for (int m = 0; m < 6; ++m) {   // one pass per flux component: each source array is read front to back
-    const double *src = sflux + fl_i * m + fl_5;
-    for (int64_t c = 0; c < h->ncol; ++c) f6[(size_t)c * 6 + m] = src[h->ipt[c]];
-  }
-  HIPCHK(hipMemcpy2DAsync(h->d_cs + CS_SFLUX1, MCKPP_CS * sizeof(double), f6, 6 * sizeof(double),
-                          6 * sizeof(double), (size_t)h->ncol, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipEventRecord(h->ev_f, h->stream));   // queued ahead of the next step on the same stream; no host wait
+  // sflux(:,1:6,5,0) is six contiguous (npts) slabs: up as they are (from the caller's array, pinned on first
+  // use), compacted into the records' flux slots on the device.  The call returns when the slabs have been read -
+  // the caller may rewrite its array - not when the records are updated (that is stream-ordered before the step).
+  const size_t n6 = (size_t)h->npts * 6;
+  const double *slabs = sflux + h->npts * (int64_t)h->c.nsflxs * 4;
+  if (ensure_stage(h, n6)) return -1;
+  pin_host(h, sflux, (size_t)h->npts * h->c.nsflxs * 5 * (size_t)(h->c.njdt + 1) * sizeof(double));
+  HIPCHK(hipMemcpyAsync(h->d_stage, slabs, n6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipEventRecord(h->ev_f, h->stream));
+  HIPCHK(mckpp_launch_unpack_sflux(h->d_stage, h->d_ipt, h->d_cs, h->ncol, h->npts, h->stream));
+  HIPCHK(hipEventSynchronize(h->ev_f));
   return 0;
 }
 
@@ -903,28 +943,33 @@ int mckpp_hip_last_kernel_ms(mckpp_hip_handle h, double *ms, int32_t *nlaunch)
 // in the caller's arrays.  The list depends on the mask and the pointers only, so the contexts of a multi-device
 // handle produce lists that correspond entry by entry.
 namespace {
-struct row_xfer { const double *dev; int src_off, nlev; double *host; };
+struct row_xfer { const double *dev; int src_off, nlev; double *host; const double *whole; size_t whole_elems; };
 }
 
 static void download_plan(mckpp_hip_ctx *h, const mckpp_state_ptrs_c *s, uint32_t mask, std::vector<row_xfer> &plan)
 {
   const int nzp1 = h->nzp1, nz = h->nz;
   const size_t slab = (size_t)h->npts * nzp1;
-  auto add = [&](const double *dev, int off, int nlev, double *host) { plan.push_back({dev, off, nlev, host}); };
+  const double *whole = nullptr;   // the array the next slabs belong to, and its size: what gets pinned
+  size_t whole_elems = 0;
+  auto add = [&](const double *dev, int off, int nlev, double *host) { plan.push_back({dev, off, nlev, host, whole, whole_elems}); };
   if ((mask & MCKPP_F_PROFILES)) {
-    if (s->U) { add(h->d_prof[P_U], 0, nzp1, s->U); add(h->d_prof[P_V], 0, nzp1, s->U + slab); }
-    if (s->X) { add(h->d_prof[P_T], 0, nzp1, s->X); add(h->d_prof[P_S], 0, nzp1, s->X + slab); }
+    if (s->U) { whole = s->U; whole_elems = 2 * slab; add(h->d_prof[P_U], 0, nzp1, s->U); add(h->d_prof[P_V], 0, nzp1, s->U + slab); }
+    if (s->X) { whole = s->X; whole_elems = 2 * slab; add(h->d_prof[P_T], 0, nzp1, s->X); add(h->d_prof[P_S], 0, nzp1, s->X + slab); }
   }
   if ((mask & MCKPP_F_SAVED)) {
     if (s->Us) {
+      whole = s->Us; whole_elems = 4 * slab;
       add(h->d_prof[P_US0], 0, nzp1, s->Us + 0 * slab); add(h->d_prof[P_VS0], 0, nzp1, s->Us + 1 * slab);
       add(h->d_prof[P_US1], 0, nzp1, s->Us + 2 * slab); add(h->d_prof[P_VS1], 0, nzp1, s->Us + 3 * slab);
     }
     if (s->Xs) {
+      whole = s->Xs; whole_elems = 4 * slab;
       add(h->d_prof[P_TS0], 0, nzp1, s->Xs + 0 * slab); add(h->d_prof[P_SS0], 0, nzp1, s->Xs + 1 * slab);
       add(h->d_prof[P_TS1], 0, nzp1, s->Xs + 2 * slab); add(h->d_prof[P_SS1], 0, nzp1, s->Xs + 3 * slab);
     }
   }
+  whole = nullptr; whole_elems = 0;
   if ((mask & MCKPP_F_DIAG)) {
     const int n1 = h->c.nztmax + 1;        // extent of (0:nztmax)
     const size_t s1 = (size_t)h->npts * n1;
@@ -935,11 +980,13 @@ static void download_plan(mckpp_hip_ctx *h, const mckpp_state_ptrs_c *s, uint32_
     if (s->difs) add(h->d_diag[D_DIFS], 0, nzp1 + 1, s->difs);
     if (s->dift) add(h->d_diag[D_DIFT], 0, nzp1 + 1, s->dift);
     if (s->ghat) add(h->d_diag[D_GHAT], 1, nz, s->ghat);
-    if (s->wU) { add(h->d_diag[D_WU1], 0, nz + 1, s->wU); add(h->d_diag[D_WU2], 0, nz + 1, s->wU + s1); }
+    if (s->wU) { whole = s->wU; whole_elems = 2 * s1; add(h->d_diag[D_WU1], 0, nz + 1, s->wU); add(h->d_diag[D_WU2], 0, nz + 1, s->wU + s1); }
     if (s->wX) {
+      whole = s->wX; whole_elems = 3 * s1;
       add(h->d_diag[D_WX1], 0, nz + 1, s->wX); add(h->d_diag[D_WX2], 0, nz + 1, s->wX + s1);
       add(h->d_diag[D_WX3], 0, nz + 1, s->wX + 2 * s1);
     }
+    whole = nullptr; whole_elems = 0;
     if (s->wXNT) add(h->d_diag[D_WXNT1], 0, nz + 1, s->wXNT);
     if (s->Rig) add(h->d_diag[D_RIG], 1, nz, s->Rig);
     if (s->Shsq) add(h->d_diag[D_SHSQ], 1, nz, s->Shsq);
@@ -961,43 +1008,100 @@ static int download_records(mckpp_hip_ctx *h, mckpp_state_ptrs_c *s, uint32_t ma
   const int64_t npts = h->npts, ncol = h->ncol;
   const bool want_tabs = (mask & MCKPP_F_DIAG) && (s->swfrac || s->swdk_opt);
   if (!(mask & (MCKPP_F_SAVED | MCKPP_F_SCALARS)) && !want_tabs) return 0;
+  if (ncol == npts && !want_tabs) {
+    // every grid point is a resident column: the wanted record slots are packed into (npts) slabs on the device and
+    // land in the caller's arrays as they are - no host loop, half the bytes
+    struct dst_d { double *p; };
+    struct dst_i { int32_t *p; };
+    mckpp_pack_list l{};
+    dst_d dd[MCKPP_CS];
+    dst_i di[MCKPP_CI];
+    auto addd = [&](double *p, int slot) { if (p) { dd[l.nd].p = p; l.dslot[l.nd++] = slot; } };
+    auto addi = [&](int32_t *p, int slot) { if (p) { di[l.ni].p = p; l.islot[l.ni++] = slot; } };
+    if (mask & MCKPP_F_SAVED) {
+      if (s->hmixd) { addd(s->hmixd, CS_HMIXD0); addd(s->hmixd + npts, CS_HMIXD1); }
+      addi(s->old, CI_OLD); addi(s->new_, CI_NEW);
+    }
+    if (mask & MCKPP_F_SCALARS) {
+      addd(s->hmix, CS_HMIX); addd(s->kmix, CS_KMIX); addd(s->Tref, CS_TREF); addd(s->uref, CS_UREF); addd(s->vref, CS_VREF);
+      addd(s->Ssurf, CS_SSURF); addd(s->reset_flag, CS_RESET); addd(s->dampu_flag, CS_DAMPU); addd(s->dampv_flag, CS_DAMPV);
+      addd(s->freeze_flag, CS_FREEZE);
+      if (h->ext) addd(s->fcorr, CS_FCORR);
+      addi(s->l_initflag, CI_INITFLAG);
+      if (s->sflux)
+        for (int m = 0; m < 6; ++m) addd(s->sflux + npts * m + npts * (int64_t)h->c.nsflxs * 4, CS_SFLUX1 + m);
+    }
+    if (!h->d_pack) HIPCHK(hipMalloc(&h->d_pack, (size_t)npts * MCKPP_CS * sizeof(double)));
+    if (!h->d_ipack) HIPCHK(hipMalloc(&h->d_ipack, (size_t)npts * MCKPP_CI * sizeof(int)));
+    HIPCHK(mckpp_launch_pack_records(h->d_cs, h->d_ci, h->d_ipt, ncol, npts, l, h->d_pack, h->d_ipack, h->stream));
+    for (int j = 0; j < l.nd; ++j) {
+      // consecutive slabs that are consecutive at the destination too (sflux, hmixd) go as one transfer
+      int k = j;
+      while (k + 1 < l.nd && dd[k + 1].p == dd[k].p + npts) ++k;
+      const size_t bytes = (size_t)npts * (k - j + 1) * sizeof(double);
+      pin_host(h, dd[j].p, bytes);
+      HIPCHK(hipMemcpyAsync(dd[j].p, h->d_pack + (size_t)npts * j, bytes, hipMemcpyDeviceToHost, h->stream));
+      j = k;
+    }
+    for (int j = 0; j < l.ni; ++j) {
+      pin_host(h, di[j].p, (size_t)npts * sizeof(int));
+      HIPCHK(hipMemcpyAsync(di[j].p, h->d_ipack + (size_t)npts * j, (size_t)npts * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+  }
   if (mask & (MCKPP_F_SAVED | MCKPP_F_SCALARS))
     HIPCHK(hipMemcpyAsync(h->h_cs, h->d_cs, (size_t)ncol * MCKPP_CS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(h->h_ci, h->d_ci, (size_t)ncol * MCKPP_CI * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   const double *cs = h->h_cs;
   const int *ci = h->h_ci;
-  if (mask & MCKPP_F_SAVED) {
-    for (int64_t c = 0; c < ncol; ++c) {
-      const int64_t i = h->ipt[c];
+  const bool saved = mask & MCKPP_F_SAVED, scal = mask & MCKPP_F_SCALARS;
+  const bool fc = scal && s->fcorr && h->ext;
+  double *sfl = (scal && s->sflux) ? s->sflux + npts * (int64_t)h->c.nsflxs * 4 : nullptr;   // sflux(:,1:6,5,0)
+  const int *ipt = h->ipt.data();
+  for_columns(ncol, [&](int64_t c0, int64_t c1) {
+    for (int64_t c = c0; c < c1; ++c) {
+      const int64_t i = ipt[c];
       const double *r = &cs[(size_t)c * MCKPP_CS];
       const int *q = &ci[(size_t)c * MCKPP_CI];
-      if (s->hmixd) { s->hmixd[i] = r[CS_HMIXD0]; s->hmixd[i + npts] = r[CS_HMIXD1]; }
-      if (s->old) s->old[i] = q[CI_OLD];
-      if (s->new_) s->new_[i] = q[CI_NEW];
+      if (saved) {
+        if (s->hmixd) { s->hmixd[i] = r[CS_HMIXD0]; s->hmixd[i + npts] = r[CS_HMIXD1]; }
+        if (s->old) s->old[i] = q[CI_OLD];
+        if (s->new_) s->new_[i] = q[CI_NEW];
+      }
+      if (scal) {
+        if (s->hmix) s->hmix[i] = r[CS_HMIX];
+        if (s->kmix) s->kmix[i] = r[CS_KMIX];
+        if (s->Tref) s->Tref[i] = r[CS_TREF];
+        if (s->uref) s->uref[i] = r[CS_UREF];
+        if (s->vref) s->vref[i] = r[CS_VREF];
+        if (s->Ssurf) s->Ssurf[i] = r[CS_SSURF];
+        if (s->reset_flag) s->reset_flag[i] = r[CS_RESET];
+        if (s->dampu_flag) s->dampu_flag[i] = r[CS_DAMPU];
+        if (s->dampv_flag) s->dampv_flag[i] = r[CS_DAMPV];
+        if (s->freeze_flag) s->freeze_flag[i] = r[CS_FREEZE];
+        if (s->l_initflag) s->l_initflag[i] = q[CI_INITFLAG];
+        if (fc) s->fcorr[i] = r[CS_FCORR];
+        if (sfl) for (int m = 0; m < 6; ++m) sfl[i + npts * m] = r[CS_SFLUX1 + m];
+      }
     }
-  }
-  if (mask & MCKPP_F_SCALARS) {
-    // one pass per destination array: each is written front to back
-    auto put = [&](double *dst, int slot) {
-      if (!dst) return;
-      for (int64_t c = 0; c < ncol; ++c) dst[h->ipt[c]] = cs[(size_t)c * MCKPP_CS + slot];
-    };
-    put(s->hmix, CS_HMIX); put(s->kmix, CS_KMIX); put(s->Tref, CS_TREF); put(s->uref, CS_UREF); put(s->vref, CS_VREF);
-    put(s->Ssurf, CS_SSURF); put(s->reset_flag, CS_RESET); put(s->dampu_flag, CS_DAMPU); put(s->dampv_flag, CS_DAMPV);
-    put(s->freeze_flag, CS_FREEZE);
-    if (h->ext) put(s->fcorr, CS_FCORR);
-    if (s->l_initflag) for (int64_t c = 0; c < ncol; ++c) s->l_initflag[h->ipt[c]] = ci[(size_t)c * MCKPP_CI + CI_INITFLAG];
-    if (s->sflux)   // sflux(:,1:6,5,0) as assembled by mckpp_hip_fluxes / set_forcing
-      for (int m = 0; m < 6; ++m) put(s->sflux + npts * m + npts * (int64_t)h->c.nsflxs * 4, CS_SFLUX1 + m);
-  }
-  if (want_tabs) {
-    for (int64_t c = 0; c < ncol; ++c) {
-      const int64_t i = h->ipt[c];
-      const int jw = ci[(size_t)c * MCKPP_CI + CI_JERLOV];
-      if (s->swfrac) for (int l = 1; l <= nzp1; ++l) s->swfrac[i + npts * (l - 1)] = h->h_swfrac_tab[(size_t)jw * h->ldc + l];
-      if (s->swdk_opt) for (int k = 0; k <= nz; ++k) s->swdk_opt[i + npts * k] = h->h_swdk_tab[(size_t)jw * h->ldc + k];
-    }
+  });
+  if (want_tabs) {   // level by level within a block of columns: every destination slab is written front to back
+    const double *tf = h->h_swfrac_tab.data(), *tk = h->h_swdk_tab.data();
+    const size_t ldc = (size_t)h->ldc;
+    for_columns(ncol, [&](int64_t c0, int64_t c1) {
+      if (s->swfrac)
+        for (int l = 1; l <= nzp1; ++l) {
+          double *dst = s->swfrac + npts * (int64_t)(l - 1);
+          for (int64_t c = c0; c < c1; ++c) dst[ipt[c]] = tf[(size_t)ci[(size_t)c * MCKPP_CI + CI_JERLOV] * ldc + l];
+        }
+      if (s->swdk_opt)
+        for (int k = 0; k <= nz; ++k) {
+          double *dst = s->swdk_opt + npts * (int64_t)k;
+          for (int64_t c = c0; c < c1; ++c) dst[ipt[c]] = tk[(size_t)ci[(size_t)c * MCKPP_CI + CI_JERLOV] * ldc + k];
+        }
+    });
   }
   return 0;
 }
@@ -1011,7 +1115,7 @@ int mckpp_hip_download(mckpp_hip_handle h, mckpp_state_ptrs_c *s, uint32_t mask)
   std::vector<row_xfer> plan;
   download_plan(h, s, mask, plan);
   for (const row_xfer &x : plan)
-    if (down_rows(h, x.dev, h->ld, x.src_off, x.nlev, x.host)) return -1;
+    if (down_rows(h, x.dev, h->ld, x.src_off, x.nlev, x.host, x.whole, x.whole_elems)) return -1;
   if (download_records(h, s, mask)) return -1;   // (waits for the context's stream: the last step has finished)
   return xfer_finish(h);
 }
@@ -1581,7 +1685,7 @@ static int multi_prepare_root(mckpp_hip_multi *m, int root, size_t nout, size_t 
 }
 
 static int multi_gather_rows(mckpp_hip_multi *m, int root, const std::vector<const double *> &src, int ld, int src_off,
-                             int nlev, double *out)
+                             int nlev, double *out, const double *whole = nullptr, size_t whole_elems = 0)
 {
   const int ndev = (int)m->ctx.size();
   mckpp_hip_ctx *r = m->ctx[root];
@@ -1592,7 +1696,8 @@ static int multi_gather_rows(mckpp_hip_multi *m, int root, const std::vector<con
     if (d != root) nstage += (size_t)m->ctx[d]->ncol * ld;   // the root's own rows are read where they are
   }
   if (multi_prepare_root(m, root, nout, nstage ? nstage : 1)) return -1;
-  pin_host(r, out, nout * sizeof(double));
+  if (whole) pin_host(r, whole, whole_elems * sizeof(double));
+  else pin_host(r, out, nout * sizeof(double));
   // the 3-D image: behind the transfer of the previous gather; land points keep the caller's values
   HIPCHK(hipStreamWaitEvent(r->stream, m->ev_gcopy, 0));
   if (ncols < (size_t)m->npts) HIPCHK(hipMemcpyAsync(m->d_out, out, nout * sizeof(double), hipMemcpyHostToDevice, r->stream));
@@ -1670,7 +1775,7 @@ int mckpp_hip_multi_download(mckpp_hip_multi_handle m, mckpp_state_ptrs_c *s, ui
   for (size_t e = 0; e < plans[0].size(); ++e) {
     for (int d = 0; d < ndev; ++d) src[d] = plans[d][e].dev;
     const row_xfer &x = plans[0][e];
-    if (multi_gather_rows(m, 0, src, m->ctx[0]->ld, x.src_off, x.nlev, x.host)) return -1;
+    if (multi_gather_rows(m, 0, src, m->ctx[0]->ld, x.src_off, x.nlev, x.host, x.whole, x.whole_elems)) return -1;
   }
   for (auto *x : m->ctx) {
     if (x->ncol == 0) continue;

@@ -73,3 +73,28 @@ def test_shard_indices_partition():
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
         vals = [p * 2.0 for p in parts]
         assert np.array_equal(sharding.unshard(vals, ntotal), np.arange(ntotal) * 2.0)
+
+
+def test_bench_starts_its_own_ranks_without_touching_the_gpu():
+    """`python bench.py --gpus N` with no launcher around it becomes the launcher: N ranks under
+    torch.distributed.run on 127.0.0.1, started before this process imports torch or loads the library (a process
+    that has initialised the GPU must not start the ranks).  Without a GPU the ranks refuse to run and the exit
+    code comes back."""
+    import json
+    import subprocess
+
+    bench = os.path.join(cm.ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "3", "--print-launch"], capture_output=True,
+                       text=True, env=env, timeout=60)
+    assert r.returncode == 0, r.stderr
+    plan = json.loads(r.stdout.strip().splitlines()[-1])
+    assert plan["torch_imported"] is False and plan["library_loaded"] is False
+    cmd = plan["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
+    # a real launch here (no GPU): both ranks say so, the parent hands the failure on
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--no-cpu-baseline"], capture_output=True,
+                       text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "MI355X" in r.stderr and '"metric"' not in r.stdout
