@@ -213,7 +213,7 @@ def test_vary_bottom_temp(mk, nz, switches):
         ctx.bottomtemp(k3.bottom_temp)
 
 
-@pytest.mark.parametrize("nz", [30, 69, 100, 150])
+@pytest.mark.parametrize("nz", [30, 69, 100, 150, 200, 509])
 def test_options_on_other_depths(mk, nz):
     """The optional physics where a slot's items span one to three wavefronts (k_column_ps<EXT>): the level
     counts of check_profile (damped levels, frozen levels), the isotherm sums and the double-diffusion

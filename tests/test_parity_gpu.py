@@ -595,11 +595,14 @@ def test_kernel_name_and_depth_limit(mk):
 
 @pytest.mark.parametrize("nz,ncol,nsteps,grid", [(12, 90, 2, "uniform"), (40, 70, 2, "uniform"), (61, 67, 2, "uniform"),
                                                  (62, 67, 2, "uniform"), (69, 131, 2, "stretched"),
-                                                 (125, 35, 2, "uniform"), (126, 35, 2, "uniform"), (150, 41, 2, "uniform")])
+                                                 (125, 35, 2, "uniform"), (126, 35, 2, "uniform"), (150, 41, 2, "uniform"),
+                                                 (200, 37, 2, "uniform"), (300, 29, 2, "uniform"), (509, 23, 2, "uniform")])
 def test_every_depth_bitexact(mk, nz, ncol, nsteps, grid):
     """12 levels: four small workgroups per CU; 40..69: two workgroups of 8 waves with 13-21 slots, one or two
     trips of the item loop; 125..150: one 16-wave workgroup.  61/62 and 125/126 levels straddle a wave boundary
-    of a column's items (nzp1 + 2 of them with the two equation-of-state items)."""
+    of a column's items (nzp1 + 2 of them with the two equation-of-state items).  200, 300 and 509 (the deepest
+    the library accepts): few slots per workgroup, several trips of the item loop per slot, the launcher's cost
+    model and the magic-number divisions of the item map far from where they were tuned."""
     out, k3, ob, kc, oc = _run_both(mk, ncol, nz, nsteps, grid=grid, land_every=5, jerlov_mix=True)
     assert kc._hip_ctx.kernel_name == "k_column_ps"
     for tag, res in out:

@@ -3,7 +3,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=gpurun_out/prof_r02
+OUT=gpurun_out/prof_r03
 rm -rf $OUT && mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --no-cpu-baseline > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo "stats done"
@@ -17,7 +17,7 @@ for nz in 60 69 100; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write_$nz -- $B > $OUT/write_$nz.json 2> $OUT/write_$nz.err
   echo "pmc nz=$nz done"
 done
-python3 tools/r02_profile_digest.py $OUT
+python3 tools/r03_profile_digest.py $OUT
 # keep only the small files for the merge back
 find $OUT -name "*.csv" -size +3M -delete
 du -sh $OUT

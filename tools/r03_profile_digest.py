@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Digest the rocprofv3 output of tools/r02_profile.sh: per-kernel stats of the default bench run, the
+"""Digest the rocprofv3 output of tools/r03_profile.sh: per-kernel stats of the default bench run, the
 column-kernel rows of its trace, and the PMC counters of the LAST column-kernel dispatch of each counter run
 (the third timed step: 6 passes per column) -> profiles-ready files."""
 import csv

@@ -1,10 +1,11 @@
 # HBM traffic of one column-kernel launch (FETCH_SIZE, WRITE_SIZE in separate --pmc passes, last dispatch of
-# bench.py --steps 3): CFGS="<levels> ..."; LIB=<path> swaps in another build of the library for the run.
+# bench.py --steps 3): CFGS="<levels> ..."; LIB=<path> runs another build of the library (through
+# MCKPP_HIP_LIBRARY: the product library is not touched).
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 OUT=gpurun_out/traffic
 rm -rf $OUT && mkdir -p $OUT
-if [ -n "$LIB" ]; then cp mckpp_f90_amd/libmckpp_hip.so /tmp/lib_keep.so; cp $LIB mckpp_f90_amd/libmckpp_hip.so; fi
+if [ -n "$LIB" ]; then export MCKPP_HIP_LIBRARY=$(realpath $LIB); fi
 for nz in ${CFGS:-60}; do
   B="python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras --nz $nz"
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$nz -- $B > $OUT/fetch_$nz.json 2> $OUT/fetch_$nz.err
@@ -20,4 +21,3 @@ fe, wr = last("fetch"), last("write")
 print("nz=$nz ${LIB:-product} FETCH_SIZE %.0f KB (x2: %.2f GB)  WRITE_SIZE %.0f KB (%.2f GB)  total %.2f GB" % (fe, 2 * fe * 1024 / 1e9, wr, wr * 1024 / 1e9, (2 * fe + wr) * 1024 / 1e9))
 PY
 done
-if [ -n "$LIB" ]; then cp /tmp/lib_keep.so mckpp_f90_amd/libmckpp_hip.so; fi
