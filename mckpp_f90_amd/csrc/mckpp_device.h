@@ -41,7 +41,8 @@ template <template <class> class P>
 struct mckpp_kparams_t {
   int nz, nzp1, ncol, ld;
   int ntime, itermax, mode, diag;
-  int L_SSref, LDD, clim_present, pad0;
+  int L_SSref, LDD, clim_present;
+  int l2pre;      // L2 works from per-layer terms formed once per column (deep reference-level sums; host-chosen)
   double hmixtolfrac, dto, grav, vonk, sice;
   double Vtc;     // bldepth_mod.F90:91, host-evaluated
   double cg;      // blmix_mod.F90:62, host-evaluated (libm pow)

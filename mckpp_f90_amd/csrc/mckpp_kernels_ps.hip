@@ -43,10 +43,12 @@ enum {
   I_STATE = 0, I_ACT, I_COL, I_OLD, I_NEW, I_JER, I_INITFLAG, I_STATUS, I_NPASS, I_NPASS_TRY, I_ICONV, I_COMP, I_KMIXN,
   I_KBL, I_NRESET, I_FIN, I_MAYBE, I_LOAD /* 1: new column, 2: restart the iteration (trap retry) */, I_JU,
   I_KBLC, I_NVIOL, I_NOVER, I_NU, I_NV, I_NF, I_BAD, I_L1A /* L1 but for V done ahead, during the V sweep */,
-  I_MAYBE_NEXT, I_LOCEAN, I_PAR /* which C_T1X holds the iterate's level-1 temperature */, I_COUNT
+  I_MAYBE_NEXT, I_LOCEAN, I_PAR /* which C_T1X holds the iterate's level-1 temperature */,
+  I_TINY /* some whole-layer term of the reference-level sums is a tiny non-zero number (L2) */, I_COUNT
 };
 // LDS rows of a slot and what each holds between which phases of a pass:
-//   Q_DM   (LDD talpha L1..L2)  difm: interior L3, final L5 .. L7
+//   Q_DM   (LDD talpha L1..L2; else the whole-layer terms of the reference-level sum of U, L2)  difm: interior L3,
+//          final L5 .. L7
 //   Q_DT   Ritop L2..L3; dift L3/L5 .. M4, where the T system's gam overwrites it level by level; q = -cu of the
 //          momentum system L7..M5 (V sweep)
 //   Q_DS   dVsq L2..L3; with double diffusion difs L3/L5 .. M4, then the S system's gam - without it difs = dift
@@ -58,7 +60,7 @@ enum {
 //   Q_YV   previous V solution .. L1; V of the iterate L1..L2; bulk Ri L3..L4 (scan M2); ghat L5..L6;
 //          rhs L7; solution M5
 //   Q_GM   Rig L2..L3; gam of the momentum system M4..M5
-//   Q_BET  (LDD T L1..L2) pivots of the momentum system M4..M5
+//   Q_BET  (LDD T L1..L2; else the whole-layer terms of V, L2) pivots of the momentum system M4..M5
 // In the instability trap Q_DM, Q_DT, Q_DS, Q_GM carry the four rmsd terms, in the isotherm check Q_DM, Q_DT.
 // Optional-physics builds: rho, cp (L1..L6); with double diffusion also alphaDT, betaDS (L2..L3), LDD sbeta and
 // S (L1..L2).  Three kernel variants XV: 0 default physics (9 rows), 1 optional physics (11), 2 optional physics
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           msi[I_NRESET] = 0; msi[I_KMIXN] = 0; msi[I_KBL] = 0; msi[I_LOAD] = 1; msi[I_BAD] = 0;
           msi[I_MAYBE] = (p.mode != MCKPP_MODE_STEP) ? 1 : 0;
           msi[I_KBLC] = 0x7fffffff; msi[I_NVIOL] = 0; msi[I_NU] = 0; msi[I_NV] = 0; msi[I_NF] = 0; msi[I_PAR] = 0;
-          msi[I_L1A] = 0; msi[I_MAYBE_NEXT] = msi[I_MAYBE];
+          msi[I_L1A] = 0; msi[I_MAYBE_NEXT] = msi[I_MAYBE]; msi[I_TINY] = 0;
           msc[C_F] = cs[CS_F]; msc[C_WXNT0] = 0.0; msc[C_HMIXE] = 0.0; msc[C_HMIXN] = 0.0;
           msc[C_SREF] = cs[CS_SREF]; msc[C_SSURF] = cs[CS_SSURF]; msc[C_OCDEPTH] = cs[CS_OCDEPTH];
           msc[C_SFLUX1] = cs[CS_SFLUX1]; msc[C_SFLUX2] = cs[CS_SFLUX2]; msc[C_SFLUX3] = cs[CS_SFLUX3];
@@ -754,6 +756,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       if (msi[I_ACT]) {
         if (p.mode != MCKPP_MODE_INIT && msi[I_BAD]) msi[I_STATUS] = msi[I_STATUS] | 1;
         msi[I_BAD] = 0;
+        msi[I_TINY] = 0;
         msi[I_MAYBE] = msi[I_MAYBE_NEXT];
       }
     }
@@ -941,6 +944,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     const double zmk = c_zm[k];
     const double zm1 = c_zm[1];
     const double U1 = aU[1], V1 = aV[1], Bu1 = aB[1];
+    const strided<ROWS> aNU = row(Q_DM), aNV = row(Q_BET);   // whole-layer terms of U and V (L2a)
+    const bool pre = p.l2pre != 0;
+    const bool guard = si[I_TINY] != 0;
     const double zref = eps01 * zmk, rzref = rcp_refine(zref);
     double wz = dmax2(zm1, zref);
     double ur = div_fast_guarded(U1 * wz, zref, rzref), vr = div_fast_guarded(V1 * wz, zref, rzref),
@@ -951,22 +957,50 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     bool live = actz;
     int klp = 0;
     double zk = zm1, Uk = U1, Vk = V1, Bk = Bu1;
-    for (int kl = 1; kl <= nz; ++kl) {
-      live = live && !(zref >= zk);
-      if (!__any(live)) break;
-      const double zk1 = c_zm[kl + 1], Uk1 = aU[kl + 1], Vk1 = aV[kl + 1], Bk1 = aB[kl + 1];
-      if (live) {
-        const double dzk = zk - zk1;
-        if (dzk > zk - zref) {   // the minimum is zm(kl)-zref < dz: partial layer (then zref > zm(kl+1): the last)
-          klp = kl;
-          live = false;
-        } else {
-          ur = ur - div_fast_guarded(dzk * (Uk + 0.5 * (Uk1 - Uk)), zref, rzref);
-          vr = vr - div_fast_guarded(dzk * (Vk + 0.5 * (Vk1 - Vk)), zref, rzref);
-          br = br - div_fast(dzk * (Bk + 0.5 * (Bk1 - Bk)), zref, rzref);
+    if (pre) {
+      // the numerators of the whole layers, dz (U(kl) + 0.5 (U(kl+1) - U(kl))) and the same of V, do not depend on
+      // the level whose reference values are being formed: L2a has put them into two rows, and has said whether
+      // any of them is a tiny non-zero number (div_fast must not see those)
+      for (int kl = 1; kl <= nz; ++kl) {
+        live = live && !(zref >= zk);
+        if (!__any(live)) break;
+        const double zk1 = c_zm[kl + 1], nu = aNU[kl], nv = aNV[kl], Bk1 = aB[kl + 1];
+        if (live) {
+          const double dzk = zk - zk1;
+          if (dzk > zk - zref) {   // the minimum is zm(kl)-zref < dz: partial layer (then zref > zm(kl+1): the last)
+            klp = kl;
+            live = false;
+          } else {
+            if (__builtin_expect(guard, 0)) {
+              ur = ur - div_fast_guarded(nu, zref, rzref);
+              vr = vr - div_fast_guarded(nv, zref, rzref);
+            } else {
+              ur = ur - div_fast(nu, zref, rzref);
+              vr = vr - div_fast(nv, zref, rzref);
+            }
+            br = br - div_fast(dzk * (Bk + 0.5 * (Bk1 - Bk)), zref, rzref);
+          }
         }
+        zk = zk1; Bk = Bk1;
       }
-      zk = zk1; Uk = Uk1; Vk = Vk1; Bk = Bk1;
+    } else {
+      for (int kl = 1; kl <= nz; ++kl) {
+        live = live && !(zref >= zk);
+        if (!__any(live)) break;
+        const double zk1 = c_zm[kl + 1], Uk1 = aU[kl + 1], Vk1 = aV[kl + 1], Bk1 = aB[kl + 1];
+        if (live) {
+          const double dzk = zk - zk1;
+          if (dzk > zk - zref) {
+            klp = kl;
+            live = false;
+          } else {
+            ur = ur - div_fast_guarded(dzk * (Uk + 0.5 * (Uk1 - Uk)), zref, rzref);
+            vr = vr - div_fast_guarded(dzk * (Vk + 0.5 * (Vk1 - Vk)), zref, rzref);
+            br = br - div_fast(dzk * (Bk + 0.5 * (Bk1 - Bk)), zref, rzref);
+          }
+        }
+        zk = zk1; Uk = Uk1; Vk = Vk1; Bk = Bk1;
+      }
     }
     if (klp) {
       const double zl = c_zm[klp], zl1 = c_zm[klp + 1];
@@ -1036,6 +1070,19 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     __syncthreads();
     STAMP(1);
 
+    // ---- L2a: the whole-layer terms of the reference-level sums (verticalmixing_mod.F90:122-127 with wz = dz,
+    // del = 0.5), once per layer instead of once per (level, layer)
+    if (p.l2pre) {   // (chosen by the host: deep reference-level sums, and no double diffusion - it has the two rows then)
+      FOR_ITEMS
+        if (!actz) continue;
+        const double dzk = c_zm[k] - c_zm[k + 1];
+        const double Uk = row(Q_YU)[k], Uk1 = row(Q_YU)[k + 1], Vk = row(Q_YV)[k], Vk1 = row(Q_YV)[k + 1];
+        const double nu = dzk * (Uk + 0.5 * (Uk1 - Uk)), nv = dzk * (Vk + 0.5 * (Vk1 - Vk));
+        row(Q_DM)[k] = nu; row(Q_BET)[k] = nv;
+        if (__builtin_expect(tiny_nonzero(nu) || tiny_nonzero(nv), 0)) si[I_TINY] = 1;
+      END_ITEMS
+      __syncthreads();
+    }
     // ---- M1 | L2: surface fluxes (wave 0) | reference-level loop, Ri pieces (verticalmixing_mod.F90:111-137)
     if (wv == mgr) M1();
     // measured: the level-major order pays from ~50 levels on (+2 % at 60, +13 % on the stretched 69-level grid,

@@ -609,6 +609,17 @@ def test_every_depth_bitexact(mk, nz, ncol, nsteps, grid):
         _assert_bitexact(res, f"nz={nz} {tag}")
 
 
+@pytest.mark.parametrize("nz,grid,l2pre", [(40, "uniform", "1"), (60, "uniform", "1"), (69, "stretched", "0"), (150, "uniform", "1")])
+def test_reference_level_sums_both_ways(mk, monkeypatch, nz, grid, l2pre):
+    """The reference-level sums of L2 (verticalmixing_mod.F90:118-131) run either layer by layer from the profiles
+    or from whole-layer terms formed once per column in an extra phase; the launcher picks by the depth of the
+    sums (stretched 69-level grid: the latter).  MCKPP_L2PRE forces the way it would not pick."""
+    monkeypatch.setenv("MCKPP_L2PRE", l2pre)
+    out, k3, ob, kc, oc = _run_both(mk, 83, nz, 2, grid=grid, land_every=5, jerlov_mix=True)
+    for tag, res in out:
+        _assert_bitexact(res, f"nz={nz} {grid} MCKPP_L2PRE={l2pre} {tag}")
+
+
 @pytest.mark.parametrize("nz,geometry", [(60, "1x1x1"), (60, "3x2x4"), (60, "16x4x2"), (60, "21x16x1"), (60, "5x8x2"),
                                          (23, "21x2x4"), (150, "3x4x2"), (150, "13x16x1")])
 def test_forced_workgroup_geometries(mk, monkeypatch, nz, geometry):
@@ -706,15 +717,20 @@ def test_config2_pass_every_depth(mk):
         ctx.close()
 
 
-@pytest.mark.parametrize("nz", [40, 60, 69, 100])
-def test_tiny_and_denormal_velocities_take_the_ieee_paths(mk, nz):
-    """The kernel drops the v_div_scale rescaling where operand ranges are known and guard the
+@pytest.mark.parametrize("nz,l2pre", [(40, None), (100, None), (60, "1"), (69, "1")])
+def test_tiny_and_denormal_velocities_take_the_ieee_paths(mk, monkeypatch, nz, l2pre):
+    """(l2pre: MCKPP_L2PRE=1 makes the reference-level sums work from per-layer terms formed once per column,
+    which the launcher picks by itself on grids whose sums span many layers; a tiny term is then flagged per
+    column and that column's sums take the guarded quotients.)
+    The kernel drops the v_div_scale rescaling where operand ranges are known and guard the
     quotients whose numerators can be tiny non-zero numbers (velocities diffused down a deep column):
     reference-level averages, Thomas solution numerators.  Profiles of 1e-290 ... denormal velocities
     (and an almost-vanishing wind stress) push those guards into their IEEE fallbacks; the results
     must still be the oracle's bits."""
     from oracle import orc
 
+    if l2pre is not None:
+        monkeypatch.setenv("MCKPP_L2PRE", l2pre)
     ncol = 48
     oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1)
     kc, k3 = cm.make_hip_case(ncol, nz)
