@@ -51,7 +51,8 @@ struct mckpp_kparams_t {
   P<const double> zm, hm, tri0, tri1;
   P<const double> swfrac_tab;  // [6][ldc]  swfrac(k), k=1..nzp1, per Jerlov type
   P<const double> swdk_tab;    // [6][ldc]  swdk_opt(k), k=0..nz
-  int ldc, pad1;
+  int ldc;
+  int LRI;        // rimix (kppmix_mod.F90:72-74); .FALSE.: the interior diffusivities stay zero, Rig is not formed
   P<const double> wtab;        // [(NJ+2)][(NI+2)] pairs {wmt, wst}
   // state
   P<double> U, V, T, S;

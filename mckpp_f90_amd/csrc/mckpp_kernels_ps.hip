@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     if (isnzp1) row(Q_GM)[k] = 0.0;
     if (p.diag && si[I_MAYBE]) {
       const size_t od = ro + k;
-      if (actz) { p.Rig[od] = Rig; p.dbloc[od] = dbloc; p.Shsq[od] = shsq; }
+      if (actz) { if (p.LRI) p.Rig[od] = Rig; p.dbloc[od] = dbloc; p.Shsq[od] = shsq; }   // (Rig is rimix's, rimix_mod.F90:47-56)
     }
   };
 
@@ -1122,6 +1122,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       double dm_i = (0.0001 + fri * 0.005);
       double ds_i = (0.00001 + fri * 0.005);
       double dt_i = ds_i;   // dift = difs, rimix_mod.F90:95-97
+      if (!p.LRI) { dm_i = 0.0; ds_i = 0.0; dt_i = 0.0; }   // kppmix_mod.F90:65-74: zeroed, rimix not called
       if constexpr (EXT) {
         if (DD && p.LDD) {   // ddmix_mod.F90:12-52
           const double Rrho0 = 1.9, dsfmax = 1.0e-4;

@@ -223,7 +223,10 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   if (c->nztmax < c->nz + 1) return fail("mckpp_hip_init: nztmax=%d < nzp1=%d", c->nztmax, c->nz + 1);
   if (!c->zm || !c->hm || !c->dm || !c->tri || !c->wmt || !c->wst)
     return fail("mckpp_hip_init: zm/hm/dm/tri/wmt/wst must all be set");
-  if (!c->LKPP || !c->LRI) return fail("mckpp_hip_init: LKPP and LRI must be .TRUE. (the device path implements the KPP scheme)");
+  // LKPP=.FALSE. is not a defined configuration of the reference: kppmix then never assigns hbl / kbl
+  // (src/mckpp_physics_verticalmixing_kppmix_mod.F90:87-118 is skipped), which ocnstep stores as hmix / kmix and uses as
+  // the index of dm() (src/mckpp_physics_ocnstep_mod.F90:305-314, ocnint_mod.F90:97-114) - uninitialised memory.  Refused.
+  if (!c->LKPP) return fail("mckpp_hip_init: LKPP=.FALSE. leaves hmix/kmix unassigned in the reference (kppmix_mod.F90:87-118): not a defined configuration, not emulated");
   if (c->maxmodeadv < 0 || c->maxmodeadv > 16) return fail("mckpp_hip_init: maxmodeadv=%d", c->maxmodeadv);
   if (c->L_NO_ISOTHERM && (c->iso_bot < 2 || c->iso_bot > c->nz + 1))
     return fail("mckpp_hip_init: iso_bot=%d outside 2..nzp1", c->iso_bot);
@@ -775,7 +778,7 @@ static void fill_params(mckpp_hip_ctx *h, mckpp_kparams &p, int ntime, int mode)
   p.nz = h->nz; p.nzp1 = h->nzp1; p.ncol = (int)h->ncol; p.ld = h->ld;
   p.ntime = ntime; p.itermax = h->c.itermax; p.mode = mode; p.diag = h->diag;
   p.L_SSref = h->c.L_SSref; p.LDD = h->c.LDD; p.clim_present = h->c.clim_present;
-  p.l2pre = h->l2pre;
+  p.l2pre = h->l2pre; p.LRI = h->c.LRI ? 1 : 0;
   p.hmixtolfrac = h->c.hmixtolfrac; p.dto = h->c.dto; p.grav = h->c.grav; p.vonk = h->c.vonk; p.sice = h->c.sice;
   p.Vtc = h->Vtc; p.cg = h->cg; p.dm_nz = h->dm_nz;
   p.zm = h->d_zm; p.hm = h->d_hm; p.tri0 = h->d_tri0; p.tri1 = h->d_tri1;

@@ -284,6 +284,30 @@ def test_options_on_other_depths(mk, nz):
     _case(mk, 42, nz, dict(L_ADVECT=1), prep_adv, grid="stretched" if nz == 69 else "uniform")
 
 
+@pytest.mark.parametrize("nz,sw", [(40, dict(LRI=0)), (69, dict(LRI=0)), (60, dict(LRI=0, LDD=1)), (40, dict(LRI=0, L_DAMP_CURR=1, dt_uvdamp=360))])
+def test_without_the_richardson_mixing(mk, nz, sw):
+    """LRI=.FALSE. (src/mckpp_physics_verticalmixing_kppmix_mod.F90:65-74): rimix is not called, the interior
+    diffusivities stay at the zeros kppmix starts from (double diffusion adds to those), Rig is not formed; the
+    boundary-layer scheme and the solves run on that.  Default and optional-physics builds."""
+    def prep(k3, ob):
+        if sw.get("LDD"):
+            S = np.asarray(k3.X[:, :, 1]).copy()
+            S[::2] = 0.4 - 0.8 * np.linspace(0, 1, nz + 1)[None, :]
+            k3.X[:, :, 1] = S
+            ob.a["S"][:, 1:nz + 2] = S
+    k3, ob = _case(mk, 60, nz, sw, prep, nsteps=3, grid="stretched" if nz == 69 else "uniform")
+    assert np.all(np.asarray(k3.Rig) == 0.0)          # never written
+    assert np.any(np.asarray(k3.difm)[:, 1:nz] == 0.0)   # below the boundary layer
+
+
+def test_lkpp_false_is_refused_with_the_reason(mk):
+    kc = mk.KppConstFields(40)
+    kc.LKPP = 0
+    mk.mckpp_physics_lookup(kc)
+    with pytest.raises(mk.MckppHipError, match="unassigned in the reference"):
+        mk.MckppHip(kc)
+
+
 def test_optional_physics_kernel_selection(mk):
     for nz, want in [(40, "k_column_ps<EXT>"), (60, "k_column_ps<EXT>"), (69, "k_column_ps<EXT>"), (150, "k_column_ps<EXT>")]:
         kc = mk.KppConstFields(nz)
