@@ -365,7 +365,8 @@ __device__ __forceinline__ void ps_thomas_uts_back(int W, double *slots, int SS,
 // sweep formed (same functions of the same arguments), in two rows that are dead once T and S are solved - so a
 // level is n = rhs + q y (= rhs - cu y, ocnint / solvers.F90:153) and one div_fast.  A tiny non-zero numerator
 // (which div_fast must not see) is looked for once per trip of two levels, after the fact; the trip is then
-// redone from the value it started with, with IEEE divisions.
+// redone from the value it started with, with IEEE divisions.  118 cycles per level alone on a CU (150 with
+// compiler-scheduled reads of single values; tools/ubench/sweeps.hip).
 __device__ __forceinline__ void ps_thomas_v_fwd(int W, double *slots, int SS, int KS, int nz, const int *sact,
                                                 int sact_stride, int lane)
 {
@@ -376,26 +377,60 @@ __device__ __forceinline__ void ps_thomas_v_fwd(int W, double *slots, int SS, in
     const double b1 = betm[(1) * KS];
     double yy = div_by_refined(y[(1) * KS], b1, rbm[(1) * KS]);
     y[(1) * KS] = yy;
+    asm volatile("" : "+v"(yy));   // the waits for its operands here, not inside the loop below
     int i = 2;
-    double a_rhs = y[(2) * KS], a_q = qm[(2) * KS], a_b = betm[(2) * KS], a_r = rbm[(2) * KS];
-    for (; i + 1 <= nz; i += 2) {
-      const double b_rhs = y[(i + 1) * KS], b_q = qm[(i + 1) * KS], b_b = betm[(i + 1) * KS], b_r = rbm[(i + 1) * KS];
-      const double y_in = yy;
-      const double n0 = a_rhs + a_q * yy;
-      double y0 = div_fast(n0, a_b, a_r);
-      const double n1 = b_rhs + b_q * y0;
-      double y1 = div_fast(n1, b_b, b_r);
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(tiny_nonzero(n0) || tiny_nonzero(n1)) != 0ull, 0)) {
-        y0 = (a_rhs + a_q * y_in) / a_b;
-        y1 = (b_rhs + b_q * y0) / b_b;
+    // A trip is two levels; its eight operands - (q, 1/bet) and (rhs, bet) of either level, neighbours in the slot's
+    // level-interleaved block - come with four ds_read2_b64 issued one trip ahead (ps_lds_read2 / ps_lds_wait, above).
+    if (i + 1 <= nz) {
+      static_assert(Q_DT == 1 && Q_DS == 2 && Q_YV == 6 && Q_BET == 8, "offsets of the V sweep's operands in a level block");
+      const unsigned step = 2u * (unsigned)KS * 8u;
+      unsigned ad = ps_lds_addr(base + i * KS);
+      auto rd_qr0 = [&](unsigned a) { return ps_lds_read2<1, 2>(a); };
+      auto rd_hb0 = [&](unsigned a) { return ps_lds_read2<6, 8>(a); };
+      auto rd_qr1 = [&](unsigned a) { return KS == 9 ? ps_lds_read2<10, 11>(a) : KS == 11 ? ps_lds_read2<12, 13>(a) : ps_lds_read2<16, 17>(a); };
+      auto rd_hb1 = [&](unsigned a) { return KS == 9 ? ps_lds_read2<15, 17>(a) : KS == 11 ? ps_lds_read2<17, 19>(a) : ps_lds_read2<21, 23>(a); };
+      auto body = [&](unsigned aw, const ps_d2 &qr0, const ps_d2 &hb0, const ps_d2 &qr1, const ps_d2 &hb1) {
+        const double y_in = yy;
+        const double n0 = hb0.x + qr0.x * yy;
+        double y0 = div_fast(n0, hb0.y, qr0.y);
+        const double n1 = hb1.x + qr1.x * y0;
+        double y1 = div_fast(n1, hb1.y, qr1.y);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tiny_nonzero(n0) || tiny_nonzero(n1)) != 0ull, 0)) {
+          y0 = (hb0.x + qr0.x * y_in) / hb0.y;
+          y1 = (hb1.x + qr1.x * y0) / hb1.y;
+        }
+        yy = y1;
+        if (KS == 9) ps_lds_write2<6, 15>(aw, y0, y1);
+        else if (KS == 11) ps_lds_write2<6, 17>(aw, y0, y1);
+        else ps_lds_write2<6, 21>(aw, y0, y1);
+      };
+      ps_d2 a0 = rd_qr0(ad), a1 = rd_hb0(ad), a2 = rd_qr1(ad), a3 = rd_hb1(ad), b0, b1_, b2, b3;
+      while (i + 5 <= nz) {   // this trip, the next, and one more after it
+        b0 = rd_qr0(ad + step); b1_ = rd_hb0(ad + step); b2 = rd_qr1(ad + step); b3 = rd_hb1(ad + step);
+        ps_lds_wait<4>(a0, a1, a2, a3);
+        body(ad, a0, a1, a2, a3);
+        a0 = rd_qr0(ad + 2 * step); a1 = rd_hb0(ad + 2 * step); a2 = rd_qr1(ad + 2 * step); a3 = rd_hb1(ad + 2 * step);
+        ps_lds_wait<4>(b0, b1_, b2, b3);
+        body(ad + step, b0, b1_, b2, b3);
+        i += 4; ad += 2 * step;
       }
-      yy = y1;
-      y[(i) * KS] = y0; y[(i + 1) * KS] = y1;
-      if (i + 2 <= nz) { a_rhs = y[(i + 2) * KS]; a_q = qm[(i + 2) * KS]; a_b = betm[(i + 2) * KS]; a_r = rbm[(i + 2) * KS]; }
+      if (i + 3 <= nz) {
+        b0 = rd_qr0(ad + step); b1_ = rd_hb0(ad + step); b2 = rd_qr1(ad + step); b3 = rd_hb1(ad + step);
+        ps_lds_wait<4>(a0, a1, a2, a3);
+        body(ad, a0, a1, a2, a3);
+        ps_lds_wait<0>(b0, b1_, b2, b3);
+        body(ad + step, b0, b1_, b2, b3);
+        i += 4;
+      } else {
+        ps_lds_wait<0>(a0, a1, a2, a3);
+        body(ad, a0, a1, a2, a3);
+        i += 2;
+      }
+      ps_lds_drain();
     }
     if (i <= nz) {
-      const double n0 = a_rhs + a_q * yy;
-      yy = div_fast_guarded(n0, a_b, a_r);
+      const double n0 = y[(i) * KS] + qm[(i) * KS] * yy;
+      yy = div_fast_guarded(n0, betm[(i) * KS], rbm[(i) * KS]);
       y[(i) * KS] = yy;
     }
   }

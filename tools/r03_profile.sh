@@ -1,4 +1,4 @@
-# Round-2 profiles (run on the GPU box through gpurun): kernel trace + stats of the default bench run,
+# Round-3 profiles (run on the GPU box through gpurun): kernel trace + stats of the default bench run,
 # then SQ and TCC counter passes (separate --pmc runs, kernel-trace only) for three shapes.
 set -e
 cd $GRAFT_REPO_ROOT
