@@ -444,8 +444,11 @@ static void pin_host(mckpp_hip_ctx *h, const void *ptr, size_t bytes)
     if (b >= static_cast<const char *>(r.first) && b + bytes <= static_cast<const char *>(r.first) + r.second) return;
   for (auto &r : h->unpinnable)    // tried before: pinned by someone else, or cannot be
     if (r.first == ptr && r.second == bytes) return;
-  if (hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterPortable) == hipSuccess) h->pinned.emplace_back(ptr, bytes);
+  static const bool verbose = getenv("MCKPP_HIP_VERBOSE") != nullptr;
+  const hipError_t e = hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterPortable);
+  if (e == hipSuccess) h->pinned.emplace_back(ptr, bytes);
   else { (void)hipGetLastError(); h->unpinnable.emplace_back(ptr, bytes); }
+  if (verbose) fprintf(stderr, "[mckpp] hipHostRegister(%p, %zu B): %s\n", ptr, bytes, e == hipSuccess ? "pinned" : hipGetErrorString(e));
 }
 
 static int ensure_xfer(mckpp_hip_ctx *h, unsigned b, size_t elems)

@@ -43,3 +43,19 @@ for name, mask in (("restart", mk.api.F_RESTART),):
         nt += 1
         ctx.set_forcing(k3.sflux); ctx.step(nt, 1); ctx.download(k3, mask)
     print(name, "no waits in between: %.3f ms per step" % ((time.perf_counter() - t0) / 6 * 1e3))
+# one step per call with a host wait after each, against many steps per call (same work)
+ctx.step(nt + 1, 20); ctx.synchronize(); nt += 20
+t0 = time.perf_counter(); ctx.step(nt + 1, 20); ctx.synchronize(); t1 = time.perf_counter(); nt += 20
+print("20 steps in one call: %.3f ms per step" % ((t1 - t0) / 20 * 1e3))
+t0 = time.perf_counter()
+for it in range(20):
+    nt += 1; ctx.step(nt, 1); ctx.synchronize()
+print("20 calls of one step, a wait after each: %.3f ms per step; kernel %.3f ms" % ((time.perf_counter() - t0) / 20 * 1e3, ctx.last_kernel_ms()[0]))
+t0 = time.perf_counter()
+for it in range(20):
+    nt += 1; ctx.set_forcing(k3.sflux); ctx.step(nt, 1); ctx.synchronize()
+print("  + set_forcing: %.3f ms per step; kernel %.3f ms" % ((time.perf_counter() - t0) / 20 * 1e3, ctx.last_kernel_ms()[0]))
+t0 = time.perf_counter()
+for it in range(20):
+    nt += 1; ctx.set_forcing(k3.sflux); ctx.step(nt, 1); ctx.download(k3, mk.api.F_SCALARS)
+print("  + download of the scalar group: %.3f ms per step; kernel %.3f ms" % ((time.perf_counter() - t0) / 20 * 1e3, ctx.last_kernel_ms()[0]))
