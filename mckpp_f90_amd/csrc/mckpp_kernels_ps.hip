@@ -47,23 +47,24 @@ enum {
   I_TINY /* some whole-layer term of the reference-level sums is a tiny non-zero number (L2) */, I_COUNT
 };
 // LDS rows of a slot and what each holds between which phases of a pass:
-//   Q_DM   (LDD talpha L1..L2; else the whole-layer terms of the reference-level sum of U, L2)  difm: interior L3,
-//          final L5 .. L7
-//   Q_DT   Ritop L2..L3; dift L3/L5 .. M4, where the T system's gam overwrites it level by level; q = -cu of the
-//          momentum system L7..M5 (V sweep)
-//   Q_DS   dVsq L2..L3; with double diffusion difs L3/L5 .. M4, then the S system's gam - without it difs = dift
-//          bit for bit, T and S share Q_DT and its gam, and Q_DS takes their pivots in M4; refined reciprocals
-//          of the momentum pivots L7..M5 (V sweep)
+//   Q_DM   (LDD talpha L1..L2; else the whole-layer terms of the reference-level sum of U, L2)  difm: interior L3;
+//          from L5 p = tri(:,1) difm of the momentum system, which its pivots overwrite in M4 (kept to M5)
+//   Q_DT   Ritop L2..L3; dift interior L3; from L5 p of the T system (without double diffusion: of T and S, whose
+//          difs = dift bit for bit, one factorisation for both), its pivots in M4; refined reciprocals of the
+//          momentum pivots L7..M5 (V sweep)
+//   Q_DS   dVsq L2..L3; with double diffusion difs L3, p and the pivots of the S system L5..M4; without it dift
+//          for L6 (L5..L6), then gam of the momentum system M4..M5
 //   Q_YU   previous U solution .. L1; U of the iterate L1..L2; Monin-Obukhov depth L3..L4; rhs L6; solution M4
 //   Q_YT   previous T solution .. L1; dbloc L2..L3; rhs L6; solution M4
 //   Q_YS   previous S solution .. L1; buoyancy L1..L2; hmin candidates L4..M3; rhs L6; solution M4
 //   Q_YV   previous V solution .. L1; V of the iterate L1..L2; bulk Ri L3..L4 (scan M2); ghat L5..L6;
 //          rhs L7; solution M5
-//   Q_GM   Rig L2..L3; gam of the momentum system M4..M5
-//   Q_BET  (LDD T L1..L2; else the whole-layer terms of V, L2) pivots of the momentum system M4..M5
+//   Q_GM   Rig L2..L3; q = tri(:,0) difm(k-1) of the momentum system L5..M5 (U and V sweeps)
+//   Q_BET  (LDD T L1..L2; else the whole-layer terms of V, L2) q of the T (and S) system L5..M4, which its gam
+//          overwrites level by level
 // In the instability trap Q_DM, Q_DT, Q_DS, Q_GM carry the four rmsd terms, in the isotherm check Q_DM, Q_DT.
-// Optional-physics builds: rho, cp (L1..L6); with double diffusion also alphaDT, betaDS (L2..L3), LDD sbeta and
-// S (L1..L2).  Three kernel variants XV: 0 default physics (9 rows), 1 optional physics (11), 2 optional physics
+// Optional-physics builds: rho, cp (L1..L6); with double diffusion also Q_X1, Q_X2: alphaDT, betaDS (L2..L3), then
+// dift, difs for L6; Q_S1, Q_S2: LDD sbeta and S (L1..L2), then q / gam of the S system and gam of the momentum system.  Three kernel variants XV: 0 default physics (9 rows), 1 optional physics (11), 2 optional physics
 // with double diffusion (15).
 enum { Q_DM = 0, Q_DT, Q_DS, Q_YU, Q_YT, Q_YS, Q_YV, Q_GM, Q_BET, Q_COUNT,
        Q_RHO = Q_COUNT, Q_CP, Q_COUNT_EXT, Q_X1 = Q_COUNT_EXT, Q_X2, Q_S1, Q_S2, Q_COUNT_EXT_DD };
@@ -259,40 +260,44 @@ __device__ __forceinline__ void ps_backsub(double *y, const double *gm, int KS, 
   }
 }
 
-// The rows of tridiagonal system `sys` (0 momentum, 1 temperature, 2 salinity) of kernel variant XV: its
-// diffusivity, where its gam goes and where its pivots go.  Without double diffusion dift and difs are the same
-// numbers (rimix_mod.F90:95-97 sets them equal, blmix and enhance treat them alike), so T and S share one
-// diffusivity row and one factorisation: both lanes form the same gam and pivots and store them to the same
-// places (gam over the diffusivities just consumed, the pivots in the row difs would have had); the momentum
-// system keeps difm, gam and its pivots for the V sweep.  With double diffusion the pivots of T and S go to two
-// staging rows that are dead by then, so no lane's store needs a predicate.
+// The rows of tridiagonal system `sys` (0 momentum, 1 temperature, 2 salinity) of kernel variant XV.  L5, which forms
+// the final diffusivities, leaves the sweeps their products with the grid's tri(:,0:1): p(i) = tri(i,1) diff(i)
+// and q(i) = tri(i,0) diff(i-1) (= -cl(i), -cu(i) of tridcof, solvers.F90:28-40; the level that owns diff(i)
+// writes p(i) and q(i+1)), so a level of the sweep fetches two operands less and multiplies twice less.  The
+// pivots go over p (level i-1's, in a register by then), gam over q - except the momentum system's, whose q the
+// V sweep needs again: its gam has a row of its own.  Without double diffusion dift and difs are the same numbers
+// (rimix_mod.F90:95-97 sets them equal, blmix and enhance treat them alike), so T and S share p, q and one
+// factorisation: both lanes form the same gam and pivots and store them to the same places.  With double
+// diffusion S has its own rows among the staging rows that are dead by then.  L6 reads the diffusivities of T
+// and S themselves (rows dl6).
 template <int XV> struct ps_sysrows {
   static constexpr bool DD = XV == 2;
-  __device__ static __forceinline__ int d(int sys) { return sys == 0 ? (int)Q_DM : (DD && sys == 2) ? (int)Q_DS : (int)Q_DT; }
-  __device__ static __forceinline__ int gam(int sys) { return sys == 0 ? (int)Q_GM : d(sys); }
-  __device__ static __forceinline__ int bet(int sys) { return sys == 0 ? (int)Q_BET : DD ? (sys == 1 ? (int)Q_X1 : (int)Q_X2) : (int)Q_DS; }
+  __device__ static __forceinline__ int p(int sys) { return sys == 0 ? (int)Q_DM : (DD && sys == 2) ? (int)Q_DS : (int)Q_DT; }
+  __device__ static __forceinline__ int q(int sys) { return sys == 0 ? (int)Q_GM : (DD && sys == 2) ? (int)Q_S1 : (int)Q_BET; }
+  __device__ static __forceinline__ int gam(int sys) { return sys == 0 ? gam_m : q(sys); }
+  __device__ static __forceinline__ int bet(int sys) { return p(sys); }
+  static constexpr int gam_m = DD ? (int)Q_S2 : (int)Q_DS;   // gam of the momentum system, M4..M5
+  static constexpr int dl6_t = DD ? (int)Q_X1 : (int)Q_DS, dl6_s = DD ? (int)Q_X2 : (int)Q_DS;   // dift, difs L5..L6
 };
 
 // tridcof + tridmat, forward part (solvers.F90:14-44, 112-154) for U, T, S, skewed by one level: iteration i forms
 // gam(i) = cl(i-1)/bet(i-1) and y(i-1) = num(i-1)/bet(i-1) over the same denominator.  lane = (slot, system).
 template <int XV>
-__device__ __forceinline__ void ps_thomas_uts_fwd(int W, double *slots, int SS, int CS, int nz, const double *c_t0,
-                                                  const double *c_t1, const int *sact, int sact_stride, int *sbad,
-                                                  int sbad_stride, int lane)
+__device__ __forceinline__ void ps_thomas_uts_fwd(int W, double *slots, int SS, int nz, const int *sact, int sact_stride,
+                                                  int *sbad, int sbad_stride, int lane)
 {
   constexpr int KS = XV == 2 ? (int)Q_COUNT_EXT_DD : XV == 1 ? (int)Q_COUNT_EXT : (int)Q_COUNT;
   if (lane < 3 * W) {
     const int sl = lane / 3, sys = lane - 3 * sl;
     if (sact[sl * sact_stride]) {
       double *base = slots + sl * SS;
-      const double *d = base + ps_sysrows<XV>::d(sys);
-      double *y = base + (Q_YU + sys), *gm = base + ps_sysrows<XV>::gam(sys), *betp = base + ps_sysrows<XV>::bet(sys);
+      const double *qq = base + ps_sysrows<XV>::q(sys);
+      double *y = base + (Q_YU + sys), *gm = base + ps_sysrows<XV>::gam(sys), *pb = base + ps_sysrows<XV>::p(sys);
       int bad = 0;
       // The coefficients of tridcof share their products: with p(i) = tri(i,1) diff(i) and q(i) = tri(i,0) diff(i-1)
       //   cl(i) = -p(i), cu(i) = -q(i), cc(i) = (1 + p(i)) + q(i)      (solvers.F90:28-40, same roundings: a
-      //   negation is exact), so a level forms p and q once; cu*x is -(q*x) exactly, hence cc - cu*gam = cc + q*gam.
-      double dm1 = d[(1) * KS];
-      double pm1 = c_t1[(1) * CS] * dm1;   // p(1)
+      //   negation is exact); cu*x is -(q*x) exactly, hence cc - cu*gam = cc + q*gam.
+      double pm1 = pb[(1) * KS];           // p(1)
       double bet = 1. + pm1;               // cc(1)
       double ynum = y[(1) * KS];           // y(1) = rhs(1)/bet, formed in the next level's step
       // One level: the pivot chain bet -> 1/bet -> gam -> bet' interleaved with the solution chain, both on
@@ -300,48 +305,46 @@ __device__ __forceinline__ void ps_thomas_uts_fwd(int W, double *slots, int SS, 
       // tiny non-zero solution numerator that div_fast must not see; they practically never occur, so a trip of two
       // levels runs straight through, the state each of its levels started from is tested once at its end, and if
       // any lane of the wave was in either condition the trip is redone from its saved state with IEEE sequences.
-      auto level = [&](int i, double di, double t0, double t1, double rhs, auto slow) {
+      auto level = [&](int i, double p, double q, double rhs, auto slow) {
         if (slow.value && bet == 0.) { bad = 1; bet = 1.E-12; }
         const double clm1 = -pm1;
-        const double q = t0 * dm1;          // -cu(i)
-        const double p = t1 * di;           // -cl(i)
         const double cc = (1. + p) + q;
         const double rb = rcp_refine(bet);
         const double g = slow.value ? div_by_refined(clm1, bet, rb) : div_fast(clm1, bet, rb);
         const double yprev = slow.value ? div_by_refined(ynum, bet, rb) : div_fast(ynum, bet, rb);
-        betp[(i - 1) * KS] = bet;
+        pb[(i - 1) * KS] = bet;
         y[(i - 1) * KS] = yprev;
         gm[(i) * KS] = g;
         bet = cc + q * g;
         ynum = rhs + q * yprev;
-        dm1 = di; pm1 = p;
+        pm1 = p;
       };
       bool f_in = tiny_nonzero(ynum);   // of the state the next level starts from
       {   // two levels per trip; each half's operands are fetched while the other half runs
         int i = 2;
-        double a_d = d[(2) * KS], a_t0 = c_t0[(2) * CS], a_t1 = c_t1[(2) * CS], a_r = y[(2) * KS];
+        double a_p = pb[(2) * KS], a_q = qq[(2) * KS], a_r = y[(2) * KS];
         for (; i + 1 <= nz; i += 2) {
-          const double b_d = d[(i + 1) * KS], b_t0 = c_t0[(i + 1) * CS], b_t1 = c_t1[(i + 1) * CS], b_r = y[(i + 1) * KS];
-          const double s_dm1 = dm1, s_pm1 = pm1, s_bet = bet, s_ynum = ynum;
-          level(i, a_d, a_t0, a_t1, a_r, std::false_type{});
+          const double b_p = pb[(i + 1) * KS], b_q = qq[(i + 1) * KS], b_r = y[(i + 1) * KS];
+          const double s_pm1 = pm1, s_bet = bet, s_ynum = ynum;
+          level(i, a_p, a_q, a_r, std::false_type{});
           const bool f_mid = tiny_nonzero(ynum) || bet == 0.;
-          level(i + 1, b_d, b_t0, b_t1, b_r, std::false_type{});
+          level(i + 1, b_p, b_q, b_r, std::false_type{});
           if (__builtin_expect(__builtin_amdgcn_ballot_w64(f_in || f_mid) != 0ull, 0)) {
-            dm1 = s_dm1; pm1 = s_pm1; bet = s_bet; ynum = s_ynum;
-            level(i, a_d, a_t0, a_t1, a_r, std::true_type{});
-            level(i + 1, b_d, b_t0, b_t1, b_r, std::true_type{});
+            pm1 = s_pm1; bet = s_bet; ynum = s_ynum;
+            level(i, a_p, a_q, a_r, std::true_type{});
+            level(i + 1, b_p, b_q, b_r, std::true_type{});
           }
           f_in = tiny_nonzero(ynum) || bet == 0.;
-          if (i + 2 <= nz) { a_d = d[(i + 2) * KS]; a_t0 = c_t0[(i + 2) * CS]; a_t1 = c_t1[(i + 2) * CS]; a_r = y[(i + 2) * KS]; }
+          if (i + 2 <= nz) { a_p = pb[(i + 2) * KS]; a_q = qq[(i + 2) * KS]; a_r = y[(i + 2) * KS]; }
         }
         if (i <= nz) {
-          if (__builtin_expect(__builtin_amdgcn_ballot_w64(f_in) != 0ull, 0)) level(i, a_d, a_t0, a_t1, a_r, std::true_type{});
-          else level(i, a_d, a_t0, a_t1, a_r, std::false_type{});
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(f_in) != 0ull, 0)) level(i, a_p, a_q, a_r, std::true_type{});
+          else level(i, a_p, a_q, a_r, std::false_type{});
         }
       }
       if (bet == 0.) { bad = 1; bet = 1.E-12; }
       y[(nz) * KS] = div_by_refined(ynum, bet, rcp_refine(bet));
-      betp[(nz) * KS] = bet;
+      pb[(nz) * KS] = bet;
       if (bad) sbad[sl * sbad_stride] = 1;
     }
   }
@@ -360,10 +363,10 @@ __device__ __forceinline__ void ps_thomas_uts_back(int W, double *slots, int SS,
   }
 }
 
-// V on the stored momentum factorisation, forward part; lane = slot.  L7 (all threads) has left beside the pivots
-// (Q_BET) their refined reciprocals (row Q_DS) and q(i) = tri(i,0) difm(i-1) = -cu(i) (row Q_DT) - the values the U
-// sweep formed (same functions of the same arguments), in two rows that are dead once T and S are solved - so a
-// level is n = rhs + q y (= rhs - cu y, ocnint / solvers.F90:153) and one div_fast.  A tiny non-zero numerator
+// V on the stored momentum factorisation, forward part; lane = slot.  The U sweep has left the pivots (Q_DM) and
+// kept q(i) = tri(i,0) difm(i-1) = -cu(i) (row Q_GM); L7 (all threads) has put the refined reciprocals of the
+// pivots beside them (row Q_DT, dead once T and S are solved) - so a level is n = rhs + q y (= rhs - cu y,
+// ocnint / solvers.F90:153) and one div_fast.  A tiny non-zero numerator
 // (which div_fast must not see) is looked for once per trip of two levels, after the fact; the trip is then
 // redone from the value it started with, with IEEE divisions.  118 cycles per level alone on a CU (150 with
 // compiler-scheduled reads of single values; tools/ubench/sweeps.hip).
@@ -372,32 +375,33 @@ __device__ __forceinline__ void ps_thomas_v_fwd(int W, double *slots, int SS, in
 {
   if (lane < W && sact[lane * sact_stride]) {
     double *base = slots + lane * SS;
-    const double *betm = base + Q_BET, *rbm = base + Q_DS, *qm = base + Q_DT;
+    const double *betm = base + Q_DM, *rbm = base + Q_DT, *qm = base + Q_GM;
     double *y = base + Q_YV;
     const double b1 = betm[(1) * KS];
     double yy = div_by_refined(y[(1) * KS], b1, rbm[(1) * KS]);
     y[(1) * KS] = yy;
     asm volatile("" : "+v"(yy));   // the waits for its operands here, not inside the loop below
     int i = 2;
-    // A trip is two levels; its eight operands - (q, 1/bet) and (rhs, bet) of either level, neighbours in the slot's
+    // A trip is two levels; its eight operands - (1/bet, q) and (bet, rhs) of either level, all in the slot's
     // level-interleaved block - come with four ds_read2_b64 issued one trip ahead (ps_lds_read2 / ps_lds_wait, above).
     if (i + 1 <= nz) {
-      static_assert(Q_DT == 1 && Q_DS == 2 && Q_YV == 6 && Q_BET == 8, "offsets of the V sweep's operands in a level block");
+      static_assert(Q_DM == 0 && Q_DT == 1 && Q_YV == 6 && Q_GM == 7, "offsets of the V sweep's operands in a level block");
       const unsigned step = 2u * (unsigned)KS * 8u;
       unsigned ad = ps_lds_addr(base + i * KS);
-      auto rd_qr0 = [&](unsigned a) { return ps_lds_read2<1, 2>(a); };
-      auto rd_hb0 = [&](unsigned a) { return ps_lds_read2<6, 8>(a); };
-      auto rd_qr1 = [&](unsigned a) { return KS == 9 ? ps_lds_read2<10, 11>(a) : KS == 11 ? ps_lds_read2<12, 13>(a) : ps_lds_read2<16, 17>(a); };
-      auto rd_hb1 = [&](unsigned a) { return KS == 9 ? ps_lds_read2<15, 17>(a) : KS == 11 ? ps_lds_read2<17, 19>(a) : ps_lds_read2<21, 23>(a); };
-      auto body = [&](unsigned aw, const ps_d2 &qr0, const ps_d2 &hb0, const ps_d2 &qr1, const ps_d2 &hb1) {
+      // rq = (1/bet, q), bh = (bet, rhs)
+      auto rd_qr0 = [&](unsigned a) { return ps_lds_read2<1, 7>(a); };
+      auto rd_hb0 = [&](unsigned a) { return ps_lds_read2<0, 6>(a); };
+      auto rd_qr1 = [&](unsigned a) { return KS == 9 ? ps_lds_read2<10, 16>(a) : KS == 11 ? ps_lds_read2<12, 18>(a) : ps_lds_read2<16, 22>(a); };
+      auto rd_hb1 = [&](unsigned a) { return KS == 9 ? ps_lds_read2<9, 15>(a) : KS == 11 ? ps_lds_read2<11, 17>(a) : ps_lds_read2<15, 21>(a); };
+      auto body = [&](unsigned aw, const ps_d2 &rq0, const ps_d2 &bh0, const ps_d2 &rq1, const ps_d2 &bh1) {
         const double y_in = yy;
-        const double n0 = hb0.x + qr0.x * yy;
-        double y0 = div_fast(n0, hb0.y, qr0.y);
-        const double n1 = hb1.x + qr1.x * y0;
-        double y1 = div_fast(n1, hb1.y, qr1.y);
+        const double n0 = bh0.y + rq0.y * yy;
+        double y0 = div_fast(n0, bh0.x, rq0.x);
+        const double n1 = bh1.y + rq1.y * y0;
+        double y1 = div_fast(n1, bh1.x, rq1.x);
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(tiny_nonzero(n0) || tiny_nonzero(n1)) != 0ull, 0)) {
-          y0 = (hb0.x + qr0.x * y_in) / hb0.y;
-          y1 = (hb1.x + qr1.x * y0) / hb1.y;
+          y0 = (bh0.y + rq0.y * y_in) / bh0.x;
+          y1 = (bh1.y + rq1.y * y0) / bh1.x;
         }
         yy = y1;
         if (KS == 9) ps_lds_write2<6, 15>(aw, y0, y1);
@@ -436,12 +440,12 @@ __device__ __forceinline__ void ps_thomas_v_fwd(int W, double *slots, int SS, in
   }
 }
 
-__device__ __forceinline__ void ps_thomas_v_back(int W, double *slots, int SS, int KS, int nz, const int *sact,
+__device__ __forceinline__ void ps_thomas_v_back(int W, double *slots, int SS, int KS, int gam_row, int nz, const int *sact,
                                                  int sact_stride, int lane)
 {
   if (lane < W && sact[lane * sact_stride]) {
     double *base = slots + lane * SS;
-    ps_backsub(base + Q_YV, base + Q_GM, KS, nz);
+    ps_backsub(base + Q_YV, base + gam_row, KS, nz);
   }
 }
 
@@ -673,7 +677,6 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         // from them here (index 1: salinity, 2: temperature)
         constexpr int MS = DD ? 1 : 2;   // first of the scalar systems to evaluate
         {
-          const double wm = wm_1, ws = ws_1;
           int ifx = (int)(caseA + epsln20);
           int kn = ifx * (kbl - 1) + (1 - ifx) * kbl;
           double hmkn = c_hm[kn], hmkn1 = c_hm[kn + 1];
@@ -691,9 +694,11 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
             dh[m] = dd[m][kn] + dp[m] * delhat;
           }
           double u4 = ((ustar * ustar) * ustar) * ustar;
-          const double u4e = u4 + epsln20, wme = wm + epsln20, wse = ws + epsln20;
-          const double r_wme = rcp_refine(wme), r_wse = rcp_refine(wse);
+          const double u4e = u4 + epsln20;
           double f1 = div_fast(stable * 5.0 * bfsfc, u4e, rcp_refine(u4e));
+          const double wm = wm_1, ws = ws_1;
+          const double wme = wm + epsln20, wse = ws + epsln20;
+          const double r_wme = rcp_refine(wme), r_wse = rcp_refine(wse);
           gat1[0] = div_fast(div_fast(dh[0], hbl, r_hbl), wme, r_wme);
           dat1[0] = div_fast(-dp[0], wme, r_wme) + f1 * dh[0];
           dat1[0] = dmin2(dat1[0], 0.);
@@ -1312,7 +1317,16 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         difm = b0; difs = b1; dift = b2; ghat = gh;
       }
       if (k >= nz) { difm = 0.0001; difs = 0.00001; dift = 0.00001; ghat = 0.0; }
-      row(Q_DM)[k] = difm; if (DD) row(Q_DS)[k] = difs; row(Q_DT)[k] = dift; row(Q_YV)[k] = ghat;
+      // what the sweeps take: p(k) = tri(k,1) diff(k), q(k+1) = tri(k+1,0) diff(k) (ps_sysrows); L6: dift, difs, ghat
+      if (k <= nz) {
+        const double t1k = c_t1[k];
+        row(Q_DM)[k] = t1k * difm; row(Q_DT)[k] = t1k * dift; if (DD) row(Q_DS)[k] = t1k * difs;
+        if (k < nz) {
+          const double t0n = c_t0[k + 1];
+          row(Q_GM)[k + 1] = t0n * difm; row(Q_BET)[k + 1] = t0n * dift; if (DD) row(Q_S1)[k + 1] = t0n * difs;
+        }
+      }
+      row(ps_sysrows<XV>::dl6_t)[k] = dift; if (DD) row(ps_sysrows<XV>::dl6_s)[k] = difs; row(Q_YV)[k] = ghat;
       if (p.diag && si[I_MAYBE]) {   // the sweeps reuse these rows: what the last vmix leaves behind goes out now
         const size_t od = ro + k;
         p.difm[od] = difm; p.difs[od] = difs; p.dift[od] = dift;
@@ -1327,7 +1341,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     if (do_ocnint) {
       FOR_ITEMS
         if (!act) continue;
-        const strided<ROWS> aDt = row(Q_DT), aDs = row(DD ? (int)Q_DS : (int)Q_DT), aGh = row(Q_YV);
+        const strided<ROWS> aDt = row(ps_sysrows<XV>::dl6_t), aDs = row(ps_sysrows<XV>::dl6_s), aGh = row(Q_YV);
         const double f = sc[C_F];
         const size_t o = ro + (k - 1);
         const double Uo = p.U[o], Vo = p.V[o], To = p.T[o], So = p.S[o];
@@ -1336,7 +1350,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         const strided<ROWS> yU = row(Q_YU), yT = row(Q_YT), yS = row(Q_YS);
         if (actz) {
           const double V = first_ ? rV : xs_[LS];   // of the iterate (its row holds ghat by now)
-          const double difm = row(Q_DM)[k], difs = aDs[k], dift = aDt[k], ghat = aGh[k];
+          const double difm = 0.0001 /* only level nz asks: kppmix / L5 */, difs = aDs[k], dift = aDt[k], ghat = aGh[k];
           const int jer = si[I_JER];
           const double rho0cp0 = sc[C_RHO0CP0], r_rc = sc[C_RRC], sflux3 = sc[C_SFLUX3];
           const double dt_m1 = aDt[k - 1], ds_m1 = aDs[k - 1];
@@ -1374,8 +1388,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 
     // ---- M4: Thomas factorise + sweep for U, T, S (solvers.F90:14-44, 112-161)
     if (wv == mgr && do_ocnint) {
-      ps_thomas_uts_fwd<XV>(W, slots, SS, K_STRIDE, nz, cst + K_T0, cst + K_T1, sirec + I_ACT, I_COUNT, sirec + I_BAD,
-                            I_COUNT, lane);
+      ps_thomas_uts_fwd<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
       STAMP(24);
       ps_thomas_uts_back<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, lane);
      
@@ -1394,15 +1407,14 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         const strided<ROWS> yU = row(Q_YU), yV = row(Q_YV);
         if (actz) {
           // beside the right-hand side, what the V sweep needs of the momentum factorisation apart from the
-          // recurrence itself: the refined reciprocal of the pivot and q = tri(k,0) difm(k-1) = -cu(k), exactly the
-          // values the U sweep formed, into the two rows the T and S systems are done with
-          row(Q_DS)[k] = rcp_refine(row(Q_BET)[k]);
-          row(Q_DT)[k] = c_t0[k] * row(Q_DM)[k - 1];
+          // recurrence itself: the refined reciprocal of the pivot, exactly the value the U sweep formed, into a
+          // row the T and S systems are done with
+          row(Q_DT)[k] = rcp_refine(row(Q_DM)[k]);
           const double un = yU[k];
           double rhsV;
           if (k == 1) rhsV = Vo - dto * (f * .5 * (Uo + un) + div_fast(sc[C_WU02], c_hm[1], c_misc[0]));
           else rhsV = Vo - dto * f * .5 * (Uo + un);
-          if (k == nz) rhsV = rhsV + c_t1[nz] * row(Q_DM)[k] * p.V[ro + (nzp1 - 1)];
+          if (k == nz) rhsV = rhsV + c_t1[nz] * 0.0001 /* difm(nz): kppmix / L5 */ * p.V[ro + (nzp1 - 1)];
           yV[k] = rhsV;
         } else {
           yV[k] = Vo;
@@ -1418,7 +1430,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       if (do_ocnint) {
         ps_thomas_v_fwd(W, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane);
         STAMP(25);
-        ps_thomas_v_back(W, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane);
+        ps_thomas_v_back(W, slots, SS, ROWS, ps_sysrows<XV>::gam_m, nz, sirec + I_ACT, I_COUNT, lane);
       }
       G_late();
      

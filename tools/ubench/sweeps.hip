@@ -30,8 +30,9 @@ __global__ __launch_bounds__(1024) void k_sweep(int W, int nz, int busy, unsigne
     const int sl = i / NL, k = i - sl * NL;
     double *my = slots + sl * SS + k * ROWS;
     my[Q_YU] = 0.1 + 0.001 * k; my[Q_YT] = 10.0 + 0.01 * k; my[Q_YS] = 0.2 - 0.001 * k; my[Q_YV] = 0.05 + 0.001 * k;
-    my[Q_BET] = 1.5 + 0.001 * k; my[Q_GM] = -0.2; my[Q_DS] = TEST == T_V_FWD ? 1. / (1.5 + 0.001 * k) : 1.5;
-    if (TEST == T_V_FWD) my[Q_DT] = 0.3;
+    if (TEST == T_FUSED_FWD) { my[Q_DM] = 0.31 + 0.001 * k; my[Q_DT] = 0.29; my[Q_GM] = 0.3; my[Q_BET] = 0.28 + 0.001 * k; }   // p, q
+    if (TEST == T_V_FWD) { my[Q_DM] = 1.5 + 0.001 * k; my[Q_DT] = 1. / (1.5 + 0.001 * k); my[Q_GM] = 0.3; }   // pivots, reciprocals, q
+    if (TEST == T_BACK || TEST == T_V_BACK) { my[Q_DS] = -0.2; my[Q_BET] = -0.2; }   // gam
   }
   __syncthreads();
   unsigned long long t0 = 0, t1 = 0;
@@ -39,10 +40,10 @@ __global__ __launch_bounds__(1024) void k_sweep(int W, int nz, int busy, unsigne
   if (wv == 0) {
     t0 = __builtin_amdgcn_s_memtime();
     if (TEST == T_FUSED_FWD)
-      ps_thomas_uts_fwd<XV>(W, slots, SS, K_STRIDE, nz, cst + K_T0, cst + K_T1, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+      ps_thomas_uts_fwd<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
     if (TEST == T_BACK) ps_thomas_uts_back<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, lane);
     if (TEST == T_V_FWD) ps_thomas_v_fwd(W, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane);
-    if (TEST == T_V_BACK) ps_thomas_v_back(W, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane);
+    if (TEST == T_V_BACK) ps_thomas_v_back(W, slots, SS, ROWS, ps_sysrows<XV>::gam_m, nz, sirec + I_ACT, I_COUNT, lane);
     if (TEST == T_SCAN) ps_scan_rib(W, Q_YV, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane);
     if (TEST == T_CHAIN) {
       double a0 = slots[lane], a1 = slots[lane + 64], a2 = slots[lane + 128], a3 = slots[lane + 192];
