@@ -611,8 +611,9 @@ def main():
         # the drop-in loop once more, now that the device is in its sustained state (a long model run's condition;
         # the first measurement above follows a 0.14 s burst, and the host's waits between steps let the clock sag)
         again, _ = drop_in_block(mk, ctx, k3, 1 + SPINUP + a.warmup + a.sustained_steps + quarter, nocean,
-                                 (("scalars", mk.api.F_SCALARS, 40),))
+                                 (("scalars", mk.api.F_SCALARS, 40), ("restart_set", mk.api.F_RESTART, 8)))
         out["drop_in"]["scalars_after_the_sustained_leg"] = again["scalars"]
+        out["drop_in"]["restart_set_after_the_sustained_leg"] = again["restart_set"]
         ctx.close()
         del ctx, k3, kc
         gc.collect()
