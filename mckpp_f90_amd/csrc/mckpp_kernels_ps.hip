@@ -1078,9 +1078,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 
   // =========================== persistent pass loop ===========================
 #ifdef MCKPP_PS_STAMPS   // profiling build: per-segment cycle sums kept in registers by the manager wave
-  unsigned long long tacc[27];
+  unsigned long long tacc[31];
 #pragma unroll
-  for (int i = 0; i < 27; ++i) tacc[i] = 0;
+  for (int i = 0; i < 31; ++i) tacc[i] = 0;
   unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #define STAMP(i)                                              \
   do {                                                        \
@@ -1450,20 +1450,16 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     // finishing slot are what the last ocnint returned: they stay in the slot's solution rows (Q_YU, Q_YV,
     // Q_YT, Q_YS) and every sub-phase works on them in place.  INIT / VMIX have no solution: U,V,T,S are the
     // column's own rows in HBM.
+    // (one phase: the terms of the rms differences are formed whether or not some level violates the bounds; the
+    // decision below looks at them only if none did)
     FOR_ITEMS
       if (!act) continue;   // the two equation-of-state items exist for L1 only
-      if (si[I_FIN] != F_TRAP) continue;   // :200-207
-      const double U = row(Q_YU)[k], V = row(Q_YV)[k], T = row(Q_YT)[k], tk1 = row(Q_YT)[k + 1];
+      if (si[I_FIN] != F_TRAP) continue;   // :200-219
+      const size_t o = ro + (k - 1);
+      const double U = row(Q_YU)[k], V = row(Q_YV)[k], T = row(Q_YT)[k], S = row(Q_YS)[k], tk1 = row(Q_YT)[k + 1];
+      const double Uo = p.U[o], Vo = p.V[o], To = p.T[o], So = p.S[o];
       const bool v = actz && (__builtin_fabs(U) >= 10 || __builtin_fabs(V) >= 10 || __builtin_fabs(T - tk1) >= 10);
       if (v) atomicAdd(&si[I_NVIOL], 1);
-    END_ITEMS
-    __syncthreads();
-    FOR_ITEMS
-      if (!act) continue;   // the two equation-of-state items exist for L1 only
-      if (!(si[I_FIN] == F_TRAP && si[I_NVIOL] == 0 && act)) continue;   // :208-219
-      const size_t o = ro + (k - 1);
-      const double U = row(Q_YU)[k], V = row(Q_YV)[k], T = row(Q_YT)[k], S = row(Q_YS)[k];
-      const double Uo = p.U[o], Vo = p.V[o], To = p.T[o], So = p.S[o];
       const double hk = c_hm[k];
       row(Q_DM)[k] = (U - Uo) * (U - Uo) * hk / p.dm_nz;
       row(Q_DT)[k] = (V - Vo) * (V - Vo) * hk / p.dm_nz;
@@ -1471,6 +1467,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       row(Q_GM)[k] = (S - So) * (S - So) * hk / p.dm_nz;
     END_ITEMS
     __syncthreads();
+    STAMP(26);
     if (wv == mgr) {   // trap decision, one lane per (slot, profile) for the rmsd sums, then one per slot
       if (lane < W) sirec[lane * I_COUNT + I_NOVER] = 0;
       for (int l = lane; l < 4 * W; l += 64) {
@@ -1478,8 +1475,13 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         int *msi = sirec + ms * I_COUNT;
         if (msi[I_ACT] && msi[I_FIN] == F_TRAP && msi[I_NVIOL] == 0) {
           const strided<ROWS> t{slots + ms * SS + (mq == 3 ? (int)Q_GM : (int)Q_DM + mq)};
-          double sum = 0.;
-          for (int q = 1; q <= nzp1; ++q) sum = sum + t[q];
+          double sum = 0.;   // in the reference's order; eight terms fetched at a time, then added one by one
+          int q = 1;
+          for (; q + 7 <= nzp1; q += 8) {
+            const double a0 = t[q], a1 = t[q + 1], a2 = t[q + 2], a3 = t[q + 3], a4 = t[q + 4], a5 = t[q + 5], a6 = t[q + 6], a7 = t[q + 7];
+            sum = sum + a0; sum = sum + a1; sum = sum + a2; sum = sum + a3; sum = sum + a4; sum = sum + a5; sum = sum + a6; sum = sum + a7;
+          }
+          for (; q <= nzp1; ++q) sum = sum + t[q];
           sum = __builtin_sqrt(sum);
           if (sum >= 1.0) atomicAdd(&msi[I_NOVER], 1);
         }
@@ -1515,6 +1517,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       }
     }
     __syncthreads();
+    STAMP(27);
     // ---- outputs.  Diagnostic fluxes (ocnstep_mod.F90:242-256 / initialize_ocean.F90:66-81) from the final
     // profiles and their k+1 neighbours; STEP: level-1 references, then (optional physics) current damping.
     FOR_ITEMS
@@ -1578,6 +1581,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       }
     END_ITEMS
     __syncthreads();   // the k+1 neighbours above are read from the rows that check_profile rewrites below
+    STAMP(28);
     // ---- STEP: new time level, check_profile (overrides.F90:42-125); the optional parts count over all
     // levels of the column: LDS counters between workgroup barriers (EXT build).
     FOR_ITEMS
@@ -1705,14 +1709,17 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       }
     END_ITEMS
     __syncthreads();   // every read of the finished slots' records is done: hand them to the queue
+    STAMP(29);
     if (wv == mgr) M0();
     __syncthreads();
+    STAMP(30);
   }
 #ifdef MCKPP_PS_STAMPS
   if (p.dbg && wv == mgr && lane == 0) {
     for (int i = 0; i < 23; ++i) atomicAdd((unsigned long long *)p.dbg + i, tacc[i]);
     atomicAdd((unsigned long long *)p.dbg + 24, tacc[24]);   // of M4: its forward part
     atomicAdd((unsigned long long *)p.dbg + 25, tacc[25]);   // of M5: its forward part
+    for (int i = 26; i < 31; ++i) atomicAdd((unsigned long long *)p.dbg + i, tacc[i]);   // parts of the finish round
     atomicAdd((unsigned long long *)p.dbg + 31, tacc[23]);
   }
 #endif

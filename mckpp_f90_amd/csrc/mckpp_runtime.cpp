@@ -916,6 +916,13 @@ int mckpp_hip_synchronize(mckpp_hip_handle h)
         fprintf(stderr, " %s=%.0f", nm[i], (double)t[i] / (double)t[31]);
         tot += (double)t[i];
       }
+      {   // the finish round in parts (its own accumulators; "finish" above is what follows the last of them)
+        const char *fn[5] = {"trap-terms", "trap-decision", "outputs", "time-level+check_profile", "refill"};
+        double fin = (double)t[22];
+        fprintf(stderr, " [finish:");
+        for (int i = 0; i < 5; ++i) { fprintf(stderr, " %s=%.0f", fn[i], (double)t[26 + i] / (double)t[31]); fin += (double)t[26 + i]; tot += (double)t[26 + i]; }
+        fprintf(stderr, " all=%.0f]", fin / (double)t[31]);
+      }
       fprintf(stderr, " total=%.0f\n", tot / (double)t[31]);
     }
   }
