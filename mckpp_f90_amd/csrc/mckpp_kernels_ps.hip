@@ -1542,9 +1542,11 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         {
           if (actz) {
             const double dfm = p.difm[od], dfs = p.difs[od], dft = p.dift[od], gh = p.ghat[od];   // stored by L5 of this pass
-            p.wXNT1[od] = (ntime >= 1) ? -sflux3 * p.swdk_tab[si[I_JER] * p.ldc + k] / rho0cp0 : 0.0;
+            // (every load of the item before its first store: one memory round trip, not two)
+            const double talpha = flux_diag ? p.talpha[od] : 0.0, sbeta = flux_diag ? p.sbeta[od] : 0.0;   // of the last vmix (L1 of this pass)
+            const double swdk = (ntime >= 1) ? p.swdk_tab[si[I_JER] * p.ldc + k] : 0.0;
+            p.wXNT1[od] = (ntime >= 1) ? -sflux3 * swdk / rho0cp0 : 0.0;
             if (flux_diag) {
-              const double talpha = p.talpha[od], sbeta = p.sbeta[od];   // of the last vmix (L1 of this pass)
               double deltaz = 0.5 * (c_hm[k] + c_hm[k + 1]);
               double wX1 = -dfs * ((T - tk1) / deltaz - gh * wX0_1);
               double wX2 = -dfs * ((S - sk1) / deltaz - gh * wX0_2);
