@@ -48,12 +48,12 @@ enum {
 };
 // LDS rows of a slot and what each holds between which phases of a pass:
 //   Q_DM   (LDD talpha L1..L2; else the whole-layer terms of the reference-level sum of U, L2)  difm: interior L3;
-//          from L5 p = tri(:,1) difm of the momentum system, which its pivots overwrite in M4 (kept to M5)
+//          from L5 p = tri(:,1) difm of the momentum system (to L7)
 //   Q_DT   Ritop L2..L3; dift interior L3; from L5 p of the T system (without double diffusion: of T and S, whose
-//          difs = dift bit for bit, one factorisation for both), its pivots in M4; refined reciprocals of the
-//          momentum pivots L7..M5 (V sweep)
-//   Q_DS   dVsq L2..L3; with double diffusion difs L3, p and the pivots of the S system L5..M4; without it dift
-//          for L6 (L5..L6), then gam of the momentum system M4..M5
+//          difs = dift bit for bit, one factorisation for both) to M4; refined reciprocals of the momentum
+//          pivots L7..M5 (V sweep)
+//   Q_DS   dVsq L2..L3; with double diffusion difs L3, p of the S system L5..M4; without it dift for L6 (L5..L6),
+//          then gam of the momentum system M4..M5
 //   Q_YU   previous U solution .. L1; U of the iterate L1..L2; Monin-Obukhov depth L3..L4; rhs L6; solution M4
 //   Q_YT   previous T solution .. L1; dbloc L2..L3; rhs L6; solution M4
 //   Q_YS   previous S solution .. L1; buoyancy L1..L2; hmin candidates L4..M3; rhs L6; solution M4
@@ -61,7 +61,7 @@ enum {
 //          rhs L7; solution M5
 //   Q_GM   Rig L2..L3; q = tri(:,0) difm(k-1) of the momentum system L5..M5 (U and V sweeps)
 //   Q_BET  (LDD T L1..L2; else the whole-layer terms of V, L2) q of the T (and S) system L5..M4, which its gam
-//          overwrites level by level
+//          overwrites level by level; pivots of the momentum system L7..M5 (V sweep)
 // In the instability trap Q_DM, Q_DT, Q_DS, Q_GM carry the four rmsd terms, in the isotherm check Q_DM, Q_DT.
 // Optional-physics builds: rho, cp (L1..L6); with double diffusion also Q_X1, Q_X2: alphaDT, betaDS (L2..L3), then
 // dift, difs for L6; Q_S1, Q_S2: LDD sbeta and S (L1..L2), then q / gam of the S system and gam of the momentum system.  Three kernel variants XV: 0 default physics (9 rows), 1 optional physics (11), 2 optional physics
@@ -263,9 +263,11 @@ __device__ __forceinline__ void ps_backsub(double *y, const double *gm, int KS, 
 // The rows of tridiagonal system `sys` (0 momentum, 1 temperature, 2 salinity) of kernel variant XV.  L5, which forms
 // the final diffusivities, leaves the sweeps their products with the grid's tri(:,0:1): p(i) = tri(i,1) diff(i)
 // and q(i) = tri(i,0) diff(i-1) (= -cl(i), -cu(i) of tridcof, solvers.F90:28-40; the level that owns diff(i)
-// writes p(i) and q(i+1)), so a level of the sweep fetches two operands less and multiplies twice less.  The
-// pivots go over p (level i-1's, in a register by then), gam over q - except the momentum system's, whose q the
-// V sweep needs again: its gam has a row of its own.  Without double diffusion dift and difs are the same numbers
+// writes p(i) and q(i+1)), so a level of the sweep fetches two operands less and multiplies twice less.  gam goes
+// over q - except the momentum system's, whose q the V sweep needs again: its gam has a row of its own.  The
+// pivots are not stored (a store costs the sweep as much as three fp64 operations): what the V sweep needs of
+// them, L7 forms again from p, q and gam - bet(1) = 1 + p(1), bet(i) = ((1 + p(i)) + q(i)) + q(i) gam(i), the
+// sweep's own operations on the sweep's own operands.  Without double diffusion dift and difs are the same numbers
 // (rimix_mod.F90:95-97 sets them equal, blmix and enhance treat them alike), so T and S share p, q and one
 // factorisation: both lanes form the same gam and pivots and store them to the same places.  With double
 // diffusion S has its own rows among the staging rows that are dead by then.  L6 reads the diffusivities of T
@@ -275,7 +277,6 @@ template <int XV> struct ps_sysrows {
   __device__ static __forceinline__ int p(int sys) { return sys == 0 ? (int)Q_DM : (DD && sys == 2) ? (int)Q_DS : (int)Q_DT; }
   __device__ static __forceinline__ int q(int sys) { return sys == 0 ? (int)Q_GM : (DD && sys == 2) ? (int)Q_S1 : (int)Q_BET; }
   __device__ static __forceinline__ int gam(int sys) { return sys == 0 ? gam_m : q(sys); }
-  __device__ static __forceinline__ int bet(int sys) { return p(sys); }
   static constexpr int gam_m = DD ? (int)Q_S2 : (int)Q_DS;   // gam of the momentum system, M4..M5
   static constexpr int dl6_t = DD ? (int)Q_X1 : (int)Q_DS, dl6_s = DD ? (int)Q_X2 : (int)Q_DS;   // dift, difs L5..L6
 };
@@ -291,8 +292,8 @@ __device__ __forceinline__ void ps_thomas_uts_fwd(int W, double *slots, int SS, 
     const int sl = lane / 3, sys = lane - 3 * sl;
     if (sact[sl * sact_stride]) {
       double *base = slots + sl * SS;
-      const double *qq = base + ps_sysrows<XV>::q(sys);
-      double *y = base + (Q_YU + sys), *gm = base + ps_sysrows<XV>::gam(sys), *pb = base + ps_sysrows<XV>::p(sys);
+      const double *qq = base + ps_sysrows<XV>::q(sys), *pb = base + ps_sysrows<XV>::p(sys);
+      double *y = base + (Q_YU + sys), *gm = base + ps_sysrows<XV>::gam(sys);
       int bad = 0;
       // The coefficients of tridcof share their products: with p(i) = tri(i,1) diff(i) and q(i) = tri(i,0) diff(i-1)
       //   cl(i) = -p(i), cu(i) = -q(i), cc(i) = (1 + p(i)) + q(i)      (solvers.F90:28-40, same roundings: a
@@ -312,7 +313,6 @@ __device__ __forceinline__ void ps_thomas_uts_fwd(int W, double *slots, int SS, 
         const double rb = rcp_refine(bet);
         const double g = slow.value ? div_by_refined(clm1, bet, rb) : div_fast(clm1, bet, rb);
         const double yprev = slow.value ? div_by_refined(ynum, bet, rb) : div_fast(ynum, bet, rb);
-        pb[(i - 1) * KS] = bet;
         y[(i - 1) * KS] = yprev;
         gm[(i) * KS] = g;
         bet = cc + q * g;
@@ -344,7 +344,6 @@ __device__ __forceinline__ void ps_thomas_uts_fwd(int W, double *slots, int SS, 
       }
       if (bet == 0.) { bad = 1; bet = 1.E-12; }
       y[(nz) * KS] = div_by_refined(ynum, bet, rcp_refine(bet));
-      pb[(nz) * KS] = bet;
       if (bad) sbad[sl * sbad_stride] = 1;
     }
   }
@@ -363,10 +362,10 @@ __device__ __forceinline__ void ps_thomas_uts_back(int W, double *slots, int SS,
   }
 }
 
-// V on the stored momentum factorisation, forward part; lane = slot.  The U sweep has left the pivots (Q_DM) and
-// kept q(i) = tri(i,0) difm(i-1) = -cu(i) (row Q_GM); L7 (all threads) has put the refined reciprocals of the
-// pivots beside them (row Q_DT, dead once T and S are solved) - so a level is n = rhs + q y (= rhs - cu y,
-// ocnint / solvers.F90:153) and one div_fast.  A tiny non-zero numerator
+// V on the stored momentum factorisation, forward part; lane = slot.  The U sweep has kept q(i) = tri(i,0)
+// difm(i-1) = -cu(i) (row Q_GM); L7 (all threads) has formed the pivots again and their refined reciprocals
+// (rows Q_BET and Q_DT, dead once T and S are solved) - so a level is n = rhs + q y (= rhs - cu y, ocnint /
+// solvers.F90:153) and one div_fast.  A tiny non-zero numerator
 // (which div_fast must not see) is looked for once per trip of two levels, after the fact; the trip is then
 // redone from the value it started with, with IEEE divisions.  118 cycles per level alone on a CU (150 with
 // compiler-scheduled reads of single values; tools/ubench/sweeps.hip).
@@ -375,33 +374,33 @@ __device__ __forceinline__ void ps_thomas_v_fwd(int W, double *slots, int SS, in
 {
   if (lane < W && sact[lane * sact_stride]) {
     double *base = slots + lane * SS;
-    const double *betm = base + Q_DM, *rbm = base + Q_DT, *qm = base + Q_GM;
+    const double *betm = base + Q_BET, *rbm = base + Q_DT, *qm = base + Q_GM;
     double *y = base + Q_YV;
     const double b1 = betm[(1) * KS];
     double yy = div_by_refined(y[(1) * KS], b1, rbm[(1) * KS]);
     y[(1) * KS] = yy;
     asm volatile("" : "+v"(yy));   // the waits for its operands here, not inside the loop below
     int i = 2;
-    // A trip is two levels; its eight operands - (1/bet, q) and (bet, rhs) of either level, all in the slot's
+    // A trip is two levels; its eight operands - (1/bet, q) and (rhs, bet) of either level, all in the slot's
     // level-interleaved block - come with four ds_read2_b64 issued one trip ahead (ps_lds_read2 / ps_lds_wait, above).
     if (i + 1 <= nz) {
-      static_assert(Q_DM == 0 && Q_DT == 1 && Q_YV == 6 && Q_GM == 7, "offsets of the V sweep's operands in a level block");
+      static_assert(Q_DT == 1 && Q_YV == 6 && Q_GM == 7 && Q_BET == 8, "offsets of the V sweep's operands in a level block");
       const unsigned step = 2u * (unsigned)KS * 8u;
       unsigned ad = ps_lds_addr(base + i * KS);
-      // rq = (1/bet, q), bh = (bet, rhs)
+      // rq = (1/bet, q), hb = (rhs, bet)
       auto rd_qr0 = [&](unsigned a) { return ps_lds_read2<1, 7>(a); };
-      auto rd_hb0 = [&](unsigned a) { return ps_lds_read2<0, 6>(a); };
+      auto rd_hb0 = [&](unsigned a) { return ps_lds_read2<6, 8>(a); };
       auto rd_qr1 = [&](unsigned a) { return KS == 9 ? ps_lds_read2<10, 16>(a) : KS == 11 ? ps_lds_read2<12, 18>(a) : ps_lds_read2<16, 22>(a); };
-      auto rd_hb1 = [&](unsigned a) { return KS == 9 ? ps_lds_read2<9, 15>(a) : KS == 11 ? ps_lds_read2<11, 17>(a) : ps_lds_read2<15, 21>(a); };
-      auto body = [&](unsigned aw, const ps_d2 &rq0, const ps_d2 &bh0, const ps_d2 &rq1, const ps_d2 &bh1) {
+      auto rd_hb1 = [&](unsigned a) { return KS == 9 ? ps_lds_read2<15, 17>(a) : KS == 11 ? ps_lds_read2<17, 19>(a) : ps_lds_read2<21, 23>(a); };
+      auto body = [&](unsigned aw, const ps_d2 &rq0, const ps_d2 &hb0, const ps_d2 &rq1, const ps_d2 &hb1) {
         const double y_in = yy;
-        const double n0 = bh0.y + rq0.y * yy;
-        double y0 = div_fast(n0, bh0.x, rq0.x);
-        const double n1 = bh1.y + rq1.y * y0;
-        double y1 = div_fast(n1, bh1.x, rq1.x);
+        const double n0 = hb0.x + rq0.y * yy;
+        double y0 = div_fast(n0, hb0.y, rq0.x);
+        const double n1 = hb1.x + rq1.y * y0;
+        double y1 = div_fast(n1, hb1.y, rq1.x);
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(tiny_nonzero(n0) || tiny_nonzero(n1)) != 0ull, 0)) {
-          y0 = (bh0.y + rq0.y * y_in) / bh0.x;
-          y1 = (bh1.y + rq1.y * y0) / bh1.x;
+          y0 = (hb0.x + rq0.y * y_in) / hb0.y;
+          y1 = (hb1.x + rq1.y * y0) / hb1.y;
         }
         yy = y1;
         if (KS == 9) ps_lds_write2<6, 15>(aw, y0, y1);
@@ -1407,9 +1406,14 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         const strided<ROWS> yU = row(Q_YU), yV = row(Q_YV);
         if (actz) {
           // beside the right-hand side, what the V sweep needs of the momentum factorisation apart from the
-          // recurrence itself: the refined reciprocal of the pivot, exactly the value the U sweep formed, into a
-          // row the T and S systems are done with
-          row(Q_DT)[k] = rcp_refine(row(Q_DM)[k]);
+          // recurrence itself: the pivot and its refined reciprocal, exactly the values the U sweep formed (same
+          // operations on the same p, q, gam; solvers.F90:140-151's replacement of a zero pivot included), into
+          // two rows the T and S systems are done with
+          const double pk = row(Q_DM)[k], qk = row(Q_GM)[k], gk = row(ps_sysrows<XV>::gam_m)[k];
+          double betk = (k == 1) ? 1. + pk : ((1. + pk) + qk) + qk * gk;
+          if (betk == 0.) betk = 1.E-12;
+          row(Q_BET)[k] = betk;
+          row(Q_DT)[k] = rcp_refine(betk);
           const double un = yU[k];
           double rhsV;
           if (k == 1) rhsV = Vo - dto * (f * .5 * (Uo + un) + div_fast(sc[C_WU02], c_hm[1], c_misc[0]));

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(1024) void k_sweep(int W, int nz, int busy, unsigne
     double *my = slots + sl * SS + k * ROWS;
     my[Q_YU] = 0.1 + 0.001 * k; my[Q_YT] = 10.0 + 0.01 * k; my[Q_YS] = 0.2 - 0.001 * k; my[Q_YV] = 0.05 + 0.001 * k;
     if (TEST == T_FUSED_FWD) { my[Q_DM] = 0.31 + 0.001 * k; my[Q_DT] = 0.29; my[Q_GM] = 0.3; my[Q_BET] = 0.28 + 0.001 * k; }   // p, q
-    if (TEST == T_V_FWD) { my[Q_DM] = 1.5 + 0.001 * k; my[Q_DT] = 1. / (1.5 + 0.001 * k); my[Q_GM] = 0.3; }   // pivots, reciprocals, q
+    if (TEST == T_V_FWD) { my[Q_BET] = 1.5 + 0.001 * k; my[Q_DT] = 1. / (1.5 + 0.001 * k); my[Q_GM] = 0.3; }   // pivots, reciprocals, q
     if (TEST == T_BACK || TEST == T_V_BACK) { my[Q_DS] = -0.2; my[Q_BET] = -0.2; }   // gam
   }
   __syncthreads();
