@@ -292,7 +292,10 @@ __device__ __forceinline__ void ps_thomas_uts_fwd(int W, double *slots, int SS, 
     const int sl = lane / 3, sys = lane - 3 * sl;
     if (sact[sl * sact_stride]) {
       double *base = slots + sl * SS;
-      const double *qq = base + ps_sysrows<XV>::q(sys), *pb = base + ps_sysrows<XV>::p(sys);
+      // (without double diffusion q sits seven rows after p in either system: one base, so that the two come with
+      // one ds_read2_b64)
+      static_assert(XV == 2 || ((int)Q_GM - (int)Q_DM == 7 && (int)Q_BET - (int)Q_DT == 7), "p and q rows");
+      const double *pb = base + ps_sysrows<XV>::p(sys), *qq = XV == 2 ? base + ps_sysrows<XV>::q(sys) : pb + 7;
       double *y = base + (Q_YU + sys), *gm = base + ps_sysrows<XV>::gam(sys);
       int bad = 0;
       // The coefficients of tridcof share their products: with p(i) = tri(i,1) diff(i) and q(i) = tri(i,0) diff(i-1)
