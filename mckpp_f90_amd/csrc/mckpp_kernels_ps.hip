@@ -410,14 +410,40 @@ __device__ __forceinline__ void ps_thomas_v_fwd(int W, double *slots, int SS, in
         else if (KS == 11) ps_lds_write2<6, 17>(aw, y0, y1);
         else ps_lds_write2<6, 21>(aw, y0, y1);
       };
+      // two levels on div_fast; says whether either numerator was one that div_fast must not see
+      auto fast2 = [&](const ps_d2 &rq0, const ps_d2 &hb0, const ps_d2 &rq1, const ps_d2 &hb1, double &y0, double &y1) -> bool {
+        const double n0 = hb0.x + rq0.y * yy;
+        y0 = div_fast(n0, hb0.y, rq0.x);
+        const double n1 = hb1.x + rq1.y * y0;
+        y1 = div_fast(n1, hb1.y, rq1.x);
+        yy = y1;
+        return tiny_nonzero(n0) || tiny_nonzero(n1);
+      };
+      auto store2 = [&](unsigned aw, double y0, double y1) {
+        if (KS == 9) ps_lds_write2<6, 15>(aw, y0, y1);
+        else if (KS == 11) ps_lds_write2<6, 17>(aw, y0, y1);
+        else ps_lds_write2<6, 21>(aw, y0, y1);
+      };
       ps_d2 a0 = rd_qr0(ad), a1 = rd_hb0(ad), a2 = rd_qr1(ad), a3 = rd_hb1(ad), b0, b1_, b2, b3;
-      while (i + 5 <= nz) {   // this trip, the next, and one more after it
+      while (i + 5 <= nz) {   // this trip, the next, and one more after it; one vote on the numerators per two trips
         b0 = rd_qr0(ad + step); b1_ = rd_hb0(ad + step); b2 = rd_qr1(ad + step); b3 = rd_hb1(ad + step);
         ps_lds_wait<4>(a0, a1, a2, a3);
-        body(ad, a0, a1, a2, a3);
+        const double y_in = yy, rhs0 = a1.x, rhs1 = a3.x;   // what a redo of the first trip needs (its solution replaces rhs)
+        double ya0, ya1, yb0, yb1;
+        const bool fa = fast2(a0, a1, a2, a3, ya0, ya1);
+        store2(ad, ya0, ya1);
         a0 = rd_qr0(ad + 2 * step); a1 = rd_hb0(ad + 2 * step); a2 = rd_qr1(ad + 2 * step); a3 = rd_hb1(ad + 2 * step);
         ps_lds_wait<4>(b0, b1_, b2, b3);
-        body(ad + step, b0, b1_, b2, b3);
+        const bool fb = fast2(b0, b1_, b2, b3, yb0, yb1);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(fa || fb) != 0ull, 0)) {   // the four levels again, IEEE divisions
+          ya0 = (rhs0 + qm[(i) * KS] * y_in) / betm[(i) * KS];
+          ya1 = (rhs1 + qm[(i + 1) * KS] * ya0) / betm[(i + 1) * KS];
+          y[(i) * KS] = ya0; y[(i + 1) * KS] = ya1;
+          yb0 = (b1_.x + b0.y * ya1) / b1_.y;
+          yb1 = (b3.x + b2.y * yb0) / b3.y;
+          yy = yb1;
+        }
+        store2(ad + step, yb0, yb1);
         i += 4; ad += 2 * step;
       }
       if (i + 3 <= nz) {
