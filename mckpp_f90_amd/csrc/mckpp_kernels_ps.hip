@@ -151,14 +151,20 @@ __device__ __forceinline__ double ps_max(double a, double b)
 
 // bldepth_mod.F90:137: Rib(ku) = MAX(Rib(ku), Rib(ka) + epsln) down the column, four levels per trip, the next
 // trip's values fetched before the current trip's recurrence runs
+// Only the levels down to the first one whose running maximum exceeds Ricr matter: L4 looks for the shallowest
+// level that satisfies one of its criteria, the interpolated depth of that crossing (bldepth_mod.F90:139-150) is
+// one of them and lies within the level where it happens or the next (a quotient that rounds to one), so whatever
+// the rows hold further down cannot win.  The scan stops eight levels after the last of the workgroup's columns
+// has crossed (the running maximum never falls); a column that never crosses keeps it going to the bottom.
 __device__ __forceinline__ void ps_scan_rib(int W, int row, double *slots, int SS, int KS, int nz, const int *sact,
-                                            int sact_stride, int lane)
+                                            int sact_stride, int lane, double Ricr)
 {
   const double epsln16 = 1.e-16;
   if (lane < W && sact[lane * sact_stride]) {
     double *r = slots + lane * SS + row;
     double rb = 0.0;
     int k = 2;
+    bool stop = false;   // every column of the wave had crossed before the last eight levels scanned
     if (k + 3 <= nz) {   // a trip: levels k .. k+3; KS = 9, 11 or 15 doubles per level
       const unsigned step = 4u * (unsigned)KS * 8u;
       unsigned ad = ps_lds_addr(r + k * KS);
@@ -175,7 +181,8 @@ __device__ __forceinline__ void ps_scan_rib(int W, int row, double *slots, int S
         else { ps_lds_write2<0, 15>(aw, b0, b1); ps_lds_write2<30, 45>(aw, b2, rb); }
       };
       ps_d2 a01 = rd_lo(ad), a23 = rd_hi(ad), b01, b23;
-      while (k + 11 <= nz) {   // this trip, the next, and one more after it
+      while (k + 11 <= nz && !stop) {   // this trip, the next, and one more after it
+        const double rb_in = rb;
         b01 = rd_lo(ad + step); b23 = rd_hi(ad + step);
         ps_lds_wait<2>(a01, a23);
         body(k, a01, a23);
@@ -183,25 +190,28 @@ __device__ __forceinline__ void ps_scan_rib(int W, int row, double *slots, int S
         ps_lds_wait<2>(b01, b23);
         body(k + 4, b01, b23);
         k += 8; ad += 2 * step;
+        stop = __builtin_amdgcn_ballot_w64(!(rb_in > Ricr)) == 0ull;
       }
-      if (k + 7 <= nz) {
-        b01 = rd_lo(ad + step); b23 = rd_hi(ad + step);
-        ps_lds_wait<2>(a01, a23);
-        body(k, a01, a23);
-        ps_lds_wait<0>(b01, b23);
-        body(k + 4, b01, b23);
-        k += 8;
-      } else {
-        ps_lds_wait<0>(a01, a23);
+      // (past the loop nothing stays in flight across a branch: see ps_backsub)
+      ps_lds_wait<0>(a01, a23);   // on a stop: fetched, not needed
+      if (!stop) {
         body(k, a01, a23);
         k += 4;
+        if (k + 3 <= nz) {
+          b01 = rd_lo(ad + step); b23 = rd_hi(ad + step);
+          ps_lds_wait<0>(b01, b23);
+          body(k, b01, b23);
+          k += 4;
+        }
       }
       ps_lds_drain();
     }
+    if (!stop) {
 #pragma nounroll
-    for (; k <= nz; ++k) {   // the last one to three levels
-      rb = dmax2(r[k * KS], rb + epsln16);
-      r[k * KS] = rb;
+      for (; k <= nz; ++k) {   // the last one to three levels
+        rb = dmax2(r[k * KS], rb + epsln16);
+        r[k * KS] = rb;
+      }
     }
   }
 }
@@ -239,16 +249,17 @@ __device__ __forceinline__ void ps_backsub(double *y, const double *gm, int KS, 
       body(i - 4, b0, b1, b2, b3);
       i -= 8; ay -= 2 * step; ag -= 2 * step;
     }
-    if (i >= 8) {
+    // Past the loop nothing stays in flight across a branch: between a read and its wait the value is an ordinary
+    // variable for the compiler, and a copy it makes there (it does where paths merge) copies what the register
+    // held before the read lands - the hardware does not interlock LDS returns (tools/check_inflight.py looks for
+    // such copies in the generated code).
+    ps_lds_wait<0>(a0, a1, a2, a3);
+    body(i, a0, a1, a2, a3);
+    i -= 4;
+    if (i >= 4) {
       b0 = rd_lo(ay - step); b1 = rd_hi(ay - step); b2 = rd_lo(ag - step); b3 = rd_hi(ag - step);
-      ps_lds_wait<4>(a0, a1, a2, a3);
-      body(i, a0, a1, a2, a3);
       ps_lds_wait<0>(b0, b1, b2, b3);
-      body(i - 4, b0, b1, b2, b3);
-      i -= 8;
-    } else {
-      ps_lds_wait<0>(a0, a1, a2, a3);
-      body(i, a0, a1, a2, a3);
+      body(i, b0, b1, b2, b3);
       i -= 4;
     }
     ps_lds_drain();
@@ -446,16 +457,14 @@ __device__ __forceinline__ void ps_thomas_v_fwd(int W, double *slots, int SS, in
         store2(ad + step, yb0, yb1);
         i += 4; ad += 2 * step;
       }
-      if (i + 3 <= nz) {
+      // (past the loop nothing stays in flight across a branch: see ps_backsub)
+      ps_lds_wait<0>(a0, a1, a2, a3);
+      body(ad, a0, a1, a2, a3);
+      i += 2;
+      if (i + 1 <= nz) {
         b0 = rd_qr0(ad + step); b1_ = rd_hb0(ad + step); b2 = rd_qr1(ad + step); b3 = rd_hb1(ad + step);
-        ps_lds_wait<4>(a0, a1, a2, a3);
-        body(ad, a0, a1, a2, a3);
         ps_lds_wait<0>(b0, b1_, b2, b3);
         body(ad + step, b0, b1_, b2, b3);
-        i += 4;
-      } else {
-        ps_lds_wait<0>(a0, a1, a2, a3);
-        body(ad, a0, a1, a2, a3);
         i += 2;
       }
       ps_lds_drain();
@@ -1242,7 +1251,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(5);
 
     // ---- M2: Rib(ku) = MAX(Rib(ku), Rib(ka)+epsln), bldepth_mod.F90:137
-    if (wv == mgr) { ps_scan_rib(W, Q_YV, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane); }
+    if (wv == mgr) { ps_scan_rib(W, Q_YV, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane, Ricr); }
     STAMP(6);
     __syncthreads();
     STAMP(7);

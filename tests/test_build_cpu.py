@@ -1,4 +1,4 @@
-"""Build guards that need no GPU: the register budget of the column kernel.
+"""Build guards that need no GPU: the register budget of the column kernel, and its hand-scheduled LDS reads.
 
 The launcher's geometry (16 waves per CU) assumes at most 128 VGPRs per lane, and the kernel's speed depends on
 nothing being spilled to scratch memory - it is one 1,500-line persistent loop compiled with
@@ -37,3 +37,39 @@ def test_column_kernel_fits_its_register_budget():
         assert k["vgpr_spill_count"] == 0, f"{n}: {k['vgpr_spill_count']} VGPRs spilled to scratch"
         assert k["private_segment_fixed_size"] == 0, f"{n}: uses {k['private_segment_fixed_size']} B of scratch per lane"
         assert k["vgpr_count"] <= 128, f"{n}: {k['vgpr_count']} VGPRs - 16 waves per CU need <= 128"
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_no_instruction_touches_a_register_with_an_lds_read_in_flight():
+    """The serial sweeps issue their LDS reads through asm statements one trip ahead and wait for them with explicit
+    counts (ps_lds_read2 / ps_lds_wait).  In between the value is an ordinary variable for the compiler; a copy it
+    inserts there (where paths merge, or when it splits a live range) copies what the register held before the read
+    lands - the hardware does not interlock LDS returns - and the result depends on timing.  tools/check_inflight.py
+    follows every asm-issued read through the generated code of the three kernel variants."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_inflight
+
+    text = check_inflight.isa_text()
+    assert text.count("ds_read2_b64") > 50, "the kernel's assembly does not look like k_column_ps"
+    bad = check_inflight.check(text)
+    assert not bad, "\n".join(f"{k[:40]} line {i}: {s} (read of line {ln})" for k, i, s, ln in bad[:20])
+    # the checker itself: a copy of a register between its read and the wait is reported
+    probe = """_Zprobe:
+\t;;#ASMSTART
+\tds_read2_b64 v[2:5], v1 offset0:0 offset1:9
+\t;;#ASMEND
+\ts_cbranch_scc1 .LBB9_2
+.LBB9_1:
+\tv_mov_b64_e32 v[6:7], v[2:3]
+.LBB9_2:
+\t;;#ASMSTART
+\ts_waitcnt lgkmcnt(0)
+\t;;#ASMEND
+\tv_add_f64 v[8:9], v[2:3], v[4:5]
+\ts_endpgm
+.Lfunc_end9:
+"""
+    found = check_inflight.check(probe)
+    assert [f[1] for f in found] == [7], found
