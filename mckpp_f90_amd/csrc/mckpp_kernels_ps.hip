@@ -156,8 +156,9 @@ __device__ __forceinline__ double ps_max(double a, double b)
 // one of them and lies within the level where it happens or the next (a quotient that rounds to one), so whatever
 // the rows hold further down cannot win.  The scan stops eight levels after the last of the workgroup's columns
 // has crossed (the running maximum never falls); a column that never crosses keeps it going to the bottom.
+// *kdone: the deepest level whose running maximum is in place (nz unless the scan stopped early).
 __device__ __forceinline__ void ps_scan_rib(int W, int row, double *slots, int SS, int KS, int nz, const int *sact,
-                                            int sact_stride, int lane, double Ricr)
+                                            int sact_stride, int lane, double Ricr, int *kdone)
 {
   const double epsln16 = 1.e-16;
   if (lane < W && sact[lane * sact_stride]) {
@@ -213,6 +214,7 @@ __device__ __forceinline__ void ps_scan_rib(int W, int row, double *slots, int S
         r[k * KS] = rb;
       }
     }
+    *kdone = stop ? k - 1 : nz;   // the same for every column of the wave
   }
 }
 
@@ -1251,15 +1253,29 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(5);
 
     // ---- M2: Rib(ku) = MAX(Rib(ku), Rib(ka)+epsln), bldepth_mod.F90:137
-    if (wv == mgr) { ps_scan_rib(W, Q_YV, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane, Ricr); }
+    if (wv == mgr) {
+      if (lane == 0) s_flags[2] = nz;
+      ps_scan_rib(W, Q_YV, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane, Ricr, &s_flags[2]);
+    }
     STAMP(6);
     __syncthreads();
     STAMP(7);
 
     // ---- L4: first level with hmin < -zm(k) (bldepth_mod.F90:139-180): every hit level posts its hmin,
-    //          the shallowest one wins through an LDS minimum
-    FOR_ITEMS
-      if (!act) continue;   // the two equation-of-state items exist for L1 only
+    //          the shallowest one wins through an LDS minimum.  Level-major order: the levels below the one the
+    //          scan stopped at cannot be the first (ps_scan_rib), and the waves that hold only such levels have
+    //          nothing to do - with the boundary layer in the upper third of the column the phase is one trip
+    //          of the item loop on a few waves.
+    for (int it_ = tid, t_ = 0; it_ < nitems_lm; it_ = tid2 >= 0 ? nthreads + t_ * nhelp + tid2 : nitems_lm, ++t_) {
+      const int k = (W == 1 ? it_ : (int)__umulhi((unsigned)it_, Wmagic)) + 1;   // item = (level-1)*W + slot, rising
+      if (k > s_flags[2]) break;   // and so are the levels of a thread's later items
+      const int slot = it_ - (k - 1) * W;
+      int *const si = sirec + slot * I_COUNT;
+      if (!si[I_ACT]) continue;
+      double *const my = slots + slot * SS;
+      double *const sc = screc + slot * C_COUNT;
+      const bool actz = k <= nz;
+      auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };
       const strided<ROWS> aRaw = row(Q_YV), aDmo = row(Q_YU);
       const double zmk = c_zm[k];
       const double ocdepth = sc[C_OCDEPTH];
@@ -1286,11 +1302,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         double hmin2 = dmin2(dmin2(hri, hmonob), -ocdepth);
         if (hmin2 < -zmk) hmin = hmin2;
       }
-      if (hit) row(Q_YS)[k] = hmin;
-      // only a hit whose shallower neighbour (same wave, same column since k >= 2) did not hit can be the first
-      const unsigned long long m = __ballot(hit);
-      const bool prev = lane > 0 && ((m >> (lane - 1)) & 1ull);
-      if (hit && !prev) atomicMin(&si[I_KBLC], k);
+      if (hit) { row(Q_YS)[k] = hmin; atomicMin(&si[I_KBLC], k); }
     END_ITEMS
     STAMP(8);
     __syncthreads();
