@@ -89,7 +89,7 @@ __host__ __device__ inline int ps_scratch_ld(int nzp1) { return (nzp1 + 7) & ~7;
 __host__ __device__ inline size_t ps_lds_bytes(int L, int W, int xv)
 {
   return (size_t)(K_STRIDE * ps_nl(L) + 2 + W * ps_ss(L, xv) + W * C_COUNT) * sizeof(double) +
-         (size_t)(W * I_COUNT + 4) * sizeof(int);
+         (size_t)(W * I_COUNT + 8) * sizeof(int);
 }
 
 
@@ -156,15 +156,18 @@ __device__ __forceinline__ double ps_max(double a, double b)
 // one of them and lies within the level where it happens or the next (a quotient that rounds to one), so whatever
 // the rows hold further down cannot win.  The scan stops eight levels after the last of the workgroup's columns
 // has crossed (the running maximum never falls); a column that never crosses keeps it going to the bottom.
-// *kdone: the deepest level whose running maximum is in place (nz unless the scan stopped early).
-__device__ __forceinline__ void ps_scan_rib(int W, int row, double *slots, int SS, int KS, int nz, const int *sact,
-                                            int sact_stride, int lane, double Ricr, int *kdone)
+// The levels k0 .. nz of the rows (k0 = 2, or where an earlier call ended, whose last value is the running maximum
+// to go on from); L3 has formed the bulk Richardson numbers down to level nz only.  out[0]: the deepest level whose
+// running maximum is in place; out[1]: 1 if the scan stopped because every column had crossed.
+__device__ __forceinline__ void ps_scan_rib(int W, int row, double *slots, int SS, int KS, int k0, int nz, const int *sact,
+                                            int sact_stride, int lane, double Ricr, int *out)
 {
   const double epsln16 = 1.e-16;
   if (lane < W && sact[lane * sact_stride]) {
     double *r = slots + lane * SS + row;
-    double rb = 0.0;
-    int k = 2;
+    double rb = k0 > 2 ? r[(k0 - 1) * KS] : 0.0;
+    asm volatile("" : "+v"(rb));   // its wait here, not at its first use inside the loop
+    int k = k0;
     bool stop = false;   // every column of the wave had crossed before the last eight levels scanned
     if (k + 3 <= nz) {   // a trip: levels k .. k+3; KS = 9, 11 or 15 doubles per level
       const unsigned step = 4u * (unsigned)KS * 8u;
@@ -214,7 +217,7 @@ __device__ __forceinline__ void ps_scan_rib(int W, int row, double *slots, int S
         r[k * KS] = rb;
       }
     }
-    *kdone = stop ? k - 1 : nz;   // the same for every column of the wave
+    out[0] = stop ? k - 1 : nz; out[1] = stop ? 1 : 0;   // the same for every column of the wave
   }
 }
 
@@ -517,7 +520,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   double *slots = c_misc + 2;
   double *screc = slots + W * SS;
   int *sirec = reinterpret_cast<int *>(screc + W * C_COUNT);
-  int *s_flags = sirec + W * I_COUNT;   // [0] some slot active, [1] some slot finishing
+  // [0] some slot active, [1] some slot finishing, [2] the level the bulk-Ri scan of this pass ended at, [3] the level
+  // down to which L3 forms the bulk Richardson numbers (a guess from the pass before), [4] the guess was too shallow
+  int *s_flags = sirec + W * I_COUNT;
 
   for (int i = tid; i < NL; i += blockDim.x) {
     c_zm[i] = p.zm[i];
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   }
   if (tid == 0) { c_misc[0] = rcp_refine(p.hm[1]); c_misc[1] = rcp_refine(p.vonk); }
   for (int i = tid; i < W * I_COUNT; i += blockDim.x) sirec[i] = 0;   // every slot PS_EMPTY
-  if (tid < 4) s_flags[tid] = 0;
+  if (tid < 8) s_flags[tid] = tid == 3 ? nz : 0;
   // The manager is wave 0 (the item map below gives it items in the first trip only).  Measured and dropped:
   // electing the wave that sits on a given SIMD, so that the serial chains of all workgroups of a CU share one
   // SIMD (0.8-0.9x), or one SIMD per workgroup chosen from blockIdx (0.97x); raising its s_setprio (0.97x).
@@ -595,6 +600,20 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };             \
     (void)sc; (void)act; (void)actz; (void)is1; (void)isnz; (void)isnzp1; (void)ro; (void)row;
 
+// Level-major order again, plainly rising (item = (level-1)*W + slot, a thread's later items are deeper): for the
+// phases that only have work down to some level - the waves that hold deeper levels fall through.
+#define FOR_ITEMS_RISING                                                                  \
+  for (int it_ = tid, t_ = 0; it_ < nitems_lm; it_ = tid2 >= 0 ? nthreads + t_ * nhelp + tid2 : nitems_lm, ++t_) { \
+    const int k = (W == 1 ? it_ : (int)__umulhi((unsigned)it_, Wmagic)) + 1;              \
+    const int slot = it_ - (k - 1) * W;                                                   \
+    int *const si = sirec + slot * I_COUNT;                                               \
+    if (!si[I_ACT]) continue;                                                             \
+    double *const my = slots + slot * SS;                                                 \
+    double *const sc = screc + slot * C_COUNT;                                            \
+    const bool actz = k <= nz, is1 = k == 1, isnz = k == nz;                              \
+    auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };             \
+    (void)sc; (void)actz; (void)is1; (void)isnz; (void)row;
+
   // =========================== manager phases (wave 0) ===========================
   // M0: slots whose column has finished pull the next one from the queue 
   auto M0 = [&]() {
@@ -625,6 +644,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           msi[I_MAYBE] = (p.mode != MCKPP_MODE_STEP) ? 1 : 0;
           msi[I_KBLC] = 0x7fffffff; msi[I_NVIOL] = 0; msi[I_NU] = 0; msi[I_NV] = 0; msi[I_NF] = 0; msi[I_PAR] = 0;
           msi[I_L1A] = 0; msi[I_MAYBE_NEXT] = msi[I_MAYBE]; msi[I_TINY] = 0;
+          s_flags[3] = nz;   // no guess for a new column: L3 forms the bulk Richardson numbers of every level
           msc[C_F] = cs[CS_F]; msc[C_WXNT0] = 0.0; msc[C_HMIXE] = 0.0; msc[C_HMIXN] = 0.0;
           msc[C_SREF] = cs[CS_SREF]; msc[C_SSURF] = cs[CS_SSURF]; msc[C_OCDEPTH] = cs[CS_OCDEPTH];
           msc[C_SFLUX1] = cs[CS_SFLUX1]; msc[C_SFLUX2] = cs[CS_SFLUX2]; msc[C_SFLUX3] = cs[CS_SFLUX3];
@@ -1181,12 +1201,41 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(3);
 
     // ---- L3: rimix + z121 (rimix_mod.F90:13-106, z121_mod.F90:7-45), ddmix, interior diffusivity rows;
-    //          bldepth, level-parallel part (bldepth_mod.F90:105-147)
-    FOR_ITEMS
-      if (!act) continue;
-      const strided<ROWS> aR = row(Q_GM), aDb = row(Q_YT);
-      const double zmk = c_zm[k], zdiff = zmk - c_zm[k + 1];
-      const double Rig = aR[k], dbloc = aDb[k], Ritop = row(Q_DT)[k], dVsq = row(Q_DS)[k];
+    //          bldepth, level-parallel part (bldepth_mod.F90:105-147) - the bulk Richardson numbers only down to the
+    //          level the scan of the pass before ended at plus eight (they cost two thirds of the phase, and the scan
+    //          will not look further unless the boundary layer has deepened: then the rest is formed after it, below;
+    //          their input Ritop, whose row the interior dift takes, is kept in a free row for that).  Level-major
+    //          order, rising: the waves that hold the deeper levels do the rimix part only.
+    //          (not with double diffusion, whose difs takes the row of dVsq as well: every level at once)
+    const int kguess = DD ? nz : (p.l3cap > 0 && p.l3cap < s_flags[3] ? p.l3cap : s_flags[3]);
+    auto bulk_ri = [&](const int k, int *const si, double *const my, double *const sc, const double Ritop, const double dVsq,
+                       const bool actz, const bool is1) {
+      auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };
+      const strided<ROWS> aDb = row(Q_YT);
+      const double zmk = c_zm[k], zdiff = zmk - c_zm[k + 1], dbloc = aDb[k];
+      const double B0 = sc[C_B0], B0sol = sc[C_B0SOL], ustar = sc[C_USTAR];
+      wscale_u wu;
+      wu.ju = si[I_JU]; wu.ufrac = sc[C_UFRAC]; wu.ustar = ustar; wu.ucube = sc[C_UCUBE];
+      const double zm_kmp1 = c_zm[nzp1];
+      double swf = p.swfrac_tab[si[I_JER] * p.ldc + k];
+      double bf = B0 + B0sol * (1. - swf);
+      double st = 0.5 + dsign(0.5, bf + epsln16);
+      double sg = st * 1. + (1. - st) * eps01;
+      double wm, ws;
+      wscale_dev(p, wu, sg, -zmk, bf, wm, ws);
+      double dbm1 = aDb[k - 1];
+      double bvsq = 0.5 * (div_fast(dbm1, c_zm[k - 1] - zmk, c_rdz[k - 1]) + div_fast(dbloc, zdiff, c_rdz[k]));
+      double Vtsq = -zmk * ws * __builtin_sqrt(__builtin_fabs(bvsq)) * p.Vtc;
+      const double rawden = dVsq + Vtsq + epsln16, bfa = __builtin_fabs(bf) + epsln16;
+      double raw = div_fast(Ritop, rawden, rcp_refine(rawden));
+      double dmo = div_fast(div_fast(cmonob * ustar * ustar * ustar, p.vonk, c_misc[1]), bfa, rcp_refine(bfa));
+      dmo = st * dmo - (1. - st) * zm_kmp1;
+      if (k >= 2 && actz) { row(Q_YV)[k] = raw; row(Q_YU)[k] = dmo; }
+      if (is1) { row(Q_YV)[1] = 0.0; row(Q_YU)[1] = -zm_kmp1; }
+    };
+    FOR_ITEMS_RISING
+      const strided<ROWS> aR = row(Q_GM);
+      const double Rig = aR[k], Ritop = row(Q_DT)[k], dVsq = row(Q_DS)[k];
       const double Riinfty = 0.8;
       double vm1 = aR[k - 1], vp1 = aR[k + 1];
       double wm1 = (k - 1 >= 1 && !((vm1 < 0.0) || (vm1 > Riinfty))) ? 1.0 : 0.0;
@@ -1223,42 +1272,54 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           }
         }
       }
-      const double B0 = sc[C_B0], B0sol = sc[C_B0SOL], ustar = sc[C_USTAR];
-      wscale_u wu;
-      wu.ju = si[I_JU]; wu.ufrac = sc[C_UFRAC]; wu.ustar = ustar; wu.ucube = sc[C_UCUBE];
-      const double zm_kmp1 = c_zm[nzp1];
-      double swf = p.swfrac_tab[si[I_JER] * p.ldc + k];
-      double bf = B0 + B0sol * (1. - swf);
-      double st = 0.5 + dsign(0.5, bf + epsln16);
-      double sg = st * 1. + (1. - st) * eps01;
-      double wm, ws;
-      wscale_dev(p, wu, sg, -zmk, bf, wm, ws);
-      double dbm1 = aDb[k - 1];
-      double bvsq = 0.5 * (div_fast(dbm1, c_zm[k - 1] - zmk, c_rdz[k - 1]) + div_fast(dbloc, zdiff, c_rdz[k]));
-      double Vtsq = -zmk * ws * __builtin_sqrt(__builtin_fabs(bvsq)) * p.Vtc;
-      const double rawden = dVsq + Vtsq + epsln16, bfa = __builtin_fabs(bf) + epsln16;
-      double raw = div_fast(Ritop, rawden, rcp_refine(rawden));
-      double dmo = div_fast(div_fast(cmonob * ustar * ustar * ustar, p.vonk, c_misc[1]), bfa, rcp_refine(bfa));
-      dmo = st * dmo - (1. - st) * zm_kmp1;
+      if (k <= kguess) bulk_ri(k, si, my, sc, Ritop, dVsq, actz, is1);
+      else if (actz) row(Q_BET)[k] = Ritop;   // for the levels below the guess, should the scan get there
       // interior diffusivities (after the reads of Ritop / dVsq, which share their rows)
       // (without double diffusion difs = dift bit for bit: one row, Q_DT, serves both from here on)
       if (actz) { row(Q_DM)[k] = dm_i; if (DD) row(Q_DS)[k] = ds_i; row(Q_DT)[k] = dt_i; }
       if (isnz) { row(Q_DM)[k + 1] = dm_i; if (DD) row(Q_DS)[k + 1] = ds_i; row(Q_DT)[k + 1] = dt_i; }   // kppmix_mod.F90:82-84
       if (is1) { row(Q_DM)[0] = 0.0; if (DD) row(Q_DS)[0] = 0.0; row(Q_DT)[0] = 0.0; }
-      if (k >= 2 && actz) { row(Q_YV)[k] = raw; row(Q_YU)[k] = dmo; }
-      if (is1) { row(Q_YV)[1] = 0.0; row(Q_YU)[1] = -zm_kmp1; }
     END_ITEMS
     STAMP(4);
     __syncthreads();
     STAMP(5);
 
     // ---- M2: Rib(ku) = MAX(Rib(ku), Rib(ka)+epsln), bldepth_mod.F90:137
+    // (the scan runs down to the level L3 went to; if it gets there without every column having crossed Ricr -
+    // the boundary layer has deepened since the pass the guess comes from - the other levels follow)
+    auto scan_result = [&](int kmax) {   // what the scan's outcome means for L4, for a second round and for the next pass
+      if (lane < W && sirec[lane * I_COUNT + I_ACT]) {
+        const int kdone = s_flags[2], stopped = s_flags[5];
+        if (stopped) { s_flags[4] = 0; s_flags[3] = kdone + 8 < nz ? kdone + 8 : nz; }
+        else if (kmax >= nz) { s_flags[4] = 0; s_flags[3] = nz; }
+        else s_flags[4] = 1;
+      }
+    };
     if (wv == mgr) {
-      if (lane == 0) s_flags[2] = nz;
-      ps_scan_rib(W, Q_YV, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane, Ricr, &s_flags[2]);
+      if (lane == 0) { s_flags[2] = nz; s_flags[4] = 0; s_flags[5] = 0; }
+      // levels above the scan's start are taken as they are; the scan's fifth slot of s_flags: its `stopped`
+      {
+        int out[2] = {nz, 0};
+        ps_scan_rib(W, Q_YV, slots, SS, ROWS, 2, kguess, sirec + I_ACT, I_COUNT, lane, Ricr, out);
+        if (lane < W && sirec[lane * I_COUNT + I_ACT]) { s_flags[2] = out[0]; s_flags[5] = out[1]; }
+      }
+      scan_result(kguess);
     }
     STAMP(6);
     __syncthreads();
+    if (s_flags[4]) {   // rare: the bulk Richardson numbers of the levels below the guess, then the scan goes on
+      FOR_ITEMS_RISING
+        if (k > kguess && actz) bulk_ri(k, si, my, sc, row(Q_BET)[k], row(Q_DS)[k], actz, is1);
+      END_ITEMS
+      __syncthreads();
+      if (wv == mgr) {
+        int out[2] = {nz, 0};
+        ps_scan_rib(W, Q_YV, slots, SS, ROWS, kguess + 1, nz, sirec + I_ACT, I_COUNT, lane, Ricr, out);
+        if (lane < W && sirec[lane * I_COUNT + I_ACT]) { s_flags[2] = out[0]; s_flags[5] = out[1]; }
+        scan_result(nz);
+      }
+      __syncthreads();
+    }
     STAMP(7);
 
     // ---- L4: first level with hmin < -zm(k) (bldepth_mod.F90:139-180): every hit level posts its hmin,
@@ -1266,16 +1327,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     //          scan stopped at cannot be the first (ps_scan_rib), and the waves that hold only such levels have
     //          nothing to do - with the boundary layer in the upper third of the column the phase is one trip
     //          of the item loop on a few waves.
-    for (int it_ = tid, t_ = 0; it_ < nitems_lm; it_ = tid2 >= 0 ? nthreads + t_ * nhelp + tid2 : nitems_lm, ++t_) {
-      const int k = (W == 1 ? it_ : (int)__umulhi((unsigned)it_, Wmagic)) + 1;   // item = (level-1)*W + slot, rising
-      if (k > s_flags[2]) break;   // and so are the levels of a thread's later items
-      const int slot = it_ - (k - 1) * W;
-      int *const si = sirec + slot * I_COUNT;
-      if (!si[I_ACT]) continue;
-      double *const my = slots + slot * SS;
-      double *const sc = screc + slot * C_COUNT;
-      const bool actz = k <= nz;
-      auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };
+    FOR_ITEMS_RISING
+      if (k > s_flags[2]) break;   // (a thread's later items are deeper still)
       const strided<ROWS> aRaw = row(Q_YV), aDmo = row(Q_YU);
       const double zmk = c_zm[k];
       const double ocdepth = sc[C_OCDEPTH];

@@ -111,6 +111,7 @@ struct mckpp_hip_ctx {
   double *d_cs = nullptr;
   int *d_ci = nullptr;
   int *d_qhead = nullptr;
+  int l3cap = 0;   // MCKPP_L3_CAP (tests): see mckpp_kparams_t::l3cap
   unsigned long long *d_dbg = nullptr;
   mckpp_kparams *d_params = nullptr;   // device copy of the kernel parameter block
   // its source: two pinned host slots used in turn, so a call never waits for its own upload (a slot is reused
@@ -291,6 +292,7 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
     for (int k = 1; k <= nz; ++k) nref += c->zm[k - 1] > 0.1 * c->zm[nz - 1];
     h->l2pre = (nref >= 16 && !c->LDD) ? 1 : 0;
     if (const char *e = getenv("MCKPP_L2PRE")) h->l2pre = (atoi(e) != 0 && !c->LDD) ? 1 : 0;
+    if (const char *e = getenv("MCKPP_L3_CAP")) h->l3cap = atoi(e) > 0 ? atoi(e) : 0;
   }
   {
     std::vector<double> dm(ldc, 0.0), hs(ldc, 0.0);
@@ -781,7 +783,7 @@ static void fill_params(mckpp_hip_ctx *h, mckpp_kparams &p, int ntime, int mode)
   p.nz = h->nz; p.nzp1 = h->nzp1; p.ncol = (int)h->ncol; p.ld = h->ld;
   p.ntime = ntime; p.itermax = h->c.itermax; p.mode = mode; p.diag = h->diag;
   p.L_SSref = h->c.L_SSref; p.LDD = h->c.LDD; p.clim_present = h->c.clim_present;
-  p.l2pre = h->l2pre; p.LRI = h->c.LRI ? 1 : 0;
+  p.l2pre = h->l2pre; p.LRI = h->c.LRI ? 1 : 0; p.l3cap = h->l3cap;
   p.hmixtolfrac = h->c.hmixtolfrac; p.dto = h->c.dto; p.grav = h->c.grav; p.vonk = h->c.vonk; p.sice = h->c.sice;
   p.Vtc = h->Vtc; p.cg = h->cg; p.dm_nz = h->dm_nz;
   p.zm = h->d_zm; p.hm = h->d_hm; p.tri0 = h->d_tri0; p.tri1 = h->d_tri1;

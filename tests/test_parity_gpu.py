@@ -620,6 +620,21 @@ def test_reference_level_sums_both_ways(mk, monkeypatch, nz, grid, l2pre):
         _assert_bitexact(res, f"nz={nz} {grid} MCKPP_L2PRE={l2pre} {tag}")
 
 
+@pytest.mark.parametrize("nz,grid,cap", [(40, "uniform", "3"), (60, "uniform", "5"), (69, "stretched", "4"), (150, "uniform", "12"),
+                                         (100, "uniform", "2")])
+def test_bulk_richardson_numbers_in_two_rounds(mk, monkeypatch, nz, grid, cap):
+    """L3 forms the bulk Richardson numbers of bldepth (bldepth_mod.F90:105-147) only down to the level the scan of
+    the pass before ended at plus eight, and the scan stops eight levels below the last crossing of Ricr among
+    the workgroup's columns; when it reaches the end of what L3 formed without that, the other levels follow in
+    a second round (the boundary layer has deepened).  MCKPP_L3_CAP caps the guess, so that the second round
+    runs on every pass of every column whose boundary layer is deeper than the cap."""
+    monkeypatch.setenv("MCKPP_L3_CAP", cap)
+    out, k3, ob, kc, oc = _run_both(mk, 83, nz, 2, grid=grid, land_every=5, jerlov_mix=True)
+    for tag, res in out:
+        _assert_bitexact(res, f"nz={nz} {grid} MCKPP_L3_CAP={cap} {tag}")
+    assert np.any(np.asarray(k3.kmix)[np.asarray(k3.run_physics) != 0] > int(cap)), "no column deeper than the cap: nothing tested"
+
+
 @pytest.mark.parametrize("nz,geometry", [(60, "1x1x1"), (60, "3x2x4"), (60, "16x4x2"), (60, "21x16x1"), (60, "5x8x2"),
                                          (23, "21x2x4"), (150, "3x4x2"), (150, "13x16x1")])
 def test_forced_workgroup_geometries(mk, monkeypatch, nz, geometry):

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(1024) void k_sweep(int W, int nz, int busy, unsigne
     if (TEST == T_BACK) ps_thomas_uts_back<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, lane);
     if (TEST == T_V_FWD) ps_thomas_v_fwd(W, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane);
     if (TEST == T_V_BACK) ps_thomas_v_back(W, slots, SS, ROWS, ps_sysrows<XV>::gam_m, nz, sirec + I_ACT, I_COUNT, lane);
-    if (TEST == T_SCAN) ps_scan_rib(W, Q_YV, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane, 1.e300 /* never crossed: the whole column */, &s_flags[2]);
+    if (TEST == T_SCAN) { int out[2]; ps_scan_rib(W, Q_YV, slots, SS, ROWS, 2, nz, sirec + I_ACT, I_COUNT, lane, 1.e300 /* never crossed: the whole column */, out); sink = out[0]; }
     if (TEST == T_CHAIN) {
       double a0 = slots[lane], a1 = slots[lane + 64], a2 = slots[lane + 128], a3 = slots[lane + 192];
       double g0 = slots[lane + 256], g1 = slots[lane + 320], g2 = slots[lane + 384], g3 = slots[lane + 448], x = 1.0 + lane;
