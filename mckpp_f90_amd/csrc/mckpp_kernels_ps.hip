@@ -1369,8 +1369,10 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 
     // ---- L5: blmix shape functions, enhance, combine (blmix_mod.F90:110-133, enhance_mod.F90:10-51,
     //          kppmix_mod.F90:103-111, verticalmixing_mod.F90:151-159) -> final diffusivity rows
-    FOR_ITEMS
-      if (!act) continue;
+    //          (level-major order, rising: the shape functions and their table look-up are for the levels above
+    //          kbl only - the waves that hold deeper levels just pass the interior values on)
+    FOR_ITEMS_RISING
+      const size_t ro = (size_t)si[I_COL] * p.ld;
       const int kbl = si[I_KBL];
       const double zmk = c_zm[k];
       const double dm_i = row(Q_DM)[k], dt_l = row(Q_DT)[k], ds_i = DD ? row(Q_DS)[k] : dt_l;   // interior values of L3
