@@ -1033,23 +1033,24 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   };
 
   // ---- L2 of one item (level k <= nzp1 of a slot): surface-layer reference averages, Ri pieces
-  // (verticalmixing_mod.F90:111-137)
-  auto L2_item = [&](const int k, int *const si, double *const my, double *const sc, const size_t ro, const bool actz,
-                     const bool is1, const bool isnz, const bool isnzp1) {
-    const bool act = true;
+  // (verticalmixing_mod.F90:111-137).  The reference averages (uref, vref, bref: the loop over the layers above a
+  // tenth of the level's depth) feed Ritop and dVsq, which only bldepth's bulk Richardson number uses: they are
+  // formed for the levels L3 will form that number for (`sums`), and later for the others should the scan of M2
+  // ask for them - then from copies of the iterate's U and V in other rows (rU, rV), their own having been reused.
+  auto ref_sums = [&](const int k, int *const si, double *const my, const int rU, const int rV, const bool allow_pre,
+                      const bool actz, double &ur, double &vr, double &br) {
     auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };
-    const strided<ROWS> aU = row(Q_YU), aV = row(Q_YV), aB = row(Q_YS);
-    const double U = act ? aU[k] : 0.0, V = act ? aV[k] : 0.0, buoy = aB[k];
+    const strided<ROWS> aU = row(rU), aV = row(rV), aB = row(Q_YS);
     const double zmk = c_zm[k];
     const double zm1 = c_zm[1];
     const double U1 = aU[1], V1 = aV[1], Bu1 = aB[1];
     const strided<ROWS> aNU = row(Q_DM), aNV = row(Q_BET);   // whole-layer terms of U and V (L2a)
-    const bool pre = p.l2pre != 0;
+    const bool pre = allow_pre && p.l2pre != 0;
     const bool guard = si[I_TINY] != 0;
     const double zref = eps01 * zmk, rzref = rcp_refine(zref);
     double wz = dmax2(zm1, zref);
-    double ur = div_fast_guarded(U1 * wz, zref, rzref), vr = div_fast_guarded(V1 * wz, zref, rzref),
-           br = div_fast(Bu1 * wz, zref, rzref);
+    ur = div_fast_guarded(U1 * wz, zref, rzref); vr = div_fast_guarded(V1 * wz, zref, rzref);
+    br = div_fast(Bu1 * wz, zref, rzref);
     // The layers above zref (verticalmixing_mod.F90:118-131: wz = MIN(dz, zm(kl)-zref), del = 0.5 wz/dz).  Every
     // layer but the one zref lies in is taken whole - wz = dz, del = 0.5 exactly - and needs neither the minimum
     // nor the division; the one partial layer is the last of its lane and is done after the loop.
@@ -1110,23 +1111,36 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       vr = vr - div_fast_guarded(wz2 * (Vl + del * (Vl1 - Vl)), zref, rzref);
       br = br - div_fast(wz2 * (Bl + del * (Bl1 - Bl)), zref, rzref);
     }
+  };
+  auto L2_item = [&](const int k, int *const si, double *const my, double *const sc, const size_t ro, const bool actz,
+                     const bool is1, const bool isnz, const bool isnzp1, const bool sums) {
+    auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };
+    const strided<ROWS> aU = row(Q_YU), aV = row(Q_YV), aB = row(Q_YS);
+    const double U = aU[k], V = aV[k], buoy = aB[k];
+    const double zmk = c_zm[k];
+    if (sums) {
+      double ur, vr, br;
+      ref_sums(k, si, my, Q_YU, Q_YV, true, actz, ur, vr, br);
+      const double zref = eps01 * zmk;
+      const double Ritop = (zref - zmk) * (br - buoy);
+      const double dVsq = (ur - U) * (ur - U) + (vr - V) * (vr - V);
+      if (p.mode != MCKPP_MODE_STEP && isnz) { sc[C_UREFNZ] = ur; sc[C_VREFNZ] = vr; }
+      if (actz) { row(Q_DT)[k] = Ritop; row(Q_DS)[k] = dVsq; }
+    }
     if constexpr (EXT) {
-      if (DD && p.LDD && act) {   // verticalmixing_mod.F90:103-108
+      if (DD && p.LDD) {   // verticalmixing_mod.F90:103-108
         const double talpha = row(Q_DM)[k], sbeta = row(Q_S1)[k], T = row(Q_BET)[k], S = row(Q_S2)[k];
         row(Q_X1)[k] = 0.5 * (talpha + row(Q_DM)[k + 1]) * (T - row(Q_BET)[k + 1]);
         row(Q_X2)[k] = 0.5 * (sbeta + row(Q_S1)[k + 1]) * (S - row(Q_S2)[k + 1]);
       }
     }
     const double bk1 = aB[k + 1], uk1 = aU[k + 1], vk1 = aV[k + 1];
-    const double Ritop = (zref - zmk) * (br - buoy);
     const double dbloc = buoy - bk1;
-    const double dVsq = (ur - U) * (ur - U) + (vr - V) * (vr - V);
     const double shsq = (U - uk1) * (U - uk1) + (V - vk1) * (V - vk1);
-    if (p.mode != MCKPP_MODE_STEP && isnz) { sc[C_UREFNZ] = ur; sc[C_VREFNZ] = vr; }
     const double zdiff = zmk - c_zm[k + 1];
     const double shs = shsq + 1.e-16;
     const double Rig = div_fast(dbloc * zdiff, shs, rcp_refine(shs));
-    if (actz) { row(Q_GM)[k] = Rig; row(Q_YT)[k] = dbloc; row(Q_DT)[k] = Ritop; row(Q_DS)[k] = dVsq; }
+    if (actz) { row(Q_GM)[k] = Rig; row(Q_YT)[k] = dbloc; }
     if (is1) row(Q_GM)[0] = 0.0;
     if (isnzp1) row(Q_GM)[k] = 0.0;
     if (p.diag && si[I_MAYBE]) {
@@ -1183,17 +1197,27 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       __syncthreads();
     }
     // ---- M1 | L2: surface fluxes (wave 0) | reference-level loop, Ri pieces (verticalmixing_mod.F90:111-137)
+    // The bulk Richardson numbers of bldepth, and with them the reference-level averages here, are formed down to
+    // the level the scan of the pass before ended at plus eight (s_flags[3]; every level for a new column, with
+    // double diffusion - whose rows the second round below would need - and in the modes that return uref/vref of
+    // the deepest level).  MCKPP_L3_CAP caps the guess (tests).
+    const int kguess = (DD || p.mode != MCKPP_MODE_STEP) ? nz : (p.l3cap > 0 && p.l3cap < s_flags[3] ? p.l3cap : s_flags[3]);
     if (wv == mgr) M1();
-    // measured: the level-major order pays from ~50 levels on (+2 % at 60, +13 % on the stretched 69-level grid,
-    // -2 % at 40)
-    if (nzp1 >= 50) {
+    if (kguess < nz) {
+      // level-major order, rising: the waves that hold levels below the guess have the cheap part only
+      FOR_ITEMS_RISING
+        L2_item(k, si, my, sc, (size_t)si[I_COL] * p.ld, actz, is1, isnz, k == nzp1, k <= kguess);
+      END_ITEMS
+    } else if (nzp1 >= 50) {
+      // measured: the level-major order (a deep and a shallow item per thread) pays from ~50 levels on (+2 % at 60,
+      // +13 % on the stretched 69-level grid, -2 % at 40)
       FOR_ITEMS_BY_LEVEL
-        L2_item(k, si, my, sc, ro, actz, is1, isnz, isnzp1);
+        L2_item(k, si, my, sc, ro, actz, is1, isnz, isnzp1, true);
       END_ITEMS
     } else {
       FOR_ITEMS
         if (!act) continue;   // the two equation-of-state items exist for L1 only
-        L2_item(k, si, my, sc, ro, actz, is1, isnz, isnzp1);
+        L2_item(k, si, my, sc, ro, actz, is1, isnz, isnzp1, true);
       END_ITEMS
     }
     STAMP(2);
@@ -1201,13 +1225,10 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(3);
 
     // ---- L3: rimix + z121 (rimix_mod.F90:13-106, z121_mod.F90:7-45), ddmix, interior diffusivity rows;
-    //          bldepth, level-parallel part (bldepth_mod.F90:105-147) - the bulk Richardson numbers only down to the
-    //          level the scan of the pass before ended at plus eight (they cost two thirds of the phase, and the scan
-    //          will not look further unless the boundary layer has deepened: then the rest is formed after it, below;
-    //          their input Ritop, whose row the interior dift takes, is kept in a free row for that).  Level-major
-    //          order, rising: the waves that hold the deeper levels do the rimix part only.
-    //          (not with double diffusion, whose difs takes the row of dVsq as well: every level at once)
-    const int kguess = DD ? nz : (p.l3cap > 0 && p.l3cap < s_flags[3] ? p.l3cap : s_flags[3]);
+    //          bldepth, level-parallel part (bldepth_mod.F90:105-147) - the bulk Richardson numbers only down to
+    //          kguess (they cost two thirds of the phase, and the scan will not look further unless the boundary
+    //          layer has deepened: then the rest is formed after it, below).  Level-major order, rising: the waves
+    //          that hold the deeper levels do the rimix part only.
     auto bulk_ri = [&](const int k, int *const si, double *const my, double *const sc, const double Ritop, const double dVsq,
                        const bool actz, const bool is1) {
       auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };
@@ -1235,7 +1256,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     };
     FOR_ITEMS_RISING
       const strided<ROWS> aR = row(Q_GM);
-      const double Rig = aR[k], Ritop = row(Q_DT)[k], dVsq = row(Q_DS)[k];
+      const double Rig = aR[k];
       const double Riinfty = 0.8;
       double vm1 = aR[k - 1], vp1 = aR[k + 1];
       double wm1 = (k - 1 >= 1 && !((vm1 < 0.0) || (vm1 > Riinfty))) ? 1.0 : 0.0;
@@ -1272,8 +1293,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           }
         }
       }
-      if (k <= kguess) bulk_ri(k, si, my, sc, Ritop, dVsq, actz, is1);
-      else if (actz) row(Q_BET)[k] = Ritop;   // for the levels below the guess, should the scan get there
+      if (k <= kguess) bulk_ri(k, si, my, sc, row(Q_DT)[k], row(Q_DS)[k], actz, is1);   // (Ritop, dVsq: before dift takes the row)
       // interior diffusivities (after the reads of Ritop / dVsq, which share their rows)
       // (without double diffusion difs = dift bit for bit: one row, Q_DT, serves both from here on)
       if (actz) { row(Q_DM)[k] = dm_i; if (DD) row(Q_DS)[k] = ds_i; row(Q_DT)[k] = dt_i; }
@@ -1307,9 +1327,24 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     }
     STAMP(6);
     __syncthreads();
-    if (s_flags[4]) {   // rare: the bulk Richardson numbers of the levels below the guess, then the scan goes on
+    if (s_flags[4]) {   // rare: what the levels below the guess were spared - reference averages, Ritop, dVsq, bulk
+      // Richardson number - then the scan goes on.  The rows of the iterate's U and V hold the Monin-Obukhov depths
+      // and Richardson numbers of the upper levels by now: copies from the registers / the scratch into two rows
+      // that are free (Rig is used up, the sweeps' q not yet formed).
+      FOR_ITEMS
+        if (!act) continue;
+        row(Q_GM)[k] = first_ ? rU : xs_[0];
+        row(Q_BET)[k] = first_ ? rV : xs_[LS];
+      END_ITEMS
+      __syncthreads();
       FOR_ITEMS_RISING
-        if (k > kguess && actz) bulk_ri(k, si, my, sc, row(Q_BET)[k], row(Q_DS)[k], actz, is1);
+        if (k > kguess && actz) {
+          double ur, vr, br;
+          ref_sums(k, si, my, Q_GM, Q_BET, false, actz, ur, vr, br);
+          const double zmk = c_zm[k], zref = eps01 * zmk;
+          const double U = row(Q_GM)[k], V = row(Q_BET)[k], buoy = row(Q_YS)[k];
+          bulk_ri(k, si, my, sc, (zref - zmk) * (br - buoy), (ur - U) * (ur - U) + (vr - V) * (vr - V), actz, is1);
+        }
       END_ITEMS
       __syncthreads();
       if (wv == mgr) {
