@@ -1205,9 +1205,14 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     if (wv == mgr) M1();
     if (kguess < nz) {
       // level-major order, rising: the waves that hold levels below the guess have the cheap part only
-      FOR_ITEMS_RISING
-        L2_item(k, si, my, sc, (size_t)si[I_COL] * p.ld, actz, is1, isnz, k == nzp1, k <= kguess);
-      END_ITEMS
+      // (all items to the waves other than the manager's, which has M1 to do)
+      for (int it_ = tid2 >= 0 ? tid2 : nitems_lm; it_ < nitems_lm; it_ += nhelp) {
+        const int k = (W == 1 ? it_ : (int)__umulhi((unsigned)it_, Wmagic)) + 1;
+        const int slot = it_ - (k - 1) * W;
+        int *const si = sirec + slot * I_COUNT;
+        if (!si[I_ACT]) continue;
+        L2_item(k, si, slots + slot * SS, screc + slot * C_COUNT, (size_t)si[I_COL] * p.ld, k <= nz, k == 1, k == nz, k == nzp1, k <= kguess);
+      }
     } else if (nzp1 >= 50) {
       // measured: the level-major order (a deep and a shallow item per thread) pays from ~50 levels on (+2 % at 60,
       // +13 % on the stretched 69-level grid, -2 % at 40)
