@@ -1036,11 +1036,11 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // (verticalmixing_mod.F90:111-137).  The reference averages (uref, vref, bref: the loop over the layers above a
   // tenth of the level's depth) feed Ritop and dVsq, which only bldepth's bulk Richardson number uses: they are
   // formed for the levels L3 will form that number for (`sums`), and later for the others should the scan of M2
-  // ask for them - then from copies of the iterate's U and V in other rows (rU, rV), their own having been reused.
-  auto ref_sums = [&](const int k, int *const si, double *const my, const int rU, const int rV, const bool allow_pre,
+  // ask for them - then from copies of the iterate's U and V in other rows (rowU, rowV), their own having been reused.
+  auto ref_sums = [&](const int k, int *const si, double *const my, const int rowU, const int rowV, const bool allow_pre,
                       const bool actz, double &ur, double &vr, double &br) {
     auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };
-    const strided<ROWS> aU = row(rU), aV = row(rV), aB = row(Q_YS);
+    const strided<ROWS> aU = row(rowU), aV = row(rowV), aB = row(Q_YS);
     const double zmk = c_zm[k];
     const double zm1 = c_zm[1];
     const double U1 = aU[1], V1 = aV[1], Bu1 = aB[1];
