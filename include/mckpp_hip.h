@@ -194,6 +194,17 @@ int mckpp_hip_bottomtemp(mckpp_hip_handle h, const double *bottom_temp);
 /* Enable/disable writing of the MCKPP_F_DIAG fields by step/init (default on). */
 int mckpp_hip_set_diagnostics(mckpp_hip_handle h, int on);
 
+/* Tridiagonal solver mode of the implicit step (an extension: the reference has one solver,
+ * tridmat, src/mckpp_physics_solvers.F90:112-161).
+ *   0 (default)  tridmat's order of operations - results bit-identical to the CPU restatement of the reference;
+ *   1            the same systems eliminated from both ends at once (levels 1..nz/2 downward, nz..nz/2+1 upward,
+ *                a 2x2 system in the middle): half the dependent chain, results within rounding of mode 0
+ *                (profiles/r04/parity_tolerance.json; the oracle's solver_mode=1 restates
+ *                it operation for operation).
+ * The environment variable MCKPP_SOLVER_MODE sets the default of new handles.  <0 on an unknown mode. */
+int mckpp_hip_set_solver_mode(mckpp_hip_handle h, int mode);
+int mckpp_hip_get_solver_mode(mckpp_hip_handle h);
+
 /* mckpp_initialize_ocean_model's per-column part
  * (src/mckpp_initialize_ocean.F90:48-107): initial vmix with l_initflag,
  * hmix/kmix, initial diagnostic fluxes, old/new/Us/Xs/hmixd seeds. */
@@ -339,6 +350,7 @@ mckpp_hip_handle mckpp_hip_multi_ctx(mckpp_hip_multi_handle m, int32_t shard);
 int mckpp_hip_multi_upload(mckpp_hip_multi_handle m, const mckpp_state_ptrs_c *s);
 int mckpp_hip_multi_set_forcing(mckpp_hip_multi_handle m, const double *sflux);
 int mckpp_hip_multi_set_diagnostics(mckpp_hip_multi_handle m, int on);
+int mckpp_hip_multi_set_solver_mode(mckpp_hip_multi_handle m, int mode);
 int mckpp_hip_multi_update_ancillaries(mckpp_hip_multi_handle m, const mckpp_state_ptrs_c *s);
 int mckpp_hip_multi_bottomtemp(mckpp_hip_multi_handle m, const double *bottom_temp);
 int mckpp_hip_multi_fluxes(mckpp_hip_multi_handle m, int ntime, const double *taux, const double *tauy,

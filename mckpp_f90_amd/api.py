@@ -101,6 +101,8 @@ def _bind(lib):
     lib.mckpp_hip_upload.argtypes = [C.c_void_p, C.POINTER(_StateC)]
     lib.mckpp_hip_set_forcing.argtypes = [C.c_void_p, _dp]
     lib.mckpp_hip_set_diagnostics.argtypes = [C.c_void_p, C.c_int]
+    lib.mckpp_hip_set_solver_mode.argtypes = [C.c_void_p, C.c_int]
+    lib.mckpp_hip_get_solver_mode.argtypes = [C.c_void_p]
     lib.mckpp_hip_window_reset.argtypes = [C.c_void_p]
     lib.mckpp_hip_window_select.argtypes = [C.c_void_p, _ip, C.c_int32]
     lib.mckpp_hip_window_accumulate.argtypes = [C.c_void_p]
@@ -138,6 +140,7 @@ def _bind(lib):
     lib.mckpp_hip_multi_upload.argtypes = [C.c_void_p, C.POINTER(_StateC)]
     lib.mckpp_hip_multi_set_forcing.argtypes = [C.c_void_p, _dp]
     lib.mckpp_hip_multi_set_diagnostics.argtypes = [C.c_void_p, C.c_int]
+    lib.mckpp_hip_multi_set_solver_mode.argtypes = [C.c_void_p, C.c_int]
     lib.mckpp_hip_multi_init_ocean.argtypes = [C.c_void_p, C.c_int]
     lib.mckpp_hip_multi_step.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.mckpp_hip_multi_synchronize.argtypes = [C.c_void_p]
@@ -379,6 +382,14 @@ class MckppHip:
     def set_diagnostics(self, on):
         _chk(_lib().mckpp_hip_set_diagnostics(self._h, int(on)))
 
+    def set_solver_mode(self, mode):
+        """0: tridmat's order of operations (default); 1: two-ended elimination (mckpp_hip_set_solver_mode)."""
+        _chk(_lib().mckpp_hip_set_solver_mode(self._h, int(mode)))
+
+    @property
+    def solver_mode(self):
+        return int(_lib().mckpp_hip_get_solver_mode(self._h))
+
     def release_host_arrays(self):
         """Un-pin the caller's arrays this context registered (before they are freed while the context lives)."""
         _chk(_lib().mckpp_hip_release_host_arrays(self._h))
@@ -510,6 +521,9 @@ class MckppHipMulti:
 
     def set_diagnostics(self, on):
         _chk(_lib().mckpp_hip_multi_set_diagnostics(self._h, int(on)))
+
+    def set_solver_mode(self, mode):
+        _chk(_lib().mckpp_hip_multi_set_solver_mode(self._h, int(mode)))
 
     def set_flux_series(self, rec0, fields):
         """fields[nrec][8][npts] (taux,tauy,swf,lwf,lhf,shf,rain,snow); record 0 is flux update rec0."""

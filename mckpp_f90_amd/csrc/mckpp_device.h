@@ -53,6 +53,7 @@ struct mckpp_kparams_t {
   P<const double> swdk_tab;    // [6][ldc]  swdk_opt(k), k=0..nz
   int ldc;
   int LRI;        // rimix (kppmix_mod.F90:72-74); .FALSE.: the interior diffusivities stay zero, Rig is not formed
+  int solver_mode;   // 0: tridiagonal sweeps in the reference's order (solvers.F90:112-161); 1: two-ended elimination (opt-in)
   int l3cap;      // > 0: L3 forms the bulk Richardson numbers at most down to this level before the scan asks for the
                   // rest (MCKPP_L3_CAP, tests: the second round of the scan on every pass)
   P<const double> wtab;        // [(NJ+2)][(NI+2)] pairs {wmt, wst}

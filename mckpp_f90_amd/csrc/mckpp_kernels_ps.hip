@@ -163,6 +163,7 @@ __device__ __forceinline__ void ps_scan_rib(int W, int row, double *slots, int S
                                             int sact_stride, int lane, double Ricr, int *out)
 {
   const double epsln16 = 1.e-16;
+  asm volatile("" : "+v"(lane));
   if (lane < W && sact[lane * sact_stride]) {
     double *r = slots + lane * SS + row;
     double rb = k0 > 2 ? r[(k0 - 1) * KS] : 0.0;
@@ -223,9 +224,8 @@ __device__ __forceinline__ void ps_scan_rib(int W, int row, double *slots, int S
 
 // back substitution yn(i) = yn(i) - gam(i+1) yn(i+1) (solvers.F90:156-158), four levels per trip, the next trip's
 // operands fetched before the current trip's recurrence runs
-__device__ __forceinline__ void ps_backsub(double *y, const double *gm, int KS, int nz)
+__device__ __forceinline__ void ps_backsub_from(double *y, const double *gm, int KS, int nz, double yy)
 {
-  double yy = y[(nz) * KS];
   int i = nz - 1;
   asm volatile("" : "+v"(yy));   // its wait here, not at the first use inside the loop (where it would wait for the loop's own reads too)
   if (i >= 4) {   // a trip: levels i, i-1, i-2, i-3; KS = 9, 11 or 15 doubles per level
@@ -275,6 +275,57 @@ __device__ __forceinline__ void ps_backsub(double *y, const double *gm, int KS, 
     y[(i) * KS] = yy;
   }
 }
+__device__ __forceinline__ void ps_backsub(double *y, const double *gm, int KS, int nz) { ps_backsub_from(y, gm, KS, nz, y[(nz) * KS]); }
+
+// The same away from the middle of a column, downwards: y(i) = y(i) - g(i) y(i-1), i = k0 .. nz, from yy = y(k0-1)
+// (solver mode 1: the lower half of the two-ended elimination, below)
+__device__ __forceinline__ void ps_fwdsub_from(double *y, const double *gm, int KS, int k0, int nz, double yy)
+{
+  int i = k0;
+  asm volatile("" : "+v"(yy));
+  if (i + 3 <= nz) {   // a trip: levels i .. i+3
+    const unsigned step = 4u * (unsigned)KS * 8u;
+    unsigned ay = ps_lds_addr(y + i * KS), ag = ps_lds_addr(gm + i * KS);
+    auto rd_lo = [&](unsigned a) { return KS == 9 ? ps_lds_read2<0, 9>(a) : KS == 11 ? ps_lds_read2<0, 11>(a) : ps_lds_read2<0, 15>(a); };
+    auto rd_hi = [&](unsigned a) { return KS == 9 ? ps_lds_read2<18, 27>(a) : KS == 11 ? ps_lds_read2<22, 33>(a) : ps_lds_read2<30, 45>(a); };
+    // y01 = (y(i), y(i+1)), y23 = (y(i+2), y(i+3)); g01, g23 likewise
+    auto body = [&](unsigned aw, const ps_d2 &y01, const ps_d2 &y23, const ps_d2 &g01, const ps_d2 &g23) {
+      yy = y01.x - g01.x * yy; const double r0 = yy;
+      yy = y01.y - g01.y * yy; const double r1 = yy;
+      yy = y23.x - g23.x * yy; const double r2 = yy;
+      yy = y23.y - g23.y * yy;
+      if (KS == 9) { ps_lds_write2<0, 9>(aw, r0, r1); ps_lds_write2<18, 27>(aw, r2, yy); }
+      else if (KS == 11) { ps_lds_write2<0, 11>(aw, r0, r1); ps_lds_write2<22, 33>(aw, r2, yy); }
+      else { ps_lds_write2<0, 15>(aw, r0, r1); ps_lds_write2<30, 45>(aw, r2, yy); }
+    };
+    ps_d2 a0 = rd_lo(ay), a1 = rd_hi(ay), a2 = rd_lo(ag), a3 = rd_hi(ag), b0, b1, b2, b3;
+    while (i + 11 <= nz) {   // this trip, the next, and one more after it
+      b0 = rd_lo(ay + step); b1 = rd_hi(ay + step); b2 = rd_lo(ag + step); b3 = rd_hi(ag + step);
+      ps_lds_wait<4>(a0, a1, a2, a3);
+      body(ay, a0, a1, a2, a3);
+      a0 = rd_lo(ay + 2 * step); a1 = rd_hi(ay + 2 * step); a2 = rd_lo(ag + 2 * step); a3 = rd_hi(ag + 2 * step);
+      ps_lds_wait<4>(b0, b1, b2, b3);
+      body(ay + step, b0, b1, b2, b3);
+      i += 8; ay += 2 * step; ag += 2 * step;
+    }
+    // (past the loop nothing stays in flight across a branch: see ps_backsub_from)
+    ps_lds_wait<0>(a0, a1, a2, a3);
+    body(ay, a0, a1, a2, a3);
+    i += 4;
+    if (i + 3 <= nz) {
+      b0 = rd_lo(ay + step); b1 = rd_hi(ay + step); b2 = rd_lo(ag + step); b3 = rd_hi(ag + step);
+      ps_lds_wait<0>(b0, b1, b2, b3);
+      body(ay + step, b0, b1, b2, b3);
+      i += 4;
+    }
+    ps_lds_drain();
+  }
+#pragma nounroll
+  for (; i <= nz; ++i) {   // the last one to three levels
+    yy = y[(i) * KS] - gm[(i) * KS] * yy;
+    y[(i) * KS] = yy;
+  }
+}
 
 // The rows of tridiagonal system `sys` (0 momentum, 1 temperature, 2 salinity) of kernel variant XV.  L5, which forms
 // the final diffusivities, leaves the sweeps their products with the grid's tri(:,0:1): p(i) = tri(i,1) diff(i)
@@ -304,6 +355,7 @@ __device__ __forceinline__ void ps_thomas_uts_fwd(int W, double *slots, int SS, 
                                                   int *sbad, int sbad_stride, int lane)
 {
   constexpr int KS = XV == 2 ? (int)Q_COUNT_EXT_DD : XV == 1 ? (int)Q_COUNT_EXT : (int)Q_COUNT;
+  asm volatile("" : "+v"(lane));
   if (lane < 3 * W) {
     const int sl = lane / 3, sys = lane - 3 * sl;
     if (sact[sl * sact_stride]) {
@@ -372,11 +424,119 @@ template <int XV>
 __device__ __forceinline__ void ps_thomas_uts_back(int W, double *slots, int SS, int nz, const int *sact, int sact_stride, int lane)
 {
   constexpr int KS = XV == 2 ? (int)Q_COUNT_EXT_DD : XV == 1 ? (int)Q_COUNT_EXT : (int)Q_COUNT;
+  asm volatile("" : "+v"(lane));
   if (lane < 3 * W) {
     const int sl = lane / 3, sys = lane - 3 * sl;
     if (sact[sl * sact_stride]) {
       double *base = slots + sl * SS;
       ps_backsub(base + (Q_YU + sys), base + ps_sysrows<XV>::gam(sys), KS, nz);
+    }
+  }
+}
+
+// ---- solver mode 1 (opt-in, mckpp_hip_set_solver_mode; NOT the reference's operation order - the oracle's
+// orc_tridmat_2e restates it operation for operation): the same systems eliminated from both ends at once.  DIR = +1:
+// the levels 1..m, m = nz/2, downward as above; DIR = -1: the levels nz..m+1 upward by the mirrored recurrence
+//   g(i+1) = cu(i+1)/bet(i+1) = -q(i+1)/bet,  bet(i) = cc(i) - cl(i) g(i+1) = cc(i) + p(i) g(i+1),
+//   z(i) = (rhs(i) - cl(i) z(i+1))/bet(i) = (rhs(i) + p(i) z(i+1))/bet(i)
+// on another wave; each is a chain of nz/2 steps.  The upper half leaves z(1..m-1) in the solution row, z(m) at its
+// index 0, gam(2..m) in the gam row and gam(m+1) at its index 0; the lower half z(m+2..nz), z(m+1) at index nz+2 of
+// the solution row, g(m+2..nz) and g(m+1) at index 1 of the gam row (those entries of the rows are free by now:
+// nothing there for the other half's reads to race with).
+template <int XV, int DIR>
+__device__ __forceinline__ void ps_thomas2_uts_fwd(int W, double *slots, int SS, int nz, const int *sact, int sact_stride,
+                                                   int *sbad, int sbad_stride, int lane)
+{
+  constexpr int KS = XV == 2 ? (int)Q_COUNT_EXT_DD : XV == 1 ? (int)Q_COUNT_EXT : (int)Q_COUNT;
+  // (opaque: what is derived from the lane number is formed here, in every pass, instead of living in registers
+  // across the whole persistent loop - the compiler would hoist it out, and the kernel has no VGPR to spare)
+  asm volatile("" : "+v"(lane));
+  if (lane < 3 * W) {
+    const int sl = lane / 3, sys = lane - 3 * sl;
+    if (sact[sl * sact_stride]) {
+      double *base = slots + sl * SS;
+      const double *pb = base + ps_sysrows<XV>::p(sys), *qq = XV == 2 ? base + ps_sysrows<XV>::q(sys) : pb + 7;
+      double *y = base + (Q_YU + sys), *gm = base + ps_sysrows<XV>::gam(sys);
+      const int m = nz >> 1;
+      const int i0 = DIR > 0 ? 1 : nz;
+      int bad = 0;
+      // carry: p(i-1) on the way down (cl(i-1) = -p(i-1)), q(i+1) on the way up (cu(i+1) = -q(i+1))
+      double carry = DIR > 0 ? pb[(1) * KS] : qq[(nz) * KS];
+      double bet = DIR > 0 ? 1. + carry : (1. + pb[(nz) * KS]) + carry;   // cc(1) | cc(nz)
+      double ynum = y[(i0) * KS];
+      auto level = [&](int i, double p, double q, double rhs, auto slow) {
+        if (slow.value && bet == 0.) { bad = 1; bet = 1.E-12; }
+        const double cm1 = -carry;
+        const double cc = (1. + p) + q;
+        const double rb = rcp_refine(bet);
+        const double g = slow.value ? div_by_refined(cm1, bet, rb) : div_fast(cm1, bet, rb);
+        const double yprev = slow.value ? div_by_refined(ynum, bet, rb) : div_fast(ynum, bet, rb);
+        y[(i - DIR) * KS] = yprev;
+        gm[(DIR > 0 ? i : i + 1) * KS] = g;
+        const double mult = DIR > 0 ? q : p;
+        bet = cc + mult * g;
+        ynum = rhs + mult * yprev;
+        carry = DIR > 0 ? p : q;
+      };
+      bool f_in = tiny_nonzero(ynum);
+      {   // two levels per trip; each half's operands are fetched while the other half runs
+        int i = i0 + DIR, left = (DIR > 0 ? m : nz - m) - 1;
+        double a_p = 0., a_q = 0., a_r = 0.;
+        if (left > 0) { a_p = pb[(i) * KS]; a_q = qq[(i) * KS]; a_r = y[(i) * KS]; }
+        for (; left >= 2; left -= 2, i += 2 * DIR) {
+          const double b_p = pb[(i + DIR) * KS], b_q = qq[(i + DIR) * KS], b_r = y[(i + DIR) * KS];
+          const double s_carry = carry, s_bet = bet, s_ynum = ynum;
+          level(i, a_p, a_q, a_r, std::false_type{});
+          const bool f_mid = tiny_nonzero(ynum) || bet == 0.;
+          level(i + DIR, b_p, b_q, b_r, std::false_type{});
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(f_in || f_mid) != 0ull, 0)) {
+            carry = s_carry; bet = s_bet; ynum = s_ynum;
+            level(i, a_p, a_q, a_r, std::true_type{});
+            level(i + DIR, b_p, b_q, b_r, std::true_type{});
+          }
+          f_in = tiny_nonzero(ynum) || bet == 0.;
+          if (left >= 3) { a_p = pb[(i + 2 * DIR) * KS]; a_q = qq[(i + 2 * DIR) * KS]; a_r = y[(i + 2 * DIR) * KS]; }
+        }
+        if (left == 1) {
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(f_in) != 0ull, 0)) level(i, a_p, a_q, a_r, std::true_type{});
+          else level(i, a_p, a_q, a_r, std::false_type{});
+        }
+      }
+      if (bet == 0.) { bad = 1; bet = 1.E-12; }
+      const double rb = rcp_refine(bet);
+      // (not into y(m), y(m+1): each of those is written by one wave while the other may still have to read it)
+      y[(DIR > 0 ? 0 : nz + 2) * KS] = div_by_refined(ynum, bet, rb);        // z(m) | z(m+1) at the free ends of the row
+      gm[(DIR > 0 ? 0 : 1) * KS] = div_by_refined(-carry, bet, rb);          // gam(m+1) | g(m+1)
+      if (bad) sbad[sl * sbad_stride] = 1;
+    }
+  }
+}
+
+// ... then (after a barrier) the two unknowns in the middle from their 2x2 system, by both waves alike,
+//   y(m) = (z(m) - gam(m+1) z(m+1)) / (1 - gam(m+1) g(m+1)),  y(m+1) = z(m+1) - g(m+1) y(m),
+// and the two substitutions away from it: DIR = +1 upwards from y(m), DIR = -1 downwards from y(m+1).
+template <int XV, int DIR>
+__device__ __forceinline__ void ps_thomas2_uts_back(int W, double *slots, int SS, int nz, const int *sact, int sact_stride, int lane)
+{
+  constexpr int KS = XV == 2 ? (int)Q_COUNT_EXT_DD : XV == 1 ? (int)Q_COUNT_EXT : (int)Q_COUNT;
+  asm volatile("" : "+v"(lane));   // (see ps_thomas2_uts_fwd)
+  if (lane < 3 * W) {
+    const int sl = lane / 3, sys = lane - 3 * sl;
+    if (sact[sl * sact_stride]) {
+      double *base = slots + sl * SS;
+      double *y = base + (Q_YU + sys), *gm = base + ps_sysrows<XV>::gam(sys);
+      const int m = nz >> 1;
+      const double zt = y[0], zb = y[(nz + 2) * KS], gt = gm[0], gb = gm[KS];
+      const double den = 1. - gt * gb;
+      const double ym = (zt - gt * zb) / den;
+      if (DIR > 0) {
+        y[(m) * KS] = ym;
+        ps_backsub_from(y, gm, KS, m, ym);
+      } else {
+        const double ym1 = zb - gb * ym;
+        y[(m + 1) * KS] = ym1;
+        ps_fwdsub_from(y, gm, KS, m + 2, nz, ym1);
+      }
     }
   }
 }
@@ -391,6 +551,7 @@ __device__ __forceinline__ void ps_thomas_uts_back(int W, double *slots, int SS,
 __device__ __forceinline__ void ps_thomas_v_fwd(int W, double *slots, int SS, int KS, int nz, const int *sact,
                                                 int sact_stride, int lane)
 {
+  asm volatile("" : "+v"(lane));
   if (lane < W && sact[lane * sact_stride]) {
     double *base = slots + lane * SS;
     const double *betm = base + Q_BET, *rbm = base + Q_DT, *qm = base + Q_GM;
@@ -485,9 +646,153 @@ __device__ __forceinline__ void ps_thomas_v_fwd(int W, double *slots, int SS, in
 __device__ __forceinline__ void ps_thomas_v_back(int W, double *slots, int SS, int KS, int gam_row, int nz, const int *sact,
                                                  int sact_stride, int lane)
 {
+  asm volatile("" : "+v"(lane));
   if (lane < W && sact[lane * sact_stride]) {
     double *base = slots + lane * SS;
     ps_backsub(base + Q_YV, base + gam_row, KS, nz);
+  }
+}
+
+// Solver mode 1, V: both halves of the two-ended elimination on ONE wave - lane s works downward from level 1 of
+// slot s, lane 32+s upward from its level nz - on what L7 has laid out per level for either direction alike: the
+// pivot of the level (row Q_BET) and its refined reciprocal (Q_DT), the multiplier of the neighbour's solution in
+// the numerator (Q_GM: q(k) in the upper half, p(k) in the lower one) and the multiplier of the substitution (Q_DM:
+// gam(k+1) | g(k)).  So the two directions differ in their start level and the sign of their address step only.
+template <int OFF>
+__device__ __forceinline__ void ps_lds_write1(unsigned addr, double a)
+{
+  asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(a), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void ps_thomas2_v(int W, double *slots, int SS, int KS, int gam_row, int nz, const int *sact,
+                                             int sact_stride, int lane)
+{
+  static_assert(Q_DM == 0 && Q_DT == 1 && Q_YV == 6 && Q_GM == 7 && Q_BET == 8, "offsets of the V sweep's operands in a level block");
+  asm volatile("" : "+v"(lane));   // (see ps_thomas2_uts_fwd)
+  const int sl = lane & 31;
+  const bool up = lane >= 32;   // the lower half, worked upward
+  if (sl < W && sact[sl * sact_stride]) {
+    double *base = slots + sl * SS;
+    const int m = nz >> 1;
+    const int i0 = up ? nz : 1, iend = up ? m + 1 : m;
+    const int dstep = up ? -KS * 8 : KS * 8;   // bytes from a level to the next one of this lane's sweep
+    int left = (up ? nz - m : m) - 1;          // levels after the first
+    const int common = m - 1;                  // ... of either direction (the lower half may have one more)
+    double yy;
+    {
+      const double *l0 = base + i0 * KS;
+      yy = div_by_refined(l0[Q_YV], l0[Q_BET], l0[Q_DT]);
+      base[i0 * KS + Q_YV] = yy;
+    }
+    asm volatile("" : "+v"(yy));
+    unsigned ad = ps_lds_addr(base + i0 * KS) + (unsigned)dstep;   // the level to enter next
+    // rq = (1/bet, multiplier), hb = (rhs, bet) of a level
+    auto rd_rq = [&](unsigned a) { return ps_lds_read2<1, 7>(a); };
+    auto rd_hb = [&](unsigned a) { return ps_lds_read2<6, 8>(a); };
+    auto two = [&](unsigned a0_, unsigned a1_, const ps_d2 &rq0, const ps_d2 &hb0, const ps_d2 &rq1, const ps_d2 &hb1) {
+      const double y_in = yy;
+      const double n0 = hb0.x + rq0.y * yy;
+      double y0 = div_fast(n0, hb0.y, rq0.x);
+      const double n1 = hb1.x + rq1.y * y0;
+      double y1 = div_fast(n1, hb1.y, rq1.x);
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(tiny_nonzero(n0) || tiny_nonzero(n1)) != 0ull, 0)) {
+        y0 = (hb0.x + rq0.y * y_in) / hb0.y;
+        y1 = (hb1.x + rq1.y * y0) / hb1.y;
+      }
+      yy = y1;
+      ps_lds_write1<48>(a0_, y0);
+      ps_lds_write1<48>(a1_, y1);
+    };
+    int done = 0;
+    if (common >= 2) {   // trips of two levels, the next trip's operands in flight (ps_lds_read2 / ps_lds_wait, above)
+      ps_d2 a0 = rd_rq(ad), a1 = rd_hb(ad), a2 = rd_rq(ad + dstep), a3 = rd_hb(ad + dstep), b0, b1, b2, b3;
+      while (done + 6 <= common) {   // this trip, the next, and one more after it
+        const unsigned adb = ad + 2 * dstep, adc = ad + 4 * dstep;
+        b0 = rd_rq(adb); b1 = rd_hb(adb); b2 = rd_rq(adb + dstep); b3 = rd_hb(adb + dstep);
+        ps_lds_wait<4>(a0, a1, a2, a3);
+        two(ad, ad + dstep, a0, a1, a2, a3);
+        a0 = rd_rq(adc); a1 = rd_hb(adc); a2 = rd_rq(adc + dstep); a3 = rd_hb(adc + dstep);
+        ps_lds_wait<4>(b0, b1, b2, b3);
+        two(adb, adb + dstep, b0, b1, b2, b3);
+        done += 4; ad = adc;
+      }
+      // (past the loop nothing stays in flight across a branch: see ps_backsub_from)
+      ps_lds_wait<0>(a0, a1, a2, a3);
+      two(ad, ad + dstep, a0, a1, a2, a3);
+      done += 2; ad += 2 * dstep;
+      if (done + 2 <= common) {
+        b0 = rd_rq(ad); b1 = rd_hb(ad); b2 = rd_rq(ad + dstep); b3 = rd_hb(ad + dstep);
+        ps_lds_wait<0>(b0, b1, b2, b3);
+        two(ad, ad + dstep, b0, b1, b2, b3);
+        done += 2; ad += 2 * dstep;
+      }
+      ps_lds_drain();
+    }
+    left -= done;
+    while (__builtin_amdgcn_ballot_w64(left > 0) != 0ull) {   // what is left of either direction: at most two levels
+      if (left > 0) {
+        const double *l = reinterpret_cast<const double *>(base) + ((int)(ad - ps_lds_addr(base)) >> 3);
+        const double n0 = l[Q_YV] + l[Q_GM] * yy;
+        yy = div_fast_guarded(n0, l[Q_BET], l[Q_DT]);
+        const_cast<double *>(l)[Q_YV] = yy;
+        ad += dstep;
+      }
+      --left;
+    }
+    // the two unknowns in the middle: y(m) = (z(m) - gam(m+1) z(m+1)) / (1 - gam(m+1) g(m+1)), y(m+1) = z(m+1) - g(m+1) y(m)
+    const double other = __shfl_xor(yy, 32);
+    const double zt = up ? other : yy, zb = up ? yy : other;
+    const double gt = base[gam_row], gb = base[KS + gam_row];
+    const double den = 1. - gt * gb;
+    const double ym = (zt - gt * zb) / den;
+    const double ym1 = zb - gb * ym;
+    yy = up ? ym1 : ym;
+    base[iend * KS + Q_YV] = yy;
+    asm volatile("" : "+v"(yy));
+    // substitution away from the middle: y(k) = z(k) - mult(k) y(previous), mult in row Q_DM (L7)
+    const int bstep = -dstep;
+    int bleft = up ? nz - m - 1 : m - 1;
+    unsigned ab = ps_lds_addr(base + iend * KS) + (unsigned)bstep;
+    auto rd_mz = [&](unsigned a) { return ps_lds_read2<0, 6>(a); };   // (mult, z)
+    auto four = [&](unsigned a_, const ps_d2 &v0, const ps_d2 &v1, const ps_d2 &v2, const ps_d2 &v3) {
+      yy = v0.y - v0.x * yy; ps_lds_write1<48>(a_, yy);
+      yy = v1.y - v1.x * yy; ps_lds_write1<48>(a_ + bstep, yy);
+      yy = v2.y - v2.x * yy; ps_lds_write1<48>(a_ + 2 * bstep, yy);
+      yy = v3.y - v3.x * yy; ps_lds_write1<48>(a_ + 3 * bstep, yy);
+    };
+    int bdone = 0;
+    if (common >= 4) {
+      ps_d2 a0 = rd_mz(ab), a1 = rd_mz(ab + bstep), a2 = rd_mz(ab + 2 * bstep), a3 = rd_mz(ab + 3 * bstep), b0, b1, b2, b3;
+      while (bdone + 12 <= common) {
+        const unsigned abb = ab + 4 * bstep, abc = ab + 8 * bstep;
+        b0 = rd_mz(abb); b1 = rd_mz(abb + bstep); b2 = rd_mz(abb + 2 * bstep); b3 = rd_mz(abb + 3 * bstep);
+        ps_lds_wait<4>(a0, a1, a2, a3);
+        four(ab, a0, a1, a2, a3);
+        a0 = rd_mz(abc); a1 = rd_mz(abc + bstep); a2 = rd_mz(abc + 2 * bstep); a3 = rd_mz(abc + 3 * bstep);
+        ps_lds_wait<4>(b0, b1, b2, b3);
+        four(abb, b0, b1, b2, b3);
+        bdone += 8; ab = abc;
+      }
+      ps_lds_wait<0>(a0, a1, a2, a3);
+      four(ab, a0, a1, a2, a3);
+      bdone += 4; ab += 4 * bstep;
+      if (bdone + 4 <= common) {
+        b0 = rd_mz(ab); b1 = rd_mz(ab + bstep); b2 = rd_mz(ab + 2 * bstep); b3 = rd_mz(ab + 3 * bstep);
+        ps_lds_wait<0>(b0, b1, b2, b3);
+        four(ab, b0, b1, b2, b3);
+        bdone += 4; ab += 4 * bstep;
+      }
+      ps_lds_drain();
+    }
+    bleft -= bdone;
+    while (__builtin_amdgcn_ballot_w64(bleft > 0) != 0ull) {   // at most four levels
+      if (bleft > 0) {
+        double *l = base + ((int)(ab - ps_lds_addr(base)) >> 3);
+        yy = l[Q_YV] - l[Q_DM] * yy;
+        l[Q_YV] = yy;
+        ab += bstep;
+      }
+      --bleft;
+    }
   }
 }
 
@@ -497,7 +802,9 @@ struct strided {   // x[i] of a level-interleaved row
   __device__ __forceinline__ double &operator[](int i) const { return b[i * KS]; }
 };
 
-template <int XV>
+// XV: physics variant (rows above); SM: tridiagonal solver mode - 0 the reference's order of operations
+// (solvers.F90:112-161), 1 the two-ended elimination (opt-in, ps_thomas2_*)
+template <int XV, int SM>
 #ifndef MCKPP_PS_MINW
 #define MCKPP_PS_MINW 4
 #endif
@@ -510,7 +817,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   constexpr bool EXT = XV != 0, DD = XV == 2;
   constexpr int ROWS = XV == 2 ? (int)Q_COUNT_EXT_DD : XV == 1 ? (int)Q_COUNT_EXT : (int)Q_COUNT;
   const int NL = ps_nl(L), SS = ps_ss(L, XV);
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, lane_k = lane;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nz = p.nz, nzp1 = p.nzp1;
   double *cst = lds;
@@ -556,7 +863,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // the iterate of the under-relaxation between passes: four scratch rows per (workgroup, slot), element
   // index = level-1, each element read and rewritten in place by the one item that owns it.  The block is
   // reused by every column the slot serves, so it stays in L2.
-  double rU = 0.0, rV = 0.0, rT = 0.0, rS = 0.0;   // the iterate of this thread's first item (the others: scratch)
+  // the iterate of this thread's first item and of its second one (its items of later trips: scratch; none of the
+  // geometries the launcher chooses has a third trip)
+  double rU = 0.0, rV = 0.0, rT = 0.0, rS = 0.0, r2U = 0.0, r2V = 0.0, r2T = 0.0, r2S = 0.0;
   const int LS = ps_scratch_ld(nzp1);
   const auto scr0 = p.scratch + (size_t)blockIdx.x * (size_t)W * (size_t)(4 * LS);
 
@@ -575,7 +884,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     const int kr = act ? k : 1;                                                           \
     const size_t ro = (size_t)col * p.ld;                                                 \
     const auto xs_ = scr0 + (size_t)slot * (size_t)(4 * LS) + (kr - 1);   /* iterate U, V, T, S of this item */ \
-    const bool first_ = t_ == 0;   /* the thread's first item: its iterate stays in registers */          \
+    const int first_ = t_;   /* trip 0 / 1: the item's iterate stays in registers (rU.. / r2U..) */      \
     auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };             \
     (void)sc; (void)actz; (void)virt1; (void)virt2; (void)is1; (void)isnz; (void)isnzp1; (void)kr; (void)ro; (void)xs_; (void)first_; (void)row;
 #define END_ITEMS }
@@ -617,6 +926,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // =========================== manager phases (wave 0) ===========================
   // M0: slots whose column has finished pull the next one from the queue 
   auto M0 = [&]() {
+    int lane = lane_k; asm volatile("" : "+v"(lane));
     bool a = false;
     if (lane < W) {
       int *msi = sirec + lane * I_COUNT;
@@ -660,6 +970,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 
   // M1: surface fluxes and friction velocity (verticalmixing_mod.F90:81-100), wXNT(0) (fluxes_mod.F90:110-116)
   auto M1 = [&]() {
+    int lane = lane_k; asm volatile("" : "+v"(lane));
     if (lane < W) {
       int *msi = sirec + lane * I_COUNT;
       double *msc = screc + lane * C_COUNT;
@@ -701,6 +1012,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // M3: boundary-layer depth from the first level with hmin < -zm(k) (bldepth_mod.F90:161-201) and the
   //     slot-uniform part of blmix (blmix_mod.F90:62-100, 136-149)
   auto M3 = [&]() {
+    int lane = lane_k; asm volatile("" : "+v"(lane));
     if (lane < W) {
       int *msi = sirec + lane * I_COUNT;
       double *msc = screc + lane * C_COUNT;
@@ -802,6 +1114,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // (not with double diffusion: its L1 stages neighbour values in rows the V sweep is reading)
   const bool l1_ahead = p.mode == MCKPP_MODE_STEP && nthreads > 64 && !(EXT && p.LDD);
   auto G_early = [&]() {
+    int lane = lane_k; asm volatile("" : "+v"(lane));
     bool f_any = false;
     if (lane < W) {
       int *msi = sirec + lane * I_COUNT;
@@ -850,6 +1163,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     if (lane == 0) s_flags[1] = m != 0ull ? 1 : 0;
   };
   auto G_late = [&]() {
+    int lane = lane_k; asm volatile("" : "+v"(lane));
     if (lane < W) {
       int *msi = sirec + lane * I_COUNT;
       if (msi[I_ACT]) {
@@ -944,13 +1258,13 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   enum { L1_FULL = 0, L1_ALL_BUT_V = 1, L1_V_ONLY = 2 };
   auto L1_item = [&](const int k, const int kr, int *const si, double *const my, double *const sc, const size_t ro,
                      const bool act, const bool virt1, const bool virt2, const bool is1, const auto xs_,
-                     const bool first_, const int part) {
+                     const int first_, const int part) {
     auto row = [&](int a) -> strided<ROWS> { return strided<ROWS>{my + a}; };
     if (part == L1_V_ONLY) {
       if (act) {
-        double V = first_ ? rV : xs_[LS];
+        double V = first_ == 0 ? rV : first_ == 1 ? r2V : xs_[LS];
         V = lambda * V + (1 - lambda) * row(Q_YV)[k];
-        if (first_) rV = V; else xs_[LS] = V;
+        if (first_ == 0) rV = V; else if (first_ == 1) r2V = V; else xs_[LS] = V;
         row(Q_YV)[k] = V;
       }
       return;
@@ -974,7 +1288,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         S = 2. * sn - so;
         yu = U; yv = V; yt = T; ys = S;
       } else {
-        if (first_) { U = rU; T = rT; S = rS; if (with_v) V = rV; }
+        if (first_ == 0) { U = rU; T = rT; S = rS; if (with_v) V = rV; }
+        else if (first_ == 1) { U = r2U; T = r2T; S = r2S; if (with_v) V = r2V; }
         else if (act) { U = xs_[0]; T = xs_[2 * LS]; S = xs_[3 * LS]; if (with_v) V = xs_[LS]; }
         if (!act) T = sc[C_T1X + par];   // the two EOS items follow level 1, whose item rewrites it now
         yu = row(Q_YU)[kr]; yv = with_v ? row(Q_YV)[kr] : 0.0; yt = row(Q_YT)[kr]; ys = row(Q_YS)[kr];
@@ -985,7 +1300,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         U = lambda * U + (1 - lambda) * yu;
         if (with_v) V = lambda * V + (1 - lambda) * yv;
         S = lambda * S + (1 - lambda) * ys;
-        if (first_) { rU = U; rT = T; rS = S; if (with_v) rV = V; }
+        if (first_ == 0) { rU = U; rT = T; rS = S; if (with_v) rV = V; }
+        else if (first_ == 1) { r2U = U; r2T = T; r2S = S; if (with_v) r2V = V; }
         else { xs_[0] = U; xs_[2 * LS] = T; xs_[3 * LS] = S; if (with_v) xs_[LS] = V; }
         if (is1) sc[C_T1X + (par ^ 1)] = T;
       }
@@ -1338,8 +1654,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       // that are free (Rig is used up, the sweeps' q not yet formed).
       FOR_ITEMS
         if (!act) continue;
-        row(Q_GM)[k] = first_ ? rU : xs_[0];
-        row(Q_BET)[k] = first_ ? rV : xs_[LS];
+        row(Q_GM)[k] = first_ == 0 ? rU : first_ == 1 ? r2U : xs_[0];
+        row(Q_BET)[k] = first_ == 0 ? rV : first_ == 1 ? r2V : xs_[LS];
       END_ITEMS
       __syncthreads();
       FOR_ITEMS_RISING
@@ -1493,7 +1809,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         const double wX0_1 = sc[C_WX01], wX0_2 = sc[C_WX02];
         const strided<ROWS> yU = row(Q_YU), yT = row(Q_YT), yS = row(Q_YS);
         if (actz) {
-          const double V = first_ ? rV : xs_[LS];   // of the iterate (its row holds ghat by now)
+          const double V = first_ == 0 ? rV : first_ == 1 ? r2V : xs_[LS];   // of the iterate (its row holds ghat by now)
           const double difm = 0.0001 /* only level nz asks: kppmix / L5 */, difs = aDs[k], dift = aDt[k], ghat = aGh[k];
           const int jer = si[I_JER];
           const double rho0cp0 = sc[C_RHO0CP0], r_rc = sc[C_RRC], sflux3 = sc[C_SFLUX3];
@@ -1531,11 +1847,22 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(15);
 
     // ---- M4: Thomas factorise + sweep for U, T, S (solvers.F90:14-44, 112-161)
-    if (wv == mgr && do_ocnint) {
-      ps_thomas_uts_fwd<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+    if constexpr (SM == 0) {
+      if (wv == mgr && do_ocnint) {
+        ps_thomas_uts_fwd<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+        STAMP(24);
+        ps_thomas_uts_back<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, lane);
+      }
+    } else if (do_ocnint) {
+      // solver mode 1: the upper half of every system on the manager wave, the lower half on the wave next to it
+      // (a workgroup of one wave: one after the other); the 2x2 system in the middle needs both
+      const int wv2 = nthreads > 64 ? 1 : 0;
+      if (wv == mgr) ps_thomas2_uts_fwd<XV, 1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+      if (wv == wv2) ps_thomas2_uts_fwd<XV, -1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
       STAMP(24);
-      ps_thomas_uts_back<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, lane);
-     
+      __syncthreads();
+      if (wv == mgr) ps_thomas2_uts_back<XV, 1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, lane);
+      if (wv == wv2) ps_thomas2_uts_back<XV, -1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, lane);
     }
     STAMP(16);
     __syncthreads();
@@ -1555,7 +1882,24 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           // operations on the same p, q, gam; solvers.F90:140-151's replacement of a zero pivot included), into
           // two rows the T and S systems are done with
           const double pk = row(Q_DM)[k], qk = row(Q_GM)[k], gk = row(ps_sysrows<XV>::gam_m)[k];
-          double betk = (k == 1) ? 1. + pk : ((1. + pk) + qk) + qk * gk;
+          double betk;
+          if constexpr (SM == 0) {
+            betk = (k == 1) ? 1. + pk : ((1. + pk) + qk) + qk * gk;
+          } else {
+            // solver mode 1: the pivots of either half as its sweep formed them (ps_thomas2_uts_fwd), and the V sweep's
+            // other per-level operands where both of its directions look for them (ps_thomas2_v): the multiplier of
+            // the neighbour's solution (q(k) stays | p(k)) and the multiplier of the substitution (gam(k+1) | g(k))
+            const int m = nz >> 1;
+            const double gk1 = row(ps_sysrows<XV>::gam_m)[k + 1];
+            if (k <= m) {
+              betk = (k == 1) ? 1. + pk : ((1. + pk) + qk) + qk * gk;
+              row(Q_DM)[k] = gk1;
+            } else {
+              betk = (k == nz) ? (1. + pk) + qk : ((1. + pk) + qk) + pk * gk1;
+              row(Q_GM)[k] = pk;
+              row(Q_DM)[k] = gk;
+            }
+          }
           if (betk == 0.) betk = 1.E-12;
           row(Q_BET)[k] = betk;
           row(Q_DT)[k] = rcp_refine(betk);
@@ -1577,9 +1921,13 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     // ---- M5: Thomas sweep for V on the stored momentum factorisation | the next pass's L1 but for V
     if (wv == mgr) {
       if (do_ocnint) {
-        ps_thomas_v_fwd(W, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane);
-        STAMP(25);
-        ps_thomas_v_back(W, slots, SS, ROWS, ps_sysrows<XV>::gam_m, nz, sirec + I_ACT, I_COUNT, lane);
+        if constexpr (SM == 0) {
+          ps_thomas_v_fwd(W, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane);
+          STAMP(25);
+          ps_thomas_v_back(W, slots, SS, ROWS, ps_sysrows<XV>::gam_m, nz, sirec + I_ACT, I_COUNT, lane);
+        } else {
+          ps_thomas2_v(W, slots, SS, ROWS, ps_sysrows<XV>::gam_m, nz, sirec + I_ACT, I_COUNT, lane);
+        }
       }
       G_late();
      
@@ -1952,9 +2300,12 @@ hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kpa
   if (!p.scratch || p.scratch_doubles < (size_t)num_cu * g.per_cu * g.w * 4 * ps_scratch_ld(p.nzp1)) return hipErrorInvalidValue;
   const size_t lds = ps_lds_bytes(L, g.w, xv);
   if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
-  const void *fn = xv == 2   ? reinterpret_cast<const void *>(k_column_ps<2>)
-                   : xv == 1 ? reinterpret_cast<const void *>(k_column_ps<1>)
-                             : reinterpret_cast<const void *>(k_column_ps<0>);
+  using kern_t = void (*)(const mckpp_kparams *, int, int, int, unsigned);
+  static const kern_t kerns[2][3] = {{k_column_ps<0, 0>, k_column_ps<1, 0>, k_column_ps<2, 0>},
+                                     {k_column_ps<0, 1>, k_column_ps<1, 1>, k_column_ps<2, 1>}};
+  if (p.solver_mode < 0 || p.solver_mode > 1) return hipErrorInvalidValue;
+  const kern_t kern = kerns[p.solver_mode][xv];
+  const void *fn = reinterpret_cast<const void *>(kern);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   int nblocks = num_cu * g.per_cu;
@@ -1977,8 +2328,6 @@ hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kpa
     }
   }
   const unsigned Lmagic = (unsigned)(0x100000000ull / (unsigned long long)L) + 1u;   // it / L == umulhi(it, Lmagic) for it < 2^20
-  if (xv == 2) hipLaunchKernelGGL(k_column_ps<2>, dim3((unsigned)nblocks), dim3(64 * g.nw), lds, stream, dp, p.ntime, L, g.w, Lmagic);
-  else if (xv == 1) hipLaunchKernelGGL(k_column_ps<1>, dim3((unsigned)nblocks), dim3(64 * g.nw), lds, stream, dp, p.ntime, L, g.w, Lmagic);
-  else hipLaunchKernelGGL(k_column_ps<0>, dim3((unsigned)nblocks), dim3(64 * g.nw), lds, stream, dp, p.ntime, L, g.w, Lmagic);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(64 * g.nw), lds, stream, dp, p.ntime, L, g.w, Lmagic);
   return hipGetLastError();
 }

@@ -112,6 +112,7 @@ struct mckpp_hip_ctx {
   int *d_ci = nullptr;
   int *d_qhead = nullptr;
   int l3cap = 0;   // MCKPP_L3_CAP (tests): see mckpp_kparams_t::l3cap
+  int solver_mode = 0;   // mckpp_hip_set_solver_mode / MCKPP_SOLVER_MODE
   unsigned long long *d_dbg = nullptr;
   mckpp_kparams *d_params = nullptr;   // device copy of the kernel parameter block
   // its source: two pinned host slots used in turn, so a call never waits for its own upload (a slot is reused
@@ -229,6 +230,11 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   // the index of dm() (src/mckpp_physics_ocnstep_mod.F90:305-314, ocnint_mod.F90:97-114) - uninitialised memory.  Refused.
   if (!c->LKPP) return fail("mckpp_hip_init: LKPP=.FALSE. leaves hmix/kmix unassigned in the reference (kppmix_mod.F90:87-118): not a defined configuration, not emulated");
   if (c->maxmodeadv < 0 || c->maxmodeadv > 16) return fail("mckpp_hip_init: maxmodeadv=%d", c->maxmodeadv);
+  int solver_mode_env = 0;   // default of mckpp_hip_set_solver_mode
+  if (const char *e = getenv("MCKPP_SOLVER_MODE")) {
+    solver_mode_env = atoi(e);
+    if (solver_mode_env < 0 || solver_mode_env > 1) return fail("mckpp_hip_init: MCKPP_SOLVER_MODE=%s (0: the reference's order, 1: two-ended)", e);
+  }
   if (c->L_NO_ISOTHERM && (c->iso_bot < 2 || c->iso_bot > c->nz + 1))
     return fail("mckpp_hip_init: iso_bot=%d outside 2..nzp1", c->iso_bot);
   const int nzp1 = c->nz + 1;
@@ -293,6 +299,7 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
     h->l2pre = (nref >= 16 && !c->LDD) ? 1 : 0;
     if (const char *e = getenv("MCKPP_L2PRE")) h->l2pre = (atoi(e) != 0 && !c->LDD) ? 1 : 0;
     if (const char *e = getenv("MCKPP_L3_CAP")) h->l3cap = atoi(e) > 0 ? atoi(e) : 0;
+    h->solver_mode = solver_mode_env;
   }
   {
     std::vector<double> dm(ldc, 0.0), hs(ldc, 0.0);
@@ -777,13 +784,23 @@ int mckpp_hip_set_diagnostics(mckpp_hip_handle h, int on)
   return 0;
 }
 
+int mckpp_hip_set_solver_mode(mckpp_hip_handle h, int mode)
+{
+  if (!h) return fail("null handle");
+  if (mode < 0 || mode > 1) return fail("mckpp_hip_set_solver_mode: unknown solver mode (0: the reference's order, 1: two-ended)");
+  h->solver_mode = mode;
+  return 0;
+}
+
+int mckpp_hip_get_solver_mode(mckpp_hip_handle h) { return h ? h->solver_mode : fail("null handle"); }
+
 static void fill_params(mckpp_hip_ctx *h, mckpp_kparams &p, int ntime, int mode)
 {
   memset(&p, 0, sizeof p);
   p.nz = h->nz; p.nzp1 = h->nzp1; p.ncol = (int)h->ncol; p.ld = h->ld;
   p.ntime = ntime; p.itermax = h->c.itermax; p.mode = mode; p.diag = h->diag;
   p.L_SSref = h->c.L_SSref; p.LDD = h->c.LDD; p.clim_present = h->c.clim_present;
-  p.l2pre = h->l2pre; p.LRI = h->c.LRI ? 1 : 0; p.l3cap = h->l3cap;
+  p.l2pre = h->l2pre; p.LRI = h->c.LRI ? 1 : 0; p.l3cap = h->l3cap; p.solver_mode = h->solver_mode;
   p.hmixtolfrac = h->c.hmixtolfrac; p.dto = h->c.dto; p.grav = h->c.grav; p.vonk = h->c.vonk; p.sice = h->c.sice;
   p.Vtc = h->Vtc; p.cg = h->cg; p.dm_nz = h->dm_nz;
   p.zm = h->d_zm; p.hm = h->d_hm; p.tri0 = h->d_tri0; p.tri1 = h->d_tri1;
@@ -1618,6 +1635,7 @@ int mckpp_hip_multi_upload(mckpp_hip_multi_handle m, const mckpp_state_ptrs_c *s
 
 int mckpp_hip_multi_set_forcing(mckpp_hip_multi_handle m, const double *sflux) { MULTI_EACH(mckpp_hip_set_forcing(x, sflux)); }
 int mckpp_hip_multi_set_diagnostics(mckpp_hip_multi_handle m, int on) { MULTI_EACH(mckpp_hip_set_diagnostics(x, on)); }
+int mckpp_hip_multi_set_solver_mode(mckpp_hip_multi_handle m, int mode) { MULTI_EACH(mckpp_hip_set_solver_mode(x, mode)); }
 int mckpp_hip_multi_init_ocean(mckpp_hip_multi_handle m, int ntime) { MULTI_EACH(mckpp_hip_init_ocean(x, ntime)); }
 // asynchronous on every device: all shards are launched before the caller can wait on any of them
 int mckpp_hip_multi_step(mckpp_hip_multi_handle m, int ntime, int nsteps) { MULTI_EACH(mckpp_hip_step(x, ntime, nsteps)); }

@@ -146,6 +146,18 @@ module mckpp_hip_binding
       integer(c_int), value :: on
       integer(c_int) :: rc
     end function
+    function mckpp_hip_set_solver_mode(handle, mode) bind(C, name="mckpp_hip_set_solver_mode") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int), value :: mode
+      integer(c_int) :: rc
+    end function
+    function mckpp_hip_multi_set_solver_mode(handle, mode) bind(C, name="mckpp_hip_multi_set_solver_mode") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int), value :: mode
+      integer(c_int) :: rc
+    end function
     function mckpp_hip_init_ocean(handle, ntime) bind(C, name="mckpp_hip_init_ocean") result(rc)
       import :: c_int, c_ptr
       type(c_ptr), value :: handle

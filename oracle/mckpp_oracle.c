@@ -304,7 +304,9 @@ void orc_conv_literals(double *out)
   out[6] = 1. / 3.; out[7] = 0.04 / 49.; out[8] = 1.E-12; out[9] = 6.536332E-9; out[10] = 0.1;
 }
 
-void orc_lookup(double vonk, double *wmt, double *wst)
+void orc_lookup(double vonk, double *wmt, double *wst) { orc_lookup_mode(vonk, wmt, wst, 0); }
+
+void orc_lookup_mode(double vonk, double *wmt, double *wst, int half_pow_mode)
 {
   const int ni = ORC_NI, nj = ORC_NJ;
   const double epsln = 1.e-20, c1 = 5.0, zmin = -4.e-7, zmax = 0.0, umin = 0.0, umax = 0.04;
@@ -327,7 +329,8 @@ void orc_lookup(double vonk, double *wmt, double *wst)
         else
           wmt[TBL(i, j)] = vonk * pow(am * u3 - cm * zehat, 1. / 3.);
         if (zeta > zetas)                                 /* :60-64 */
-          wst[TBL(i, j)] = vonk * usta * sqrt(1. - c3 * zeta);   /* **(1./2.): a square root under amdflang, conv_probe.F90 */
+          wst[TBL(i, j)] = vonk * usta * (half_pow_mode ? pow(1. - c3 * zeta, 1. / 2.)
+                                                        : sqrt(1. - c3 * zeta));   /* **(1./2.): a square root under amdflang, conv_probe.F90 */
         else
           wst[TBL(i, j)] = vonk * pow(as * u3 - cs * zehat, 1. / 3.);
       }
@@ -459,6 +462,61 @@ int orc_tridmat(const double *cu, const double *cc, const double *cl,
     yn[i] = yn[i] - gam[i + 1] * yn[i + 1];
   yn[nzi + 1] = yo[nzi + 1];                              /* :159 */
   return bad;
+}
+
+/* The library's opt-in solver mode 1 (NOT the reference's operation order; orc_const.solver_mode): the same
+ * tridiagonal system, eliminated from both ends at once - downward from level 1 as tridmat does
+ * (solvers.F90:135-154) for the levels 1..m, m = nzi/2, upward from level nzi by the mirrored recurrence for the
+ * levels nzi..m+1 - then the two remaining unknowns y(m), y(m+1) from their 2x2 system, then the two back
+ * substitutions away from the middle.  Each half is a chain of nzi/2 dependent steps instead of nzi.  Every
+ * operation is one IEEE operation in the order written here; the HIP kernels' solver mode 1 performs exactly these.
+ *   upper half:  gam(i) = cl(i-1)/bet, bet = cc(i) - cu(i) gam(i), z(i) = (rhs(i) - cu(i) z(i-1))/bet
+ *   lower half:  g(i+1) = cu(i+1)/bet, bet = cc(i) - cl(i) g(i+1), z(i) = (rhs(i) - cl(i) z(i+1))/bet
+ *   middle:      y(m) = (z(m) - gam(m+1) z(m+1)) / (1 - gam(m+1) g(m+1)),  y(m+1) = z(m+1) - g(m+1) y(m)
+ *   back:        y(i) = z(i) - gam(i+1) y(i+1), i = m-1..1;   y(i) = z(i) - g(i) y(i-1), i = m+2..nzi
+ * A zero pivot is replaced as solvers.F90:140-151 does, in either half.  gam[2..m] holds the upper half's
+ * multipliers, gam[m+2..nzi] the lower half's. */
+int orc_tridmat_2e(const double *cu, const double *cc, const double *cl,
+                   const double *rhs, const double *yo, int nzi, double *yn, double *gam)
+{
+  if (nzi < 2) return orc_tridmat(cu, cc, cl, rhs, yo, nzi, yn, gam);
+  const int m = nzi / 2;
+  int bad = 0;
+  double bet = cc[1];
+  yn[1] = rhs[1] / bet;
+  for (int i = 2; i <= m; i++) {
+    gam[i] = cl[i - 1] / bet;
+    bet = cc[i] - cu[i] * gam[i];
+    if (bet == 0.) { bad = 1; bet = 1.E-12; }
+    yn[i] = (rhs[i] - cu[i] * yn[i - 1]) / bet;
+  }
+  const double gt = cl[m] / bet;                          /* gam(m+1) */
+  double betb = cc[nzi];
+  yn[nzi] = rhs[nzi] / betb;
+  for (int i = nzi - 1; i >= m + 1; i--) {
+    const double g = cu[i + 1] / betb;
+    gam[i + 1] = g;
+    betb = cc[i] - cl[i] * g;
+    if (betb == 0.) { bad = 1; betb = 1.E-12; }
+    yn[i] = (rhs[i] - cl[i] * yn[i + 1]) / betb;
+  }
+  const double gb = cu[m + 1] / betb;                     /* g(m+1) */
+  const double den = 1. - gt * gb;
+  const double ym = (yn[m] - gt * yn[m + 1]) / den;
+  const double ym1 = yn[m + 1] - gb * ym;
+  yn[m] = ym;
+  yn[m + 1] = ym1;
+  for (int i = m - 1; i >= 1; i--) yn[i] = yn[i] - gam[i + 1] * yn[i + 1];
+  for (int i = m + 2; i <= nzi; i++) yn[i] = yn[i] - gam[i] * yn[i - 1];
+  yn[nzi + 1] = yo[nzi + 1];
+  return bad;
+}
+
+static int tridmat_mode(const orc_const *c, const double *cu, const double *cc, const double *cl,
+                        const double *rhs, const double *yo, int nzi, double *yn, double *gam)
+{
+  return c->solver_mode == 1 ? orc_tridmat_2e(cu, cc, cl, rhs, yo, nzi, yn, gam)
+                             : orc_tridmat(cu, cc, cl, rhs, yo, nzi, yn, gam);
 }
 
 /* ------------------------------------------------------------------------
@@ -960,14 +1018,14 @@ static void ocnint(const orc_const *c, orc_col *q, int kmixe, double *const *Uo,
     rhs[i] = Uo[1][i] + dto * ftemp * .5 * (Uo[2][i] + q->U[2][i]);
   i = NZ;                                                 /* :56-58 */
   rhs[i] = Uo[1][i] + dto * ftemp * .5 * (Uo[2][i] + q->U[2][i]) + c->tri1[i] * q->difm[i] * Uo[1][i + 1];
-  if (orc_tridmat(cu, cc, cl, rhs, Uo[1], NZ, q->U[1], q->gam)) q->status |= ORC_ST_ZERO_PIVOT; /* :59 */
+  if (tridmat_mode(c, cu, cc, cl, rhs, Uo[1], NZ, q->U[1], q->gam)) q->status |= ORC_ST_ZERO_PIVOT; /* :59 */
   rhs[1] = Uo[2][1] - dto * (ftemp * .5 * (Uo[1][1] + q->U[1][1]) + q->wU[2][0] / hm[1]); /* :62-63 */
   for (i = 2; i <= NZ - 1; i++)                           /* :64-66 */
     rhs[i] = Uo[2][i] - dto * ftemp * .5 * (Uo[1][i] + q->U[1][i]);
   i = NZ;                                                 /* :67-69 */
   rhs[i] = Uo[2][i] - dto * ftemp * .5 * (Uo[1][i] + q->U[1][i]) + c->tri1[i] * q->difm[i] * Uo[2][i + 1];
   npd = 1;                                                /* :70 */
-  if (orc_tridmat(cu, cc, cl, rhs, Uo[2], NZ, q->U[2], q->gam)) q->status |= ORC_ST_ZERO_PIVOT; /* :71 */
+  if (tridmat_mode(c, cu, cc, cl, rhs, Uo[2], NZ, q->U[2], q->gam)) q->status |= ORC_ST_ZERO_PIVOT; /* :71 */
 
   double ghatflux = q->wX[1][0];                          /* :82-83 */
   double sturflux = q->wX[1][0];
@@ -1002,7 +1060,7 @@ static void ocnint(const orc_const *c, orc_col *q, int kmixe, double *const *Uo,
     rhs[k] = rhs[k] + q->tinc_fcorr[k];
     q->ocnTcorr[k] = q->tinc_fcorr[k] * q->rho[k] * q->cp[k] / dto;
   }
-  if (orc_tridmat(cu, cc, cl, rhs, Xo[1], NZ, q->X[1], q->gam)) q->status |= ORC_ST_ZERO_PIVOT; /* :162 */
+  if (tridmat_mode(c, cu, cc, cl, rhs, Xo[1], NZ, q->X[1], q->gam)) q->status |= ORC_ST_ZERO_PIVOT; /* :162 */
 
   for (int k = 0; k <= NZP1; k++) diff[k] = q->difs[k];   /* :165-167 */
   orc_tridcof(c, diff, NZ, cu, cc, cl);                   /* :168 */
@@ -1028,7 +1086,7 @@ static void ocnint(const orc_const *c, orc_col *q, int kmixe, double *const *Uo,
         q->scorr[k] = q->sinc_fcorr[k] / dto;
       }
     }
-    if (orc_tridmat(cu, cc, cl, rhs, Xo[n], NZ, q->X[n], q->gam)) q->status |= ORC_ST_ZERO_PIVOT; /* :218 */
+    if (tridmat_mode(c, cu, cc, cl, rhs, Xo[n], NZ, q->X[n], q->gam)) q->status |= ORC_ST_ZERO_PIVOT; /* :218 */
   }
 }
 

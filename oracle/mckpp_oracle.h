@@ -57,6 +57,8 @@ typedef struct {
   double iso_thresh;
   int dt_uvdamp;
   int exp_mode;         /* 0: libm exp (faithful); 1: portable exp shared bit-for-bit with the HIP kernels */
+  int solver_mode;      /* 0: tridmat in the reference's order (solvers.F90:112-161); 1: the two-ended elimination of
+                           orc_tridmat_2e (the library's opt-in solver mode, same operations as the HIP kernels) */
   /* grid, Fortran-indexed: zm[1..nzp1], hm[1..nzp1], dm[0..nz] */
   double *zm, *hm, *dm;
   /* tri(k,0,1) and tri(k,1,1), k = 0..nz (initialize_ocean.F90:34-43) */
@@ -115,6 +117,9 @@ void orc_z121(int kmp1, double vlo, double vhi, double *V, double *w);
 void orc_conv_probe(int n, const double *x, double *p3, double *p4, double *ph, double *pt, double *pq);
 void orc_conv_literals(double *out);
 void orc_lookup(double vonk, double *wmt, double *wst);
+/* half_pow_mode 0: x**(1./2.) is a square root (amdflang, the compiler the oracle is pinned to);
+ * 1: it is pow(x, 0.5) (how a compiler without that rewrite lowers lookup_mod.F90:60-62) */
+void orc_lookup_mode(double vonk, double *wmt, double *wst, int half_pow_mode);
 void orc_wscale(const orc_const *c, double sigma, double hbl, double ustar,
                 double bfsfc, double *wm, double *ws);
 double orc_swfrac(const orc_const *c, double fact, double z, int jwtype);
@@ -124,6 +129,9 @@ void orc_tridcof(const orc_const *c, const double *diff, int nzi, double *cu,
 int orc_tridmat(const double *cu, const double *cc, const double *cl,
                 const double *rhs, const double *yo, int nzi, double *yn,
                 double *gam);
+int orc_tridmat_2e(const double *cu, const double *cc, const double *cl,
+                   const double *rhs, const double *yo, int nzi, double *yn,
+                   double *gam);
 void orc_make_grid_uniform(int nz, double dmax, double *zm, double *hm, double *dm);
 void orc_make_tri(const orc_const *c);
 double orc_coriolis(double dlat);

@@ -40,7 +40,7 @@ class OrcConst(C.Structure):
         ("L_RELAX_SAL", C.c_int), ("L_RELAX_OCNT", C.c_int),
         ("L_NO_FREEZE", C.c_int), ("L_NO_ISOTHERM", C.c_int), ("L_DAMP_CURR", C.c_int),
         ("clim_present", C.c_int), ("iso_bot", C.c_int), ("iso_thresh", C.c_double),
-        ("dt_uvdamp", C.c_int), ("exp_mode", C.c_int),
+        ("dt_uvdamp", C.c_int), ("exp_mode", C.c_int), ("solver_mode", C.c_int),
         ("zm", C.POINTER(C.c_double)), ("hm", C.POINTER(C.c_double)), ("dm", C.POINTER(C.c_double)),
         ("tri0", C.POINTER(C.c_double)), ("tri1", C.POINTER(C.c_double)),
         ("wmt", C.POINTER(C.c_double)), ("wst", C.POINTER(C.c_double)),
@@ -69,6 +69,7 @@ def lib():
         L.orc_cpsw_batch.argtypes = [C.c_int] + [C.POINTER(C.c_double)] * 4
         L.orc_z121.argtypes = [C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_lookup.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_lookup_mode.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
         L.orc_conv_probe.argtypes = [C.c_int] + [C.POINTER(C.c_double)] * 6
         L.orc_conv_literals.argtypes = [C.POINTER(C.c_double)]
         L.orc_wscale.argtypes = [C.POINTER(OrcConst)] + [C.c_double] * 4 + [C.POINTER(C.c_double)] * 2
@@ -79,6 +80,8 @@ def lib():
         L.orc_tridcof.argtypes = [C.POINTER(OrcConst), C.POINTER(C.c_double), C.c_int] + [C.POINTER(C.c_double)] * 3
         L.orc_tridmat.restype = C.c_int
         L.orc_tridmat.argtypes = [C.POINTER(C.c_double)] * 5 + [C.c_int] + [C.POINTER(C.c_double)] * 2
+        L.orc_tridmat_2e.restype = C.c_int
+        L.orc_tridmat_2e.argtypes = [C.POINTER(C.c_double)] * 5 + [C.c_int] + [C.POINTER(C.c_double)] * 2
         L.orc_make_grid_uniform.argtypes = [C.c_int, C.c_double] + [C.POINTER(C.c_double)] * 3
         L.orc_make_tri.argtypes = [C.POINTER(OrcConst)]
         L.orc_coriolis.restype = C.c_double
@@ -141,7 +144,7 @@ def ref():
 class Const:
     """Owns the numpy buffers behind an OrcConst (Fortran-indexed arrays)."""
 
-    def __init__(self, nz, dto=3600.0, dmax=200.0, exp_mode=0, zm=None, hm=None, dm=None, **sw):
+    def __init__(self, nz, dto=3600.0, dmax=200.0, exp_mode=0, zm=None, hm=None, dm=None, half_pow_mode=0, **sw):
         L = lib()
         self.nz, self.nzp1 = nz, nz + 1
         n = nz + 4
@@ -175,7 +178,8 @@ class Const:
         c.tri0, c.tri1 = _dp(self.tri0), _dp(self.tri1)
         c.wmt, c.wst = _dp(self.wmt), _dp(self.wst)
         self.c = c
-        L.orc_lookup(c.vonk, c.wmt, c.wst)
+        self.half_pow_mode = half_pow_mode
+        L.orc_lookup_mode(c.vonk, c.wmt, c.wst, int(half_pow_mode))
         L.orc_make_tri(C.byref(c))
 
     @property

@@ -26,6 +26,9 @@ def make_oracle(ncol, nz, mix="bench", exp_mode=1, grid="uniform", dto=3600.0, n
     """Oracle const + batch with synthetic columns; runs init_ocean unless init=False."""
     zm, hm, dm = grid_for(nz, grid)
     sw = {k: v for k, v in sw.items() if k != "L_ADVECT"}   # the oracle keys advection on nmodeadv alone
+    # MCKPP_SOLVER_MODE sets the default solver mode of the library's handles: the checker follows it, so the whole
+    # -m gpu suite can be run against either mode
+    sw.setdefault("solver_mode", int(os.environ.get("MCKPP_SOLVER_MODE", "0")))
     oc = orc.Const(nz, dto=dto, exp_mode=exp_mode, zm=zm, hm=hm, dm=dm, **sw)
     col = synth.columns(ncol, nz, zm=zm, index=index, ntotal=ntotal)
     ob = orc.Batch(ncol, nz)
@@ -151,4 +154,49 @@ def compare(k3, ob, nz, fields, active=None):
         differ = np.ascontiguousarray(h).view(np.int64) != np.ascontiguousarray(o).view(np.int64)
         bits = int((differ & ~((h == 0) & (o == 0)) & ~(np.isnan(h) & np.isnan(o))).sum())
         out[name] = (float(d.max()) if d.size else 0.0, float((d / den).max()) if d.size else 0.0, bits)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# tolerance tables (tools/r04_tolerance.py, test_tolerance_vs_faithful_oracle)
+# ---------------------------------------------------------------------------
+def oracle_state(ob, nz):
+    """hmix, kmix and the T/S/U/V profiles of an oracle batch as {name: array} (views)."""
+    s = {k: ob.a[k][:, 1:nz + 2] for k in "TSUV"}
+    s["hmix"], s["kmix"] = ob["hmix"], ob["kmix"]
+    return s
+
+
+def hip_state(k3, nz):
+    s = {k: hip_field(k3, k, nz)[0] for k in "TSUV"}
+    s["hmix"], s["kmix"] = np.asarray(k3.hmix), np.asarray(k3.kmix)
+    return s
+
+
+def tolerance_metrics(a, b, same_path=None, active=None):
+    """SURVEY 8(d) parity gate between two runs `a` and `b` (dicts from oracle_state / hip_state): columns whose kmix
+    differs now, and max / 99.9-percentile error of hmix (relative) and of T, S, U, V (relative to the profile's
+    largest magnitude) - over the columns that have taken the same discrete path so far (`same_path`, default: same
+    kmix now) and over the others separately."""
+    sel = np.ones(len(a["hmix"]), bool) if active is None else np.asarray(active, bool)
+    flipped_now = (np.asarray(a["kmix"]) != np.asarray(b["kmix"])) & sel
+    same = (~flipped_now if same_path is None else np.asarray(same_path, bool) & ~flipped_now) & sel
+    other = sel & ~same
+    out = {"columns": int(sel.sum()), "kmix_differs_now": int(flipped_now.sum()), "off_path_columns": int(other.sum()),
+           "same_path": {}, "off_path": {}}
+    err = {}
+    for name in "TSUV":
+        scale = np.maximum(np.abs(b[name]).max(axis=1), 1e-30)
+        err[name] = np.abs(a[name] - b[name]).max(axis=1) / scale
+    err["hmix"] = np.abs(a["hmix"] - b["hmix"]) / np.maximum(np.abs(b["hmix"]), 1e-30)
+    for name, e in err.items():
+        es = e[same]
+        out["same_path"][name] = {"max": float(es.max()) if es.size else 0.0,
+                                  "p999": float(np.quantile(es, 0.999)) if es.size else 0.0,
+                                  "columns_above_1e-10": int((es > 1e-10).sum())}
+        eo = e[other]
+        out["off_path"][name] = {"max": float(eo.max()) if eo.size else 0.0}
+    if other.any():
+        out["off_path"]["max_abs_kmix_difference"] = float(np.abs(np.asarray(a["kmix"]) - np.asarray(b["kmix"]))[other].max())
+        out["off_path"]["max_abs_hmix_difference_m"] = float(np.abs(a["hmix"] - b["hmix"])[other].max())
     return out

@@ -39,16 +39,19 @@ def _assert_bitexact(res, tag=""):
 
 
 def _run_both(mk, ncol, nz, nsteps, grid="uniform", land_every=0, jerlov_mix=False, exp_mode=1, dto=3600.0,
-              mix="bench", nztmax=None):
+              mix="bench", nztmax=None, solver_mode=None):
     from oracle import orc
 
-    oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=exp_mode, grid=grid, dto=dto)
+    sm = {} if solver_mode is None else {"solver_mode": solver_mode}
+    oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=exp_mode, grid=grid, dto=dto, **sm)
     kc, k3 = cm.make_hip_case(ncol, nz, grid=grid, dto=dto, land_every=land_every)
     if jerlov_mix:
         jer = 1 + (np.arange(ncol) % 5).astype(np.int32)
         k3.jerlov[:] = jer
         ob["jerlov"] = jer
     ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    if solver_mode is not None:
+        ctx.set_solver_mode(solver_mode)
     orc.init_ocean(oc, ob, 0)
     active = np.nonzero(k3.run_physics)[0]
     out = [("init", cm.compare(k3, ob, nz, ALL_FIELDS, active))]
@@ -102,6 +105,20 @@ def test_step_bitexact_uniform_grid(mk, nz, ncol, nsteps):
     out, *_ = _run_both(mk, ncol, nz, nsteps)
     for tag, res in out:
         _assert_bitexact(res, f"nz={nz} {tag}")
+
+
+@pytest.mark.parametrize("nz,ncol,nsteps,grid", [(40, 64, 3, "uniform"), (60, 1000, 3, "uniform"), (100, 130, 2, "uniform"),
+                                                 (69, 333, 2, "stretched"), (2, 40, 2, "uniform"), (3, 40, 2, "uniform"),
+                                                 (5, 40, 2, "uniform"), (12, 70, 2, "uniform"), (61, 90, 2, "uniform"),
+                                                 (150, 40, 2, "uniform")])
+def test_step_bitexact_two_ended_solver(mk, nz, ncol, nsteps, grid):
+    """Solver mode 1 (mckpp_hip_set_solver_mode: every tridiagonal system eliminated from both ends at once) against
+    the oracle's restatement of exactly that order of operations (orc_tridmat_2e): bit for bit, like mode 0 against
+    tridmat's order.  Odd and even depths, the smallest ones (a half of one level), one to three trips of the item loop."""
+    out, *_ = _run_both(mk, ncol, nz, nsteps, grid=grid, solver_mode=1, land_every=3 if grid == "stretched" else 0,
+                        jerlov_mix=grid == "stretched")
+    for tag, res in out:
+        _assert_bitexact(res, f"two-ended nz={nz} {tag}")
 
 
 def test_step_bitexact_stretched_grid_69_levels_land_mask_jerlov(mk):
