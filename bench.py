@@ -20,8 +20,15 @@ driven from rank 0's process while the other ranks wait.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`,
 plus (N=1 only, never part of `value`):
-  sustained            400 more steps of the headline workload in one call (the headline's 40 steps are a
-                       0.14 s burst)
+  burst                the K steps as a cold device runs them (before the settle leg; `value` is measured after
+                       SETTLE steps of the same work, i.e. at the clock a model run sees)
+  sustained            400 more steps of the headline workload in one call
+  two_ended_solver     the headline workload with mckpp_hip_set_solver_mode(1) (opt-in: every tridiagonal system
+                       eliminated from both ends at once; `value` itself is the reference-order solver)
+  config1_pass         BASELINE configs[1]: 1e4 x 60, one kppmix + tridiagonal pass per launch (mckpp_hip_vmix_pass),
+                       with its own algorithmic bytes per column-pass
+  tail                 the headline columns with 1 % of them knocked out of balance (storm forcing switched on at
+                       the timed steps): the data-dependent tail of the iteration in a timed region
   drop_in              the reference-shaped host loop through the C-ABI, per step: mckpp_hip_set_forcing +
                        mckpp_hip_step + mckpp_hip_download of the scalar group / the restart set / every
                        field (PCIe-inclusive; never `value`)
@@ -36,7 +43,6 @@ import argparse
 import gc
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -53,6 +59,11 @@ import numpy as np  # noqa: E402
 # timed steps are ordinary ones whatever --warmup is.
 SPINUP = 3
 DIURNAL_STEPS = 48
+# Untimed steps of the headline workload right before the timed region: a cold MI355X runs ~0.2 s of fp64 work at a
+# clock it does not hold (the first 40 steps measure 3.0 ms each, 400 in a row 3.5 ms - r03), so K timed steps after
+# a short warmup describe a burst, not the run.  `value` is therefore measured after SETTLE more steps (~1.2 s); the
+# burst figure is reported beside it.
+SETTLE = 400
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -96,7 +107,14 @@ def diurnal_series(ncol, nt_first, nsteps, dto, index=None):
     return cm.synth.flux_series(ncol, nt_first, nsteps, dto, "bench", index)
 
 
-def cpu_baseline(ncol_total, nz, warmup, nsteps, stride, diurnal_stride, diurnal_nt0, dto):
+def alg_bytes_per_column_pass(nz):
+    """SURVEY.md section 8(d), configs[1] (un-fused kppmix + tridiagonal kernels, per pass):
+    kppmix 8*(9*nzp1+10) + tridiagonal solves 8*(14*nzp1+8)."""
+    nzp1 = nz + 1
+    return 8 * (9 * nzp1 + 10) + 8 * (14 * nzp1 + 8)
+
+
+def cpu_baseline(ncol_total, nz, warmup, nsteps, stride, diurnal_stride, diurnal_nt0, dto, with_diurnal=True):
     """Oracle (CPU restatement, OpenMP over columns, dynamic schedule like the reference's driver loop)
     on every `stride`-th column of the same workload: the same `warmup` untimed steps, then three
     consecutive blocks of `nsteps` model steps on all host cores (median reported; the first block is
@@ -143,6 +161,8 @@ def cpu_baseline(ncol_total, nz, warmup, nsteps, stride, diurnal_stride, diurnal
         "sample_1thread": f"{len(idx1)} columns, model steps {warmup + 1}-{warmup + nsteps}, {dt1:.1f} s",
         "mean_passes_per_column_step_last_step": passes,
     }
+    if not with_diurnal:
+        return out
     # the diurnal leg on the CPU port: every diurnal_stride-th column, the same model steps as the GPU leg
     idxd = np.arange(0, ncol_total, diurnal_stride)
     nd = len(idxd)
@@ -213,6 +233,97 @@ def side_shape(mk, cm, ncol, nz, grid, dto, land_frac, steps, warmup, diag, dev_
     return out
 
 
+def headline_variant(mk, cm, ncol, nz, idx, ntotal, a, dev_index, solver_mode=0, tail_frac=0.0):
+    """The headline workload once more in a context of its own: spin-up, warmup and settle steps as the headline,
+    then a timed region - with another solver mode, or (tail_frac > 0) with that fraction of the columns knocked out
+    of balance at the timed steps (storm forcing: taux 1.0 N/m2, 1200 W/m2 of surface cooling, no sun), so that the
+    iteration's data-dependent tail - tens of passes, the instability trap - is inside a timed region."""
+    kc, k3 = cm.make_hip_case(ncol, nz, grid=a.grid, dto=a.dto, index=idx, ntotal=ntotal)
+    ctx = mk.MckppHip(kc, device=dev_index)
+    ctx.set_solver_mode(solver_mode)
+    ctx.upload(k3)
+    ctx.set_diagnostics(a.diag)
+    ctx.init_ocean(0)
+    sf = cm.synth.forcing(ncol, "bench", index=idx)
+    cm.set_forcing_3d(k3, sf)
+    ctx.set_forcing(k3.sflux)
+    nt = 1
+    ctx.step(nt, SPINUP + a.warmup + a.settle)
+    ctx.synchronize()
+    nt += SPINUP + a.warmup + a.settle
+    nocean = int(ctx.ncolumns)
+    balg = alg_bytes_per_column_step(nz, a.diag)
+    if tail_frac <= 0.0:
+        dt, kern_s = time_steps(ctx, nt, a.steps, lambda: None)
+        st, nflag, npass = ctx.status()
+        out = {"value": nocean * a.steps / dt, "unit": "column-steps/s", "ms_per_step": dt / a.steps * 1e3, "steps": a.steps,
+               "kernel_avg_ms": kern_s * 1e3, "roofline_frac": balg * nocean / kern_s / 1e9 / HBM_PEAK_GBS,
+               "mean_passes_per_column_step_last_step": float(npass.mean()), "flagged_columns_last_step": int(nflag)}
+    else:
+        every = max(1, int(round(1.0 / tail_frac)))
+        hit = np.arange(ncol) % every == every // 2
+        sf[hit, 0] = 1.0; sf[hit, 2] = 0.0; sf[hit, 3] = -1200.0; sf[hit, 5] = 6e-5 - 1200.0 / cm.synth.EL
+        cm.set_forcing_3d(k3, sf)
+        ctx.set_forcing(k3.sflux)
+        ctx.synchronize()
+        per_step, tsum, ksum = [], 0.0, 0.0
+        for _ in range(6):
+            dt, kern_s = time_steps(ctx, nt, 1, lambda: None)
+            nt += 1
+            st, nflag, npass = ctx.status()
+            tsum += dt; ksum += kern_s
+            per_step.append({"ms": dt * 1e3, "mean_passes": float(npass.mean()), "max_passes": int(npass.max()),
+                             "mean_passes_of_the_hit_columns": float(npass[hit].mean()),
+                             "columns_with_status_bits": int(nflag), "trap_fired": int(((st & 4) != 0).sum())})
+        out = {"value": nocean * 6 / tsum, "unit": "column-steps/s", "ms_per_step": tsum / 6 * 1e3, "steps": 6,
+               "kernel_avg_ms": ksum / 6 * 1e3, "columns_hit": int(hit.sum()),
+               "column_passes_per_s": sum(p["mean_passes"] for p in per_step) * nocean / tsum, "per_step": per_step,
+               "what": f"every {every}th column gets storm forcing from the first timed step on; six single-step launches, "
+                       "status read after each (outside the timing)"}
+    ctx.close()
+    del ctx, k3, kc
+    gc.collect()
+    return out
+
+
+def config1_pass(mk, cm, dev_index, a, ncol=10000, nz=60, launches=200):
+    """BASELINE configs[1]: 1e4 columns x 60 levels, kppmix + tridiagonal solves only - one vmix + ocnint pass per
+    launch (mckpp_hip_vmix_pass, kernel mode PASS: no iteration, no relaxation), from a spun-up state."""
+    kc, k3 = cm.make_hip_case(ncol, nz)
+    ctx = mk.MckppHip(kc, device=dev_index)
+    ctx.upload(k3)
+    ctx.set_diagnostics(a.diag)
+    ctx.init_ocean(0)
+    cm.set_forcing_3d(k3, cm.synth.forcing(ncol, "bench"))
+    ctx.set_forcing(k3.sflux)
+    ctx.step(1, SPINUP + 5)
+    for _ in range(20):
+        ctx.vmix_pass(SPINUP + 6)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ksum = 0.0
+    for _ in range(launches):
+        ctx.vmix_pass(SPINUP + 6)
+        ctx.synchronize()
+        kms, nl = ctx.last_kernel_ms()
+        ksum += kms / max(nl, 1)
+    dt = time.perf_counter() - t0
+    kern_s = ksum / launches * 1e-3
+    nocean = int(ctx.ncolumns)
+    bpass = alg_bytes_per_column_pass(nz)
+    ach = bpass * nocean / kern_s / 1e9
+    out = {"workload": f"{ncol} columns x {nz} levels, one kppmix + tridiagonal pass per launch (BASELINE configs[1])",
+           "value": nocean / kern_s, "unit": "column-passes/s", "launches": launches,
+           "kernel": ctx.kernel_name + ", mode PASS", "kernel_avg_ms": kern_s * 1e3, "wall_ms_per_launch_host_synchronous": dt / launches * 1e3,
+           "algorithmic_bytes_per_column_pass": bpass,
+           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS},
+           "note": "1e4 columns are 1.3 rounds of the 7,680 column slots in flight: the launch is mostly its own tail"}
+    ctx.close()
+    del ctx, k3, kc
+    gc.collect()
+    return out
+
+
 def committed_counters(ncol, nz, kernel_name, build_id):
     """PMC-derived figures committed under profiles/ (HBM traffic per launch, VALU instruction counts).
     They describe one kernel build: returned only when recorded for the loaded library's build id and
@@ -249,12 +360,10 @@ def launch_ranks(ngpus, argv, dry_run=False):
     """`bench.py --gpus N` started plainly: run the N ranks under torch.distributed.run as a child process and relay
     rank 0's JSON line and the exit code.  Nothing here imports torch or loads the library - a process that has
     initialised the GPU must not be the one that starts the ranks."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    # --standalone: torchrun picks the rendezvous port itself (no bind-close-reuse race); 127.0.0.1 because the
+    # container's host name may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={ngpus}", os.path.abspath(__file__)] + list(argv)
     if dry_run:
         print(json.dumps({"cmd": cmd, "torch_imported": "torch" in sys.modules,
                           "library_loaded": "mckpp_f90_amd" in sys.modules}), flush=True)
@@ -367,6 +476,8 @@ def main():
     ap.add_argument("--total-ncol", type=int, default=0,
                     help="strong scaling: this many columns in all, divided over the GPUs (overrides --ncol)")
     ap.add_argument("--sustained-steps", type=int, default=400)
+    ap.add_argument("--settle", type=int, default=SETTLE,
+                    help="untimed steps of the same work before the timed region (0: time the cold device's burst)")
     ap.add_argument("--print-launch", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
 
@@ -433,7 +544,19 @@ def main():
     ctx.step(1, SPINUP)
     if a.warmup > 0:
         ctx.step(1 + SPINUP, a.warmup)
-    dt, kern_s = time_steps(ctx, 1 + SPINUP + a.warmup, a.steps, barrier)
+    nt_next = 1 + SPINUP + a.warmup
+    burst = None
+    if a.settle > 0:   # the K steps as a cold device runs them (reported, not `value`), then the settle leg
+        dtb, kern_b = time_steps(ctx, nt_next, a.steps, barrier)
+        nt_next += a.steps
+        burst = {"value_this_rank": nocean * a.steps / dtb, "unit": "column-steps/s", "ms_per_step": dtb / a.steps * 1e3,
+                 "kernel_avg_ms": kern_b * 1e3,
+                 "what": f"the same {a.steps} steps right after the {a.warmup} warmup steps, device cold (this rank's columns)"}
+        ctx.step(nt_next, a.settle)
+        ctx.synchronize()
+        nt_next += a.settle
+    dt, kern_s = time_steps(ctx, nt_next, a.steps, barrier)
+    nt_next += a.steps
 
     st, nflag, npass = ctx.status()
     ocean = k3.run_physics != 0
@@ -507,7 +630,9 @@ def main():
                             f"1/3 windy), dto={a.dto:.0f} s, "
                             + ("BASELINE configs[3] shape" if strong and nz == 100 else "BASELINE configs[2]"),
                 "columns_per_gpu": ncol, "ocean_columns_per_gpu": nocean, "levels": nz,
-                "diagnostics_written": bool(a.diag), "spin_up_steps": SPINUP,
+                "diagnostics_written": bool(a.diag), "spin_up_steps": SPINUP, "settle_steps": a.settle,
+                "solver": "reference order (mckpp_hip_set_solver_mode 0; solvers.F90:112-161)" if ctx.solver_mode == 0
+                          else "two-ended elimination (mckpp_hip_set_solver_mode 1, opt-in)",
                 "sharding": f"columns round-robin over {world} GPU(s), no data-path collective",
                 "mean_passes_per_column_step_last_step": float(npass[ocean].mean()),
                 "max_passes_last_step": int(npass[ocean].max()),
@@ -525,6 +650,12 @@ def main():
         }
         if why_not:
             out["roofline"]["counters_note"] = why_not
+        out["column_passes_per_s"] = out["value"] * float(npass[ocean].mean())
+        if burst is not None:
+            out["burst"] = burst
+        if world > 1:
+            out["roofline"]["note_ranks"] = ("rank 0's kernel on its own columns; every rank launches the same kernel on "
+                                             "its shard - per-rank step times in multi_gpu.per_rank_ms_per_step")
         if multi is not None:
             out["multi_gpu"] = multi
 
@@ -542,7 +673,7 @@ def main():
 
     extras = world == 1 and not a.no_extras
     if extras:
-        nt_s = SPINUP + a.warmup + a.steps
+        nt_s = nt_next - 1
         # ---- drop-in host loop: forcing up, one step, field groups down, every step ----
         out["drop_in"], nt_s = drop_in_block(mk, ctx, k3, nt_s, nocean, (
             ("scalars", mk.api.F_SCALARS, 20), ("restart_set", mk.api.F_RESTART, 6), ("all_fields", mk.api.F_ALL, 3)))
@@ -574,6 +705,13 @@ def main():
     gc.collect()
 
     if extras:
+        out["two_ended_solver"] = headline_variant(mk, cm, ncol, nz, idx, ntotal, a, dev_index, solver_mode=1)
+        out["two_ended_solver"]["config"] = {
+            "solver": "two-ended elimination (mckpp_hip_set_solver_mode 1): opt-in, not the reference's order of operations; "
+                      "bit-identical to the oracle's solver_mode=1, within rounding of mode 0 (profiles/r04/parity_tolerance.json)",
+            "ratio_to_value": out["two_ended_solver"]["value"] / out["value"]}
+        out["tail"] = headline_variant(mk, cm, ncol, nz, idx, ntotal, a, dev_index, tail_frac=0.01)
+        out["config1_pass"] = config1_pass(mk, cm, dev_index, a)
         out["other_shapes"] = [
             side_shape(mk, cm, 100000, 69, "stretched", 1200.0, 0.35, 10, 2, a.diag, dev_index),
             side_shape(mk, cm, 100000, 100, "uniform", 3600.0, 0.0, 10, 2, a.diag, dev_index),
@@ -618,6 +756,12 @@ def main():
         del ctx, k3, kc
         gc.collect()
     if rank == 0:
+        if world > 1 and not a.no_cpu_baseline:
+            # rank 0's host cores, every 4th of rank 0's columns (bounded: the line must come within the driver's limit
+            # at every N), no diurnal leg
+            cb = cpu_baseline(ncol, nz, a.warmup, a.cpu_steps, max(a.cpu_stride, 4), 4, 0, a.dto, with_diurnal=False)
+            cb["note"] = "timed on rank 0's host while the other ranks wait; a sample of rank 0's shard of the workload"
+            out["cpu_baseline"] = cb
         if world == 1 and not a.no_cpu_baseline:
             cb = cpu_baseline(ncol, nz, a.warmup, a.cpu_steps, a.cpu_stride, 4, SPINUP + a.warmup + a.steps, a.dto)
             if extras:

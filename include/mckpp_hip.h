@@ -126,6 +126,10 @@ const char *mckpp_hip_last_error(void);
 /* Twelve hex digits identifying the kernel sources this library was built from
  * (measurement bookkeeping: profiles/ records it next to counter values). */
 const char *mckpp_hip_build_id(void);
+/* The compiler (hipcc --version line) the kernels were built and gate-checked with: the register budget and the
+ * hand-scheduled LDS reads of the column kernel are checked on the code THAT compiler generated (tools/check_build.py,
+ * run by the library's Makefile); a build made with CHECK=0 carries "-unchecked" in its build id. */
+const char *mckpp_hip_build_compiler(void);
 
 /* Number of visible gfx950 devices (<0 on error). */
 int mckpp_hip_device_count(void);

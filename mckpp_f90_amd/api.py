@@ -172,6 +172,12 @@ def _lib():
     return _bind(load_library())
 
 
+def build_compiler():
+    lib = _lib()
+    lib.mckpp_hip_build_compiler.restype = C.c_char_p
+    return lib.mckpp_hip_build_compiler().decode()
+
+
 def build_id():
     """Identifier of the kernel sources the loaded library was built from."""
     return _lib().mckpp_hip_build_id().decode()
@@ -308,13 +314,24 @@ class MckppHip:
     def __init__(self, kpp_const_fields, device=0):
         self._h = C.c_void_p()
         self._const = kpp_const_fields
+        # The library pins (hipHostRegister) every large host array it transfers from or into and keeps the
+        # registration until release_host_arrays() / close(): an array must not be freed while it is registered (a new
+        # array at the same address would be transferred through stale page mappings).  So every array - or object
+        # holding arrays - handed to upload / download / set_forcing / gather / window_fetch stays referenced here
+        # for exactly that long.
+        self._held = []
         cc = kpp_const_fields.as_c()
         _chk(_lib().mckpp_hip_init(C.byref(cc), int(device), C.byref(self._h)))
+
+    def _hold(self, obj):
+        if not any(o is obj for o in self._held):
+            self._held.append(obj)
 
     def close(self):
         if self._h:
             _lib().mckpp_hip_finalize(self._h)
             self._h = C.c_void_p()
+        self._held = []
 
     def __del__(self):
         try:
@@ -323,12 +340,14 @@ class MckppHip:
             pass
 
     def upload(self, kpp_3d_fields):
+        self._hold(kpp_3d_fields)
         s = kpp_3d_fields.as_c()
         _chk(_lib().mckpp_hip_upload(self._h, C.byref(s)))
         self._npts_cache = kpp_3d_fields.npts
 
     def set_forcing(self, sflux):
         assert sflux.flags["F_CONTIGUOUS"]
+        self._hold(sflux)
         _chk(_lib().mckpp_hip_set_forcing(self._h, sflux.ctypes.data_as(_dp)))
 
     def fluxes(self, ntime, taux, tauy, swf, lwf, lhf, shf, rain, snow, l_rest=0, flsn=334000.0, el=2.5e6):
@@ -340,6 +359,7 @@ class MckppHip:
         """fields[nrec, 8, npts]: taux, tauy, swf, lwf, lhf, shf, rain, snow at successive flux updates."""
         f = np.ascontiguousarray(fields, dtype=np.float64)
         assert f.ndim == 3 and f.shape[1] == 8 and f.shape[2] == self._npts_cache
+        self._hold(f)
         _chk(_lib().mckpp_hip_set_flux_series(self._h, int(rec0), int(f.shape[0]), f.ctypes.data_as(_dp)))
 
     def run_forced(self, nt_first, nsteps, ndtocn, l_rest=0, flsn=334000.0, el=2.5e6):
@@ -360,6 +380,7 @@ class MckppHip:
 
     def update_ancillaries(self, kpp_3d_fields):
         """Re-upload what mckpp_boundary_update rewrites between steps (optional-physics inputs only)."""
+        self._hold(kpp_3d_fields)
         sc = kpp_3d_fields.as_c()
         _chk(_lib().mckpp_hip_update_ancillaries(self._h, C.byref(sc)))
 
@@ -376,6 +397,7 @@ class MckppHip:
 
     def window_fetch(self, field, op, out):
         assert out.flags["F_CONTIGUOUS"] and out.dtype == np.float64
+        self._hold(out)
         _chk(_lib().mckpp_hip_window_fetch(self._h, int(field), int(op), out.ctypes.data_as(_dp)))
         return out
 
@@ -391,8 +413,10 @@ class MckppHip:
         return int(_lib().mckpp_hip_get_solver_mode(self._h))
 
     def release_host_arrays(self):
-        """Un-pin the caller's arrays this context registered (before they are freed while the context lives)."""
+        """Un-pin the caller's arrays this context registered (before they are freed while the context lives);
+        the references this object holds on them go with the registrations."""
         _chk(_lib().mckpp_hip_release_host_arrays(self._h))
+        self._held = []
 
     def init_ocean(self, ntime=0):
         _chk(_lib().mckpp_hip_init_ocean(self._h, int(ntime)))
@@ -410,6 +434,7 @@ class MckppHip:
         _chk(_lib().mckpp_hip_synchronize(self._h))
 
     def download(self, kpp_3d_fields, mask=F_ALL):
+        self._hold(kpp_3d_fields)
         s = kpp_3d_fields.as_c()
         _chk(_lib().mckpp_hip_download(self._h, C.byref(s), int(mask)))
 
@@ -476,18 +501,26 @@ class MckppHipMulti:
         dev = np.ascontiguousarray(devices, dtype=np.int32)
         _chk(_lib().mckpp_hip_multi_init(C.byref(cc), len(dev), dev.ctypes.data_as(_ip), C.byref(self._h)))
         self._npts = 0
+        self._held = []   # host arrays the shards have pinned: referenced until close() / release_host_arrays() (see MckppHip)
+
+    def _hold(self, obj):
+        if not any(o is obj for o in self._held):
+            self._held.append(obj)
 
     def close(self):
         if self._h:
             _lib().mckpp_hip_multi_finalize(self._h)
             self._h = C.c_void_p()
+        self._held = []
 
     def upload(self, k3):
+        self._hold(k3)
         sc = k3.as_c()
         _chk(_lib().mckpp_hip_multi_upload(self._h, C.byref(sc)))
         self._npts = k3.npts
 
     def set_forcing(self, sflux):
+        self._hold(sflux)
         _chk(_lib().mckpp_hip_multi_set_forcing(self._h, sflux.ctypes.data_as(_dp)))
 
     def init_ocean(self, ntime=0):
@@ -500,6 +533,7 @@ class MckppHipMulti:
         _chk(_lib().mckpp_hip_multi_synchronize(self._h))
 
     def download(self, k3, mask=F_ALL):
+        self._hold(k3)
         sc = k3.as_c()
         _chk(_lib().mckpp_hip_multi_download(self._h, C.byref(sc), mask))
 
@@ -517,6 +551,7 @@ class MckppHipMulti:
     def gather(self, field, root, out):
         """field 0 U, 1 V, 2 T, 3 S -> out(npts, nzp1) Fortran order; 4 hmix -> out(npts)."""
         assert out.flags["F_CONTIGUOUS"] and out.dtype == np.float64
+        self._hold(out)
         _chk(_lib().mckpp_hip_multi_gather(self._h, int(field), int(root), out.ctypes.data_as(_dp)))
 
     def set_diagnostics(self, on):
@@ -529,6 +564,7 @@ class MckppHipMulti:
         """fields[nrec][8][npts] (taux,tauy,swf,lwf,lhf,shf,rain,snow); record 0 is flux update rec0."""
         f = np.ascontiguousarray(fields, dtype=np.float64)
         assert f.ndim == 3 and f.shape[1] == 8 and f.shape[2] == self._npts
+        self._hold(f)
         _chk(_lib().mckpp_hip_multi_set_flux_series(self._h, int(rec0), f.shape[0], f.ctypes.data_as(_dp)))
 
     def run_forced(self, nt_first, nsteps, ndtocn, l_rest=0, flsn=334000.0, el=2.5e6):
@@ -547,6 +583,7 @@ class MckppHipMulti:
 
     def window_fetch(self, field, op, out):
         assert out.flags["F_CONTIGUOUS"] and out.dtype == np.float64
+        self._hold(out)
         _chk(_lib().mckpp_hip_multi_window_fetch(self._h, int(field), int(op), out.ctypes.data_as(_dp)))
         return out
 
@@ -558,6 +595,7 @@ class MckppHipMulti:
 
     def release_host_arrays(self):
         _chk(_lib().mckpp_hip_multi_release_host_arrays(self._h))
+        self._held = []
 
 
 def host_shard_mask(run_physics, ndev, dev):

@@ -145,8 +145,7 @@ struct mckpp_hip_ctx {
   size_t h_f_elems = 0;
   hipEvent_t ev_f = nullptr;
   // record slots as (npts) slabs in 3-D order, packed on the device (a context that holds every grid point)
-  double *d_pack = nullptr;
-  int *d_ipack = nullptr;
+  double *d_pack = nullptr, *h_pack = nullptr;   // packed record slabs of a download: device block, pinned host block
   int diag = 1;
   // optional-physics contexts: the relaxation / correction / advection inputs come with upload (or
   // update_ancillaries); load_restart does not carry them, so stepping is refused until they are there
@@ -161,6 +160,10 @@ const char *mckpp_hip_last_error(void) { return g_err.c_str(); }
 #define MCKPP_BUILD_ID "unknown"
 #endif
 const char *mckpp_hip_build_id(void) { return MCKPP_BUILD_ID; }
+#ifndef MCKPP_BUILD_COMPILER
+#define MCKPP_BUILD_COMPILER "unknown"
+#endif
+const char *mckpp_hip_build_compiler(void) { return MCKPP_BUILD_COMPILER; }
 
 int mckpp_hip_device_count(void)
 {
@@ -378,8 +381,8 @@ static void free_state(mckpp_hip_ctx *h)
   h->stage_elems = 0;
   for (int b = 0; b < 2; ++b) { if (h->d_xfer[b]) hipFree(h->d_xfer[b]); h->d_xfer[b] = nullptr; h->xfer_elems[b] = 0; }
   if (h->d_pack) hipFree(h->d_pack);
-  if (h->d_ipack) hipFree(h->d_ipack);
-  h->d_pack = nullptr; h->d_ipack = nullptr;
+  if (h->h_pack) hipHostFree(h->h_pack);
+  h->d_pack = nullptr; h->h_pack = nullptr;
   if (h->h_cs) hipHostFree(h->h_cs);
   if (h->h_ci) hipHostFree(h->h_ci);
   if (h->h_f) hipHostFree(h->h_f);
@@ -427,6 +430,9 @@ int64_t mckpp_hip_ncolumns(mckpp_hip_handle h) { return h ? h->ncol : -1; }
 static int ensure_stage(mckpp_hip_ctx *h, size_t elems)
 {
   if (elems <= h->stage_elems) return 0;
+  // a fluxes / unpack / window kernel queued by an earlier call may still be reading the block (those calls do not
+  // end with a synchronisation): wait for this context's stream, not - through hipFree - for the whole device
+  if (h->d_stage) HIPCHK(hipStreamSynchronize(h->stream));
   if (h->d_stage) hipFree(h->d_stage);
   h->d_stage = nullptr;
   h->stage_elems = 0;
@@ -1073,23 +1079,24 @@ static int download_records(mckpp_hip_ctx *h, mckpp_state_ptrs_c *s, uint32_t ma
       if (s->sflux)
         for (int m = 0; m < 6; ++m) addd(s->sflux + npts * m + npts * (int64_t)h->c.nsflxs * 4, CS_SFLUX1 + m);
     }
-    if (!h->d_pack) HIPCHK(hipMalloc(&h->d_pack, (size_t)npts * MCKPP_CS * sizeof(double)));
-    if (!h->d_ipack) HIPCHK(hipMalloc(&h->d_ipack, (size_t)npts * MCKPP_CI * sizeof(int)));
-    HIPCHK(mckpp_launch_pack_records(h->d_cs, h->d_ci, h->d_ipt, ncol, npts, l, h->d_pack, h->d_ipack, h->stream));
-    for (int j = 0; j < l.nd; ++j) {
-      // consecutive slabs that are consecutive at the destination too (sflux, hmixd) go as one transfer
-      int k = j;
-      while (k + 1 < l.nd && dd[k + 1].p == dd[k].p + npts) ++k;
-      const size_t bytes = (size_t)npts * (k - j + 1) * sizeof(double);
-      pin_host(h, dd[j].p, bytes);
-      HIPCHK(hipMemcpyAsync(dd[j].p, h->d_pack + (size_t)npts * j, bytes, hipMemcpyDeviceToHost, h->stream));
-      j = k;
-    }
-    for (int j = 0; j < l.ni; ++j) {
-      pin_host(h, di[j].p, (size_t)npts * sizeof(int));
-      HIPCHK(hipMemcpyAsync(di[j].p, h->d_ipack + (size_t)npts * j, (size_t)npts * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    }
+    // One device block (the double slabs, then the int slabs right behind them) and ONE transfer of it into a pinned
+    // block of the library's own; the caller's arrays - a dozen of them, anywhere - are filled from there by the host
+    // threads.  (A transfer per array costs a round trip each: 1.8 ms of a 4.7 ms drop-in step on a link that has
+    // been idle, r03.)
+    const size_t pack_bytes = (size_t)npts * (MCKPP_CS * sizeof(double) + MCKPP_CI * sizeof(int));
+    if (!h->d_pack) HIPCHK(hipMalloc(&h->d_pack, pack_bytes));
+    if (!h->h_pack) HIPCHK(hipHostMalloc(&h->h_pack, pack_bytes, hipHostMallocDefault));
+    int *d_ipack = reinterpret_cast<int *>(h->d_pack + (size_t)npts * l.nd);
+    HIPCHK(mckpp_launch_pack_records(h->d_cs, h->d_ci, h->d_ipt, ncol, npts, l, h->d_pack, d_ipack, h->stream));
+    const size_t used = (size_t)npts * (l.nd * sizeof(double) + l.ni * sizeof(int));
+    if (used) HIPCHK(hipMemcpyAsync(h->h_pack, h->d_pack, used, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    const double *hd = h->h_pack;
+    const int *hi = reinterpret_cast<const int *>(h->h_pack + (size_t)npts * l.nd);
+    for_columns(npts, [&](int64_t c0, int64_t c1) {
+      for (int j = 0; j < l.nd; ++j) memcpy(dd[j].p + c0, hd + (size_t)npts * j + c0, (size_t)(c1 - c0) * sizeof(double));
+      for (int j = 0; j < l.ni; ++j) memcpy(di[j].p + c0, hi + (size_t)npts * j + c0, (size_t)(c1 - c0) * sizeof(int));
+    });
     return 0;
   }
   if (mask & (MCKPP_F_SAVED | MCKPP_F_SCALARS))

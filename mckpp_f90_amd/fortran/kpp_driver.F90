@@ -10,6 +10,7 @@ program kpp_driver
   use mckpp_parameters
   use mckpp_data_fields
   use mckpp_time_control
+  use mckpp_hip_binding, only: MCKPP_F_SCALARS
   use mckpp_physics_lookup_mod, only: mckpp_physics_lookup
   use mckpp_initialize_ocean, only: mckpp_initialize_ocean_model
   use mckpp_physics_driver_mod, only: mckpp_physics_driver, mckpp_physics_finalize
@@ -17,6 +18,7 @@ program kpp_driver
   use mckpp_physics_verticalmixing_mod, only: mckpp_physics_verticalmixing
   use mckpp_fluxes_mod, only: mckpp_fluxes
   use mckpp_hip_session, only: mckpp_hip_ndevices, mckpp_hip_device_list, mckpp_hip_gather_field, mckpp_hip_sync_host, &
+                               mckpp_hip_output_mask, mckpp_hip_host_behind, &
                                mckpp_hip_all_set_flux_series, mckpp_hip_all_run_forced, mckpp_hip_all_window_select, &
                                mckpp_hip_all_window_reset, mckpp_hip_all_window_accumulate, mckpp_hip_all_window_fetch
   implicit none
@@ -40,7 +42,10 @@ program kpp_driver
   !        8 hmix and T also through the output gather (appended); 16 the time loop as ONE forced run from flux
   !        records resident on the devices (constant forcing, the records mckpp_fluxes would assemble each step);
   !        32 the same step by step with an output window: mean hmix and maximum T of the run (appended)
+  !        64 opt into the reduced per-step download (scalar group only) + mckpp_hip_sync_host before the output;
+  !           without it every call of mckpp_physics_driver leaves all of kpp_3d_fields current, as the reference does
   flags = hdr(6)
+  if (iand(flags, 64) /= 0) mckpp_hip_output_mask = MCKPP_F_SCALARS
   ! hdr(7) > 0: that many device shards; hdr(8) = 1 puts them all on HIP device 0 (one-GPU rehearsal of the
   ! multi-device path), otherwise devices 0 .. hdr(7)-1
   if (hdr(7) > 0) then
@@ -117,7 +122,11 @@ program kpp_driver
   write (*, '(a,3es14.6)') 'kpp_driver: hmix min/mean/max ', minval(kpp_3d_fields%hmix, kpp_3d_fields%run_physics), &
         sum(kpp_3d_fields%hmix)/max(1, count(kpp_3d_fields%run_physics)), maxval(kpp_3d_fields%hmix)
 
-  call mckpp_hip_sync_host()   ! the per-step download brings the scalar group only
+  if (iand(flags, 64 + 48) == 0 .and. mckpp_hip_host_behind() /= 0) then   ! the default mask: nothing may be stale
+    write (0, '(a,i0)') 'kpp_driver: kpp_3d_fields is behind the device after mckpp_physics_driver: ', mckpp_hip_host_behind()
+    error stop 2
+  end if
+  call mckpp_hip_sync_host()   ! what a reduced per-step download or the forced run left on the devices
   open (newunit=u, file=trim(fout), access='stream', form='unformatted', status='replace')
   write (u) kpp_3d_fields%U, kpp_3d_fields%X, kpp_3d_fields%Us, kpp_3d_fields%Xs
   write (u) kpp_3d_fields%hmix, kpp_3d_fields%kmix, kpp_3d_fields%hmixd, kpp_3d_fields%Tref, kpp_3d_fields%Ssurf

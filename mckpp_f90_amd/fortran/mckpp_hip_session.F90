@@ -18,6 +18,7 @@ module mckpp_hip_session
   public :: mckpp_hip_all_set_flux_series, mckpp_hip_all_run_forced, mckpp_hip_all_window_select
   public :: mckpp_hip_all_window_reset, mckpp_hip_all_window_accumulate, mckpp_hip_all_window_fetch
   public :: mckpp_hip_all_save_restart, mckpp_hip_all_load_restart, mckpp_hip_sync_host, mckpp_hip_device_advanced
+  public :: mckpp_hip_host_behind
 
   !> All devices of the run behind one handle (include/mckpp_hip.h, mckpp_hip_multi_*): the columns of
   !! kpp_3d_fields are dealt round-robin over mckpp_hip_ndevices GPUs, HIP devices mckpp_hip_device,
@@ -30,13 +31,16 @@ module mckpp_hip_session
   integer(c_int), save :: mckpp_hip_ndevices = 1
   integer(c_int32_t), allocatable, save :: mckpp_hip_device_list(:)
   type(c_ptr), save :: mckpp_hip_handle = c_null_ptr
-  !> Field groups mckpp_physics_driver copies back into kpp_3d_fields after every call.  Default: the scalar group
-  !! (hmix, kmix, Tref, uref, vref, Ssurf, flags, sflux) - 192 bytes per column.  The reference leaves ALL of
-  !! kpp_3d_fields current after every call (src/mckpp_types_transfer.F90:199-327); a host that reads profiles or
-  !! diagnostics between steps sets this to MCKPP_F_ALL (48 ms per step at 1e5 x 60 against 3.4 ms for the step
-  !! itself), or - cheaper - calls mckpp_hip_sync_host(groups) at its output steps, or fetches reduced output
-  !! fields (mckpp_hip_all_window_fetch).  mckpp_physics_finalize brings everything back before it detaches.
-  integer(c_int), save :: mckpp_hip_output_mask = MCKPP_F_SCALARS
+  !> Field groups mckpp_physics_driver copies back into kpp_3d_fields after every call.  Default MCKPP_F_ALL: the
+  !! reference leaves ALL of kpp_3d_fields current after every call (src/mckpp_types_transfer.F90:199-327), and its
+  !! time loop reads profiles and diagnostics from it every step (mckpp_output_control / mckpp_restart_control,
+  !! src/mckpp_ocean_model_3D.F90:59-66; src/mckpp_xios_io.F90:86-137,413-431), so a drop-in host gets exactly that.
+  !! OPT-IN, for a host that knows when it reads what: MCKPP_F_SCALARS keeps the per-step download to the scalar
+  !! group (hmix, kmix, Tref, uref, vref, Ssurf, flags: 192 bytes per column) and leaves the rest on the device
+  !! until mckpp_hip_sync_host([groups]) is called at an output / restart step (or reduced output fields are fetched
+  !! with mckpp_hip_all_window_fetch); mckpp_hip_host_behind() tells which groups of kpp_3d_fields are stale.
+  !! mckpp_physics_finalize brings everything back before it detaches.
+  integer(c_int), save :: mckpp_hip_output_mask = MCKPP_F_ALL
   integer(c_int), save :: mckpp_hip_device = 0
   logical, save :: resident = .false.
   !> field groups of kpp_3d_fields that are older than the device state (a step ran and did not bring them back)
@@ -194,6 +198,12 @@ contains
   subroutine mckpp_hip_device_advanced()
     host_behind = MCKPP_F_ALL
   end subroutine mckpp_hip_device_advanced
+
+  !> Field groups (MCKPP_F_* bits) of kpp_3d_fields that are older than the device state: 0 with the default
+  !! output mask; with a reduced mask, what an output or restart writer must mckpp_hip_sync_host first.
+  integer(c_int) function mckpp_hip_host_behind()
+    mckpp_hip_host_behind = host_behind
+  end function mckpp_hip_host_behind
 
   !> Output gather without a full download: field 0 U, 1 V, 2 T, 3 S -> out(npts,nzp1), 4 hmix -> out(npts);
   !! the shards' rows travel over the GPU interconnect to device `root` (0-based shard index) and cross

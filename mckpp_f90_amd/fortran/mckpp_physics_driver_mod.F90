@@ -3,8 +3,9 @@
 !! (src/mckpp_physics_driver_mod.F90:15-73).  The OpenMP column loop with its
 !! per-column 3D<->1D copies is replaced by one kernel launch per GPU over its
 !! share of the run_physics columns (mckpp_hip_session: mckpp_hip_ndevices); state stays in HBM between calls and only the field
-!! groups in mckpp_hip_output_mask come back each step (default: the scalar group; mckpp_hip_sync_host brings the
-!! rest back when the host wants to read it, mckpp_physics_finalize does so before it lets the devices go).
+!! groups in mckpp_hip_output_mask come back each step (default: all of them, the reference's contract; a host may
+!! opt into the scalar group alone and call mckpp_hip_sync_host when it wants to read the rest;
+!! mckpp_physics_finalize brings everything back before it lets the devices go).
 module mckpp_physics_driver_mod
   use iso_c_binding, only: c_int
   use mckpp_data_fields, only: kpp_3d_fields, kpp_const_fields

@@ -32,7 +32,7 @@ def test_column_kernel_fits_its_register_budget():
         elif name is not None:
             kernels[name][key] = int(val)
     variants = {n: k for n, k in kernels.items() if "k_column_ps" in n}
-    assert len(variants) == 3, f"expected the three variants of k_column_ps, found {sorted(kernels)}"
+    assert len(variants) == 6, f"expected the six variants of k_column_ps (3 physics x 2 solver modes), found {sorted(kernels)}"
     for n, k in variants.items():
         assert k["vgpr_spill_count"] == 0, f"{n}: {k['vgpr_spill_count']} VGPRs spilled to scratch"
         assert k["private_segment_fixed_size"] == 0, f"{n}: uses {k['private_segment_fixed_size']} B of scratch per lane"
@@ -73,3 +73,31 @@ def test_no_instruction_touches_a_register_with_an_lds_read_in_flight():
 """
     found = check_inflight.check(probe)
     assert [f[1] for f in found] == [7], found
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_library_build_runs_the_gate_and_records_its_compiler(built):
+    """`make` links the library only behind tools/check_build.py (both checks above on the very assembly of the build),
+    and the library says which compiler that was."""
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    assert "$(OUT): mckpp_kernels.o mckpp_kernels_ps.o mckpp_runtime.o .kernel_checked" in mk
+    assert os.path.exists(os.path.join(CSRC, ".kernel_checked")), "the in-tree library was linked without the build gate"
+    from mckpp_f90_amd import api
+
+    assert "-unchecked" not in api.build_id()
+    assert "version" in api.build_compiler().lower()
+    # the gate itself: a spilled register fails the product build, an in-flight copy fails any build
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_build
+
+    ok = "_ZN1k_column_psILi0ELi0EE:\n\ts_endpgm\n.Lfunc_end0:\n    .name: k_column_ps0\n    .vgpr_count: 120\n    .vgpr_spill_count: 0\n    .private_segment_fixed_size: 0\n"
+    tmp = os.path.join(ROOT, "gpurun_out", "_gate_probe.s")
+    os.makedirs(os.path.dirname(tmp), exist_ok=True)
+    open(tmp, "w").write(ok)
+    assert check_build.main(["check_build", tmp]) == 0
+    open(tmp, "w").write(ok.replace("vgpr_spill_count: 0", "vgpr_spill_count: 3"))
+    assert check_build.main(["check_build", tmp]) == 1
+    assert check_build.main(["check_build", tmp, "--budget-warn-only"]) == 0
+    os.remove(tmp)

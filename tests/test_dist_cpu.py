@@ -92,7 +92,7 @@ def test_bench_starts_its_own_ranks_without_touching_the_gpu():
     assert plan["torch_imported"] is False and plan["library_loaded"] is False
     cmd = plan["cmd"]
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
+    assert "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
     # a real launch here (no GPU): both ranks say so, the parent hands the failure on
     r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--no-cpu-baseline"], capture_output=True,
                        text=True, env=env, timeout=300)

@@ -66,13 +66,17 @@ def test_fortran_layer_builds_and_fails_loudly_without_gpu(built, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ncol,nz,nsteps,use_1d,land", [(500, 60, 3, 0, 0), (96, 40, 2, 0, 4), (12, 40, 2, 1, 5)])
-def test_fortran_driver_matches_cabi_path(built, tmp_path, ncol, nz, nsteps, use_1d, land):
+@pytest.mark.parametrize("ncol,nz,nsteps,use_1d,land,flags", [(500, 60, 3, 0, 0, 0), (96, 40, 2, 0, 4, 0), (12, 40, 2, 1, 5, 0),
+                                                              (96, 40, 2, 0, 4, 64)])
+def test_fortran_driver_matches_cabi_path(built, tmp_path, ncol, nz, nsteps, use_1d, land, flags):
+    """flags 0: the session's default - every mckpp_physics_driver call leaves ALL of kpp_3d_fields current (the
+    reference's contract, src/mckpp_types_transfer.F90:199-327; kpp_driver stops if anything is stale); flags 64:
+    the opt-in scalar-group download with mckpp_hip_sync_host before the output."""
     import mckpp_f90_amd as mk
 
     kc, k3 = cm.make_hip_case(ncol, nz, land_every=land)
     sf = cm.synth.forcing(ncol, "bench")
-    _write_case(tmp_path / "case.bin", kc, k3, sf, nsteps, use_1d)
+    _write_case(tmp_path / "case.bin", kc, k3, sf, nsteps, use_1d, flags=flags)
     r = subprocess.run([DRIVER, str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr + r.stdout
     got = _read_out(tmp_path / "out.bin", kc, ncol)
@@ -171,13 +175,13 @@ def test_fortran_driver_on_several_device_shards(built, tmp_path, ncol, nz, shar
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flags,shards,nz", [(16, 0, 40), (16, 3, 60), (32, 2, 69)])
+@pytest.mark.parametrize("flags,shards,nz", [(16, 0, 40), (16, 3, 60), (32, 2, 69), (32 + 64, 2, 60)])
 def test_fortran_forced_run_and_output_windows_on_all_devices(built, tmp_path, flags, shards, nz):
     """kpp_driver with its time loop on the devices: mckpp_hip_all_set_flux_series + mckpp_hip_all_run_forced
     (the reference's loop, src/mckpp_ocean_model_3D.F90:38-58, one call for all steps and all shards), and - flag
     32 - step by step with an output window on every shard (mean hmix, maximum T fetched through the gather).
-    The per-step download is the scalar group only (the session's default); mckpp_hip_sync_host brings the rest
-    back before the driver writes its output.  Against mckpp_fluxes + mckpp_physics_driver per step on the C-ABI."""
+    The forced run leaves everything on the devices and mckpp_hip_sync_host brings it back before the driver
+    writes its output; flag 64 is the session's opt-in to a scalar-group-only per-step download.  Against mckpp_fluxes + mckpp_physics_driver per step on the C-ABI."""
     import mckpp_f90_amd as mk
 
     ncol, nsteps = 211, 4
