@@ -2,7 +2,7 @@
 # LIBS="S", MODES="0 1", CFGS entries <levels>[:<geometry>], BENCH_ARGS.
 cd $GRAFT_REPO_ROOT
 for v in ${LIBS:-S}; do
-  B="python bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 2 $BENCH_ARGS"
+  B="python bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 2 --settle 0 $BENCH_ARGS"
   for sm in ${MODES:-0 1}; do
     for cfg in ${CFGS:-60}; do
       IFS=: read nz g <<< "$cfg"
