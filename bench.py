@@ -336,7 +336,7 @@ def config1_pass(mk, cm, dev_index, a, ncol=10000, nz=60, launches=200):
     return out
 
 
-def committed_counters(ncol, nz, kernel_name, build_id):
+def committed_counters(ncol, nz, kernel_name, build_id, solver_mode=0):
     """PMC-derived figures committed under profiles/ (HBM traffic per launch, VALU instruction counts).
     They describe one kernel build: returned only when recorded for the loaded library's build id and
     this workload, otherwise None with the reason."""
@@ -351,7 +351,8 @@ def committed_counters(ncol, nz, kernel_name, build_id):
         return None, None, (f"profiles/counters.json was recorded for build {cj.get('build_id')}, the loaded "
                             f"library is build {build_id}: not reported")
     for rec in cj.get("workloads", []):
-        if rec.get("ncol") == ncol and rec.get("nz") == nz and rec.get("kernel") == kernel_name:
+        if (rec.get("ncol") == ncol and rec.get("nz") == nz and rec.get("kernel") == kernel_name
+                and rec.get("solver_mode", 0) == solver_mode and "shape" not in rec):
             issue = None
             if "SQ_INSTS_VALU" in rec:
                 passes = rec.get("passes_per_column", 6.0)
@@ -626,7 +627,7 @@ def main():
         balg = alg_bytes_per_column_step(nz, a.diag)
         achieved = balg * nocean / kern_s / 1e9
         build = mkapi.build_id()
-        traffic, issue, why_not = committed_counters(ncol, nz, ctx.kernel_name, build)
+        traffic, issue, why_not = committed_counters(ncol, nz, ctx.kernel_name, build, ctx.solver_mode)
         out = {
             "metric": "column-steps/s at 1e5 cols x 60 levels, 1/2/4/8 GPU; % HBM roofline",
             "value": ncols_all * a.steps / dt,

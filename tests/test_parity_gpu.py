@@ -137,46 +137,82 @@ def test_short_timestep_bitexact(mk):
         _assert_bitexact(res, f"dto=1200 {tag}")
 
 
-def test_tolerance_vs_faithful_oracle(mk):
-    """<= 1e-10 relative error on hmix and the T/S/U/V profiles against the oracle run with libm
-    exp (the reference's EXP) - the north-star tolerance.  Columns whose discrete path differs (kmix
-    flips because hbl sits within an ulp of a level boundary) are counted, reported and bounded too:
-    kmix may move by one level, hmix by less than one layer thickness, the profiles stay within 1e-6."""
+def _diurnal_both(mk, ncol, nz, nsteps, grid, dto, orc_kw, hip_solver_mode=None, every=None):
+    """The HIP path and an oracle variant side by side through `nsteps` model steps of the diurnal forcing cycle
+    (mckpp_fluxes before every step on both sides); yields (step, k3, ob, same_path) at the steps in `every`."""
+    from oracle import orc
+
+    oc, ob = cm.make_oracle(ncol, nz, init=False, grid=grid, dto=dto, **orc_kw)
+    kc, k3 = cm.make_hip_case(ncol, nz, grid=grid, dto=dto)
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    if hip_solver_mode is not None:   # (otherwise both sides follow MCKPP_SOLVER_MODE)
+        ctx.set_solver_mode(hip_solver_mode)
+    orc.init_ocean(oc, ob, 0)
+    same = np.ones(ncol, bool)
+    names = cm.synth.FLUX_NAMES
+    for nt in range(1, nsteps + 1):
+        ser = cm.synth.flux_series(ncol, nt, 1, dto, "bench")[0]
+        orc.fluxes(oc, ob, nt, **dict(zip(names, ser)))
+        orc.physics_driver(oc, ob, nt)
+        ctx.fluxes(nt, *ser)
+        mk.mckpp_physics_driver(k3, kc, nt, new_forcing=False)
+        st, nf, npass = ctx.status()
+        same &= (np.asarray(k3.kmix) == ob["kmix"]) & (npass == ob["npasses"])
+        if every is None or nt in every:
+            yield nt, k3, ob, same.copy()
+    ctx.close()
+
+
+@pytest.mark.parametrize("nz,grid,dto,ncol,nsteps", [(40, "uniform", 3600.0, 3000, 24), (60, "uniform", 3600.0, 6000, 48),
+                                                     (100, "uniform", 3600.0, 1500, 24), (69, "stretched", 1200.0, 3000, 72)])
+def test_tolerance_vs_faithful_oracle(mk, nz, grid, dto, ncol, nsteps):
+    """The north-star tolerance against the reference's arithmetic: the oracle with libm exp (the reference's EXP;
+    the device carries a portable exp of its own), on every BASELINE depth and grid, through 24-72 steps of the
+    diurnal cycle.  What the data supports (profiles/r04/parity_tolerance.json: 1e5 columns x 72 steps, 4000 x 240,
+    250 x 1000, this test's shapes on the CPU): on the columns that have taken the same discrete path - same kmix,
+    same pass count at every step so far - hmix, T, S, U, V agree to <= 1e-10 (max; 99.9 % of them to <= 1e-11), and
+    no column leaves that path within these step counts.  A column that does leave it (first seen after ~700 steps
+    at 100 levels) differs by what the iteration's own stopping tolerance allows - hmixtolfrac of a layer,
+    ocnstep_mod.F90:157-170 - not by rounding; the long runs are in the table, the bound for such columns here is
+    that tolerance."""
     import json
 
-    ncol, nz = 6000, 60
-    out, k3, ob, kc, oc = _run_both(mk, ncol, nz, 3, exp_mode=0)
-    kdiff = np.asarray(k3.kmix) - ob["kmix"]
-    flipped = kdiff != 0
-    flips = int(flipped.sum())
-    same = ~flipped
-    rel, rel_flipped = {}, {}
-    for name in ("T", "S", "U", "V"):
-        h, lo, n = cm.hip_field(k3, name, nz)
-        o = ob.a[name][:, lo:lo + n]
-        scale = np.maximum(np.abs(o).max(axis=1, keepdims=True), 1e-30)   # profile-relative error
-        e = np.abs(h - o) / scale
-        rel[name] = float(e[same].max())
-        rel_flipped[name] = float(e[flipped].max()) if flips else 0.0
-    eh = np.abs(k3.hmix - ob["hmix"])
-    rel["hmix"] = float((eh / np.abs(ob["hmix"]))[same].max())
-    report = {"columns": ncol, "levels": nz, "steps": 3, "kmix_flips": flips, "max_rel_err_same_path": rel,
-              "max_rel_err_flipped": rel_flipped,
-              "max_abs_hmix_err_flipped_m": float(eh[flipped].max()) if flips else 0.0}
-    print("tolerance vs libm-exp oracle:", json.dumps(report))
+    report = []
+    for nt, k3, ob, same in _diurnal_both(mk, ncol, nz, nsteps, grid, dto, {"exp_mode": 0}, every=(1, 3, 24, 48, 72)):
+        m = cm.tolerance_metrics(cm.hip_state(k3, nz), cm.oracle_state(ob, nz), same)
+        m["step"] = nt
+        report.append(m)
+        for name, v in m["same_path"].items():
+            assert v["max"] <= 1e-10, (nt, name, v)
+            assert v["p999"] <= 1e-11, (nt, name, v)
+        off = m["off_path_columns"]
+        assert off <= 0.001 * ncol, f"step {nt}: {off} columns on another discrete path"
+        if off:
+            zm, hm, dm = cm.grid_for(nz, grid)
+            assert m["off_path"]["max_abs_kmix_difference"] <= 1
+            assert m["off_path"]["max_abs_hmix_difference_m"] <= hm[1:nz + 1].max()
+    print("tolerance vs libm-exp oracle:", json.dumps(report[-1]))
     try:
         os.makedirs(os.path.join(cm.ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(cm.ROOT, "gpurun_out", "parity_tolerance.json"), "w") as f:
-            json.dump(report, f)
+        with open(os.path.join(cm.ROOT, "gpurun_out", f"parity_tolerance_gpu_nz{nz}_{grid}.json"), "w") as f:
+            json.dump({"columns": ncol, "levels": nz, "grid": grid, "dto": dto, "rows": report}, f)
     except OSError:
         pass
-    assert all(v <= 1e-10 for v in rel.values()), rel
-    assert flips <= 0.002 * ncol, f"{flips} columns took a different kmix"
-    if flips:
-        hm = 200.0 / nz
-        assert np.abs(kdiff[flipped]).max() <= 1, kdiff[flipped]
-        assert eh[flipped].max() < hm, eh[flipped].max()
-        assert all(v <= 1e-6 for v in rel_flipped.values()), rel_flipped
+
+
+@pytest.mark.parametrize("nz,grid,dto,ncol,nsteps", [(60, "uniform", 3600.0, 4000, 24), (69, "stretched", 1200.0, 2000, 24)])
+def test_two_ended_solver_within_rounding_of_the_reference_order(mk, nz, grid, dto, ncol, nsteps):
+    """Solver mode 1 on the device against the oracle in the REFERENCE's order of operations (solver_mode=0): the
+    opt-in mode changes the rounding of the implicit solves, nothing else - same kmix and pass counts, profiles and
+    hmix within 1e-12 after a model day (1e5 x 72 on the CPU: <= 1.3e-14, profiles/r04/parity_tolerance.json)."""
+    for nt, k3, ob, same in _diurnal_both(mk, ncol, nz, nsteps, grid, dto, {"exp_mode": 1, "solver_mode": 0},
+                                          hip_solver_mode=1, every=(1, nsteps)):
+        m = cm.tolerance_metrics(cm.hip_state(k3, nz), cm.oracle_state(ob, nz), same)
+        assert m["off_path_columns"] == 0, (nt, m)
+        for name, v in m["same_path"].items():
+            assert v["max"] <= 1e-12, (nt, name, v)
+        if nt == nsteps:   # and it IS another order of operations: some bits differ
+            assert any(v["max"] > 0 for v in m["same_path"].values())
 
 
 def test_config2_kppmix_tridiag_pass_bitexact(mk):
@@ -557,7 +593,8 @@ def test_config5_terramaris_shape_land_masked(mk):
 
 def test_config4_100_levels_slice(mk):
     """BASELINE configs[3] per-GPU slice (1e5 x 100 over 8 GPUs = 12,500 columns x 100 levels per
-    GPU), several steps: two levels per lane (LPL=2) path, sample checked against the oracle."""
+    GPU), several steps: a 16-wave workgroup of 19 slots, two trips of the item loop; sample checked against the
+    oracle."""
     from oracle import orc
 
     ncol, nz, nsteps = 12500, 100, 3

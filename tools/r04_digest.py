@@ -1,0 +1,34 @@
+"""One screen of a bench.py line: python tools/r04_digest.py bench.json"""
+import json
+import sys
+
+d = json.load(open(sys.argv[1]))
+r = d["roofline"]
+print(f"value {d['value']:.4g} {d['unit']}  {d['ms_per_step']:.3f} ms/step  ({d['n_gpus']} GPU, {d['steps']} steps, solver: {d['config'].get('solver', '?')[:40]})")
+print(f"  roofline frac {r['frac']:.4f} = {r['achieved']:.0f} GB/s of {r['peak']:.0f}; kernel {r['kernel_avg_ms']:.3f} ms; traffic {r.get('traffic')}")
+if "burst" in d:
+    print(f"  burst (cold device): {d['burst']['value_this_rank']:.4g}, {d['burst']['ms_per_step']:.3f} ms/step")
+print(f"  column passes/s {d.get('column_passes_per_s', 0):.4g}; passes mean {d['config']['mean_passes_per_column_step_last_step']:.3f} max {d['config']['max_passes_last_step']}")
+for k in ("two_ended_solver", "sustained"):
+    if k in d:
+        print(f"  {k}: {d[k]['value']:.4g}, {d[k]['ms_per_step']:.3f} ms/step" + (f", x{d[k]['config']['ratio_to_value']:.3f} of value" if k == "two_ended_solver" else ""))
+if "tail" in d:
+    t = d["tail"]
+    print(f"  tail: {t['value']:.4g} column-steps/s, {t['column_passes_per_s']:.4g} column-passes/s; per step (ms, mean, max passes, trap): "
+          + "; ".join(f"{p['ms']:.2f} {p['mean_passes']:.2f} {p['max_passes']} {p['trap_fired']}" for p in t["per_step"]))
+if "config1_pass" in d:
+    c = d["config1_pass"]
+    print(f"  configs[1]: {c['value']:.4g} column-passes/s, kernel {c['kernel_avg_ms']:.4f} ms, roofline frac {c['roofline']['frac']:.4f}")
+if "drop_in" in d:
+    di = d["drop_in"]
+    print("  drop-in ms/step: " + ", ".join(f"{k} {v['ms_per_step']:.2f}" for k, v in di.items() if isinstance(v, dict)))
+for o in d.get("other_shapes", []):
+    print(f"  {o['workload'][:70]}: {o['value']:.4g}, frac {o['roofline_frac']:.4f}, passes {o['mean_passes_per_column_step_last_step']:.2f}")
+if "strong_scaling_proxy" in d:
+    sp = d["strong_scaling_proxy"]
+    print(f"  strong-scaling proxy: nz100 {sp['nz100']['ratio_to_1e5']:.3f}, nz60 {sp['nz60']['ratio_to_1e5']:.3f}")
+if "diurnal" in d:
+    print(f"  diurnal: {d['diurnal']['value']:.4g}; cpu port {d['diurnal'].get('cpu_port', {}).get('value', 0):.4g}")
+if "cpu_baseline" in d:
+    c = d["cpu_baseline"]
+    print(f"  cpu_baseline: {c['value']:.4g} on {c['cores']} cores ({c['kind']}); 1 thread {c.get('value_1thread', 0):.4g}")
