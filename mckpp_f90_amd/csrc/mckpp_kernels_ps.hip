@@ -36,7 +36,9 @@ enum {
   C_F, C_HMIXE, C_HMIXN, C_HBL, C_RHBL, C_STABLE, C_BFSFC, C_CASEA,
   C_GAT1, C_DAT1 = C_GAT1 + 3, C_DKM1 = C_DAT1 + 3,
   C_SREF = C_DKM1 + 3, C_SSURF, C_OCDEPTH, C_SFLUX1, C_SFLUX2, C_SFLUX3, C_SFLUX4, C_SFLUX5, C_SFLUX6,
-  C_T1X /* + parity: the level-1 temperature of the iterate, for the two EOS items */, C_COUNT = C_T1X + 2
+  C_T1X /* + parity: the level-1 temperature of the iterate, for the two EOS items */,
+  C_JRFAC = C_T1X + 2, C_JA1, C_JA2, C_JRA1, C_JRA2 /* the column's Jerlov constants (swfrac_mod.F90:59-61), fetched once per column */,
+  C_COUNT
 };
 // per-slot int record
 enum {
@@ -76,19 +78,60 @@ enum { Q_DM = 0, Q_DT, Q_DS, Q_YU, Q_YT, Q_YS, Q_YV, Q_GM, Q_BET, Q_COUNT,
 enum { K_ZM = 0, K_HM, K_T0, K_T1, K_RDZ, K_DTOHK, K_STRIDE = 7 };
 __host__ __device__ inline int ps_rows(int xv) { return xv == 2 ? (int)Q_COUNT_EXT_DD : xv == 1 ? (int)Q_COUNT_EXT : (int)Q_COUNT; }
 __host__ __device__ inline int ps_nl(int L) { return L; }   // level indices 0..nzp1+1 (L = nzp1+2 items per column)
-__host__ __device__ inline int ps_ss(int L, int xv)
+// Slot stride (doubles) of a workgroup of W slots.  LDS has 64 banks of 4 bytes; an 8-byte access of a wave goes
+// through in two halves of 32 lanes, each conflict-free if its lanes' double-word addresses differ mod 32.  The
+// level-major phases (L2..L5) take the items in the order (level, slot) - consecutive lanes are consecutive slots
+// of one level, then the next level - so lane j of a half-wave sits at slot*SS + level*ROWS: an arithmetic
+// progression mod 32 exactly when W*SS = ROWS (mod 32), and then - SS odd - a permutation of the 32 residues: no
+// conflict at all.  (Round 3 had SS = ROWS*L rounded up to odd: at 69 levels SS = ROWS = 9 mod 32, every lane of a
+// level conflicting with its neighbour slot of the next - 0.59 of the LDS-active cycles were bank conflicts, 0.22 at
+// 60 levels.)  Of the 32 paddings the one with the fewest conflicts of that pattern is taken, then of the manager
+// lanes' pattern (slot*SS + row of the system), then the smallest; at most 31 doubles per slot.
+// MEASURED (r04, profiles/r04/experiments/slot_stride.txt): the conflict-free stride changes the rate by -1.7 ... +0.5 %
+// (60, 69, 100 levels, both solver modes; the shipped-namelist shape within noise): bank conflicts are not what
+// these phases wait for.  So the default stays round 3's rule - rows*L rounded up to odd, not +-1 mod 32 (the manager
+// lanes' pattern) - and MCKPP_PS_CONFLICT_FREE=1 selects the stride below (the counters of both are on record).
+__host__ inline int ps_ss(int L, int xv, int W)
 {
-  // lane (slot s, system m) of the serial sweeps touches s*SS + i*ROWS + m: an odd SS that is not +-1 (mod 32
-  // doubles) spreads the 3W lanes over the banks about evenly (LDS is the scarce resource here: no more padding)
-  int s = ps_rows(xv) * ps_nl(L);
-  if (!(s & 1)) ++s;
-  while ((s & 31) == 1 || (s & 31) == 31) s += 2;
-  return s;
+  const int rows = ps_rows(xv), s0 = rows * ps_nl(L);
+  static const bool conflict_free = getenv("MCKPP_PS_CONFLICT_FREE") != nullptr && atoi(getenv("MCKPP_PS_CONFLICT_FREE")) != 0;
+  if (!conflict_free) {
+    int s = s0;
+    if (!(s & 1)) ++s;
+    while ((s & 31) == 1 || (s & 31) == 31) s += 2;
+    return s;
+  }
+  if (W <= 1) return s0 | 1;
+  int best = s0, best_cost = 1 << 30;
+  for (int pad = 0; pad < 32; ++pad) {
+    const int ss = s0 + pad;
+    int lm = 0;   // level-major: the worst multiplicity of a residue in a half-wave, summed over its alignments
+    for (int start = 0; start < W * 8; start += 8) {
+      int cnt[32] = {0}, worst = 0;
+      for (int j = start; j < start + 32; ++j) {
+        const int b = ((j % W) * ss + (j / W) * rows) & 31;
+        if (++cnt[b] > worst) worst = cnt[b];
+      }
+      lm += worst;
+    }
+    int mg = 0;   // manager lanes (slot, system) of the sweeps: solution rows Q_YU + system
+    for (int half = 0; half < 2; ++half) {
+      int cnt[32] = {0}, worst = 0;
+      for (int l = 32 * half; l < 32 * half + 32 && l < 3 * W; ++l) {
+        const int b = ((l / 3) * ss + (int)Q_YU + l % 3) & 31;
+        if (++cnt[b] > worst) worst = cnt[b];
+      }
+      mg += worst;
+    }
+    const int cost = lm * 64 + mg * 8 * W + pad;   // (lm is a sum over W alignments)
+    if (cost < best_cost) { best_cost = cost; best = ss; }
+  }
+  return best;
 }
 __host__ __device__ inline int ps_scratch_ld(int nzp1) { return (nzp1 + 7) & ~7; }   // row length of the iterate's scratch
-__host__ __device__ inline size_t ps_lds_bytes(int L, int W, int xv)
+__host__ inline size_t ps_lds_bytes(int L, int W, int xv)
 {
-  return (size_t)(K_STRIDE * ps_nl(L) + 2 + W * ps_ss(L, xv) + W * C_COUNT) * sizeof(double) +
+  return (size_t)(K_STRIDE * ps_nl(L) + 2 + W * ps_ss(L, xv, W) + W * C_COUNT) * sizeof(double) +
          (size_t)(W * I_COUNT + 8) * sizeof(int);
 }
 
@@ -125,10 +168,6 @@ __device__ __forceinline__ ps_d2 ps_lds_read2(unsigned addr)
 }
 template <int N> __device__ __forceinline__ void ps_lds_wait(ps_d2 &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
 template <int N> __device__ __forceinline__ void ps_lds_wait(ps_d2 &a, ps_d2 &b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
-template <int N> __device__ __forceinline__ void ps_lds_wait1(ps_d2 &a, double &b, ps_d2 &c, double &d)
-{
-  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
-}
 template <int N> __device__ __forceinline__ void ps_lds_wait(ps_d2 &a, ps_d2 &b, ps_d2 &c, ps_d2 &d)
 {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
@@ -438,24 +477,12 @@ __device__ __forceinline__ void ps_thomas_uts_back(int W, double *slots, int SS,
   }
 }
 
-// 1/d correctly rounded (IEEE 1.0 / d) for any d div_fast may see: div_fast(1.0, d, rcp_refine(d)) with the
-// product 1.0 * r folded
-__device__ __forceinline__ double ps_recip(double d)
-{
-  const double r = rcp_refine(d);
-  const double e = __builtin_fma(-d, r, 1.0);
-  const double res = __builtin_fma(e, r, r);
-  return __builtin_amdgcn_div_fixup(res, d, 1.0);
-}
-
 // ---- solver mode 1 (opt-in, mckpp_hip_set_solver_mode; NOT the reference's operation order - the oracle's
 // orc_tridmat_2e restates it operation for operation): the same systems eliminated from both ends at once.  DIR = +1:
 // the levels 1..m, m = nz/2, downward as above; DIR = -1: the levels nz..m+1 upward by the mirrored recurrence
-//   g(i+1) = cu(i+1) r(i+1) = -q(i+1) r,  bet(i) = cc(i) - cl(i) g(i+1) = cc(i) + p(i) g(i+1),
-//   z(i) = (rhs(i) - cl(i) z(i+1)) r(i) = (rhs(i) + p(i) z(i+1)) r(i),   r(i) = 1/bet(i) correctly rounded,
-// on another wave; each is a chain of nz/2 steps, and a step divides once - both quotients of tridmat's step are
-// products with the pivot's reciprocal (so no operand needs other arithmetic: no guards, no second path).  The
-// upper half leaves z(1..m-1) in the solution row, z(m) at its
+//   g(i+1) = cu(i+1)/bet(i+1) = -q(i+1)/bet,  bet(i) = cc(i) - cl(i) g(i+1) = cc(i) + p(i) g(i+1),
+//   z(i) = (rhs(i) - cl(i) z(i+1))/bet(i) = (rhs(i) + p(i) z(i+1))/bet(i)
+// on another wave; each is a chain of nz/2 steps.  The upper half leaves z(1..m-1) in the solution row, z(m) at its
 // index 0, gam(2..m) in the gam row and gam(m+1) at its index 0; the lower half z(m+2..nz), z(m+1) at index nz+2 of
 // the solution row, g(m+2..nz) and g(m+1) at index 1 of the gam row (those entries of the rows are free by now:
 // nothing there for the other half's reads to race with).
@@ -479,14 +506,15 @@ __device__ __forceinline__ void ps_thomas2_uts_fwd(int W, double *slots, int SS,
       // carry: p(i-1) on the way down (cl(i-1) = -p(i-1)), q(i+1) on the way up (cu(i+1) = -q(i+1))
       double carry = DIR > 0 ? pb[(1) * KS] : qq[(nz) * KS];
       double bet = DIR > 0 ? 1. + carry : (1. + pb[(nz) * KS]) + carry;   // cc(1) | cc(nz)
+      if (DIR < 0 && bet == 0.) { bad = 1; bet = 1.E-12; }   // (cc(nz) is a pivot tridmat checks; cc(1) it does not)
       double ynum = y[(i0) * KS];
-      auto level = [&](int i, double p, double q, double rhs) {
-        if (bet == 0.) { bad = 1; bet = 1.E-12; }
+      auto level = [&](int i, double p, double q, double rhs, auto slow) {
+        if (slow.value && bet == 0.) { bad = 1; bet = 1.E-12; }
         const double cm1 = -carry;
         const double cc = (1. + p) + q;
-        const double r = ps_recip(bet);
-        const double g = cm1 * r;
-        const double yprev = ynum * r;
+        const double rb = rcp_refine(bet);
+        const double g = slow.value ? div_by_refined(cm1, bet, rb) : div_fast(cm1, bet, rb);
+        const double yprev = slow.value ? div_by_refined(ynum, bet, rb) : div_fast(ynum, bet, rb);
         y[(i - DIR) * KS] = yprev;
         gm[(DIR > 0 ? i : i + 1) * KS] = g;
         const double mult = DIR > 0 ? q : p;
@@ -494,23 +522,35 @@ __device__ __forceinline__ void ps_thomas2_uts_fwd(int W, double *slots, int SS,
         ynum = rhs + mult * yprev;
         carry = DIR > 0 ? p : q;
       };
+      bool f_in = tiny_nonzero(ynum);
       {   // two levels per trip; each half's operands are fetched while the other half runs
         int i = i0 + DIR, left = (DIR > 0 ? m : nz - m) - 1;
         double a_p = 0., a_q = 0., a_r = 0.;
         if (left > 0) { a_p = pb[(i) * KS]; a_q = qq[(i) * KS]; a_r = y[(i) * KS]; }
         for (; left >= 2; left -= 2, i += 2 * DIR) {
           const double b_p = pb[(i + DIR) * KS], b_q = qq[(i + DIR) * KS], b_r = y[(i + DIR) * KS];
-          level(i, a_p, a_q, a_r);
-          level(i + DIR, b_p, b_q, b_r);
+          const double s_carry = carry, s_bet = bet, s_ynum = ynum;
+          level(i, a_p, a_q, a_r, std::false_type{});
+          const bool f_mid = tiny_nonzero(ynum) || bet == 0.;
+          level(i + DIR, b_p, b_q, b_r, std::false_type{});
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(f_in || f_mid) != 0ull, 0)) {
+            carry = s_carry; bet = s_bet; ynum = s_ynum;
+            level(i, a_p, a_q, a_r, std::true_type{});
+            level(i + DIR, b_p, b_q, b_r, std::true_type{});
+          }
+          f_in = tiny_nonzero(ynum) || bet == 0.;
           if (left >= 3) { a_p = pb[(i + 2 * DIR) * KS]; a_q = qq[(i + 2 * DIR) * KS]; a_r = y[(i + 2 * DIR) * KS]; }
         }
-        if (left == 1) level(i, a_p, a_q, a_r);
+        if (left == 1) {
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(f_in) != 0ull, 0)) level(i, a_p, a_q, a_r, std::true_type{});
+          else level(i, a_p, a_q, a_r, std::false_type{});
+        }
       }
       if (bet == 0.) { bad = 1; bet = 1.E-12; }
-      const double rb = ps_recip(bet);
+      const double rb = rcp_refine(bet);
       // (not into y(m), y(m+1): each of those is written by one wave while the other may still have to read it)
-      y[(DIR > 0 ? 0 : nz + 2) * KS] = ynum * rb;        // z(m) | z(m+1) at the free ends of the row
-      gm[(DIR > 0 ? 0 : 1) * KS] = -carry * rb;          // gam(m+1) | g(m+1)
+      y[(DIR > 0 ? 0 : nz + 2) * KS] = div_by_refined(ynum, bet, rb);        // z(m) | z(m+1) at the free ends of the row
+      gm[(DIR > 0 ? 0 : 1) * KS] = div_by_refined(-carry, bet, rb);          // gam(m+1) | g(m+1)
       if (bad) sbad[sl * sbad_stride] = 1;
     }
   }
@@ -659,10 +699,9 @@ __device__ __forceinline__ void ps_thomas_v_back(int W, double *slots, int SS, i
 
 // Solver mode 1, V: both halves of the two-ended elimination on ONE wave - lane s works downward from level 1 of
 // slot s, lane 32+s upward from its level nz - on what L7 has laid out per level for either direction alike: the
-// correctly rounded reciprocal r of the level's pivot (Q_DT), the multiplier of the neighbour's solution in
+// pivot of the level (row Q_BET) and its refined reciprocal (Q_DT), the multiplier of the neighbour's solution in
 // the numerator (Q_GM: q(k) in the upper half, p(k) in the lower one) and the multiplier of the substitution (Q_DM:
 // gam(k+1) | g(k)).  So the two directions differ in their start level and the sign of their address step only.
-// A level of the forward part is z = (rhs + mult z') r: three operations, nothing that needs a second path.
 template <int OFF>
 __device__ __forceinline__ void ps_lds_write1(unsigned addr, double a)
 {
@@ -682,41 +721,51 @@ __device__ __forceinline__ void ps_thomas2_v(int W, double *slots, int SS, int K
     const int dstep = up ? -KS * 8 : KS * 8;   // bytes from a level to the next one of this lane's sweep
     int left = (up ? nz - m : m) - 1;          // levels after the first
     const int common = m - 1;                  // ... of either direction (the lower half may have one more)
-    double yy = base[i0 * KS + Q_YV] * base[i0 * KS + Q_DT];   // z = rhs r, r = 1/bet (L7)
-    base[i0 * KS + Q_YV] = yy;
+    double yy;
+    {
+      const double *l0 = base + i0 * KS;
+      yy = div_by_refined(l0[Q_YV], l0[Q_BET], l0[Q_DT]);
+      base[i0 * KS + Q_YV] = yy;
+    }
     asm volatile("" : "+v"(yy));
     unsigned ad = ps_lds_addr(base + i0 * KS) + (unsigned)dstep;   // the level to enter next
-    // of a level: rh = (r, rhs), the multiplier of the neighbour's solution on its own
-    auto rd_rh = [&](unsigned a) { return ps_lds_read2<1, 6>(a); };
-    auto rd_m = [&](unsigned a) { double v; asm volatile("ds_read_b64 %0, %1 offset:56" : "=v"(v) : "v"(a) : "memory"); return v; };
-    auto two = [&](unsigned a0_, unsigned a1_, const ps_d2 &rh0, const double m0, const ps_d2 &rh1, const double m1) {
-      const double y0 = (rh0.y + m0 * yy) * rh0.x;
-      const double y1 = (rh1.y + m1 * y0) * rh1.x;
+    // rq = (1/bet, multiplier), hb = (rhs, bet) of a level
+    auto rd_rq = [&](unsigned a) { return ps_lds_read2<1, 7>(a); };
+    auto rd_hb = [&](unsigned a) { return ps_lds_read2<6, 8>(a); };
+    auto two = [&](unsigned a0_, unsigned a1_, const ps_d2 &rq0, const ps_d2 &hb0, const ps_d2 &rq1, const ps_d2 &hb1) {
+      const double y_in = yy;
+      const double n0 = hb0.x + rq0.y * yy;
+      double y0 = div_fast(n0, hb0.y, rq0.x);
+      const double n1 = hb1.x + rq1.y * y0;
+      double y1 = div_fast(n1, hb1.y, rq1.x);
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(tiny_nonzero(n0) || tiny_nonzero(n1)) != 0ull, 0)) {
+        y0 = (hb0.x + rq0.y * y_in) / hb0.y;
+        y1 = (hb1.x + rq1.y * y0) / hb1.y;
+      }
       yy = y1;
       ps_lds_write1<48>(a0_, y0);
       ps_lds_write1<48>(a1_, y1);
     };
     int done = 0;
     if (common >= 2) {   // trips of two levels, the next trip's operands in flight (ps_lds_read2 / ps_lds_wait, above)
-      ps_d2 a0 = rd_rh(ad), a2 = rd_rh(ad + dstep), b0, b2;
-      double a1 = rd_m(ad), a3 = rd_m(ad + dstep), b1, b3;
+      ps_d2 a0 = rd_rq(ad), a1 = rd_hb(ad), a2 = rd_rq(ad + dstep), a3 = rd_hb(ad + dstep), b0, b1, b2, b3;
       while (done + 6 <= common) {   // this trip, the next, and one more after it
         const unsigned adb = ad + 2 * dstep, adc = ad + 4 * dstep;
-        b0 = rd_rh(adb); b1 = rd_m(adb); b2 = rd_rh(adb + dstep); b3 = rd_m(adb + dstep);
-        ps_lds_wait1<4>(a0, a1, a2, a3);
+        b0 = rd_rq(adb); b1 = rd_hb(adb); b2 = rd_rq(adb + dstep); b3 = rd_hb(adb + dstep);
+        ps_lds_wait<4>(a0, a1, a2, a3);
         two(ad, ad + dstep, a0, a1, a2, a3);
-        a0 = rd_rh(adc); a1 = rd_m(adc); a2 = rd_rh(adc + dstep); a3 = rd_m(adc + dstep);
-        ps_lds_wait1<4>(b0, b1, b2, b3);
+        a0 = rd_rq(adc); a1 = rd_hb(adc); a2 = rd_rq(adc + dstep); a3 = rd_hb(adc + dstep);
+        ps_lds_wait<4>(b0, b1, b2, b3);
         two(adb, adb + dstep, b0, b1, b2, b3);
         done += 4; ad = adc;
       }
       // (past the loop nothing stays in flight across a branch: see ps_backsub_from)
-      ps_lds_wait1<0>(a0, a1, a2, a3);
+      ps_lds_wait<0>(a0, a1, a2, a3);
       two(ad, ad + dstep, a0, a1, a2, a3);
       done += 2; ad += 2 * dstep;
       if (done + 2 <= common) {
-        b0 = rd_rh(ad); b1 = rd_m(ad); b2 = rd_rh(ad + dstep); b3 = rd_m(ad + dstep);
-        ps_lds_wait1<0>(b0, b1, b2, b3);
+        b0 = rd_rq(ad); b1 = rd_hb(ad); b2 = rd_rq(ad + dstep); b3 = rd_hb(ad + dstep);
+        ps_lds_wait<0>(b0, b1, b2, b3);
         two(ad, ad + dstep, b0, b1, b2, b3);
         done += 2; ad += 2 * dstep;
       }
@@ -725,9 +774,10 @@ __device__ __forceinline__ void ps_thomas2_v(int W, double *slots, int SS, int K
     left -= done;
     while (__builtin_amdgcn_ballot_w64(left > 0) != 0ull) {   // what is left of either direction: at most two levels
       if (left > 0) {
-        double *l = base + ((int)(ad - ps_lds_addr(base)) >> 3);
-        yy = (l[Q_YV] + l[Q_GM] * yy) * l[Q_DT];
-        l[Q_YV] = yy;
+        const double *l = reinterpret_cast<const double *>(base) + ((int)(ad - ps_lds_addr(base)) >> 3);
+        const double n0 = l[Q_YV] + l[Q_GM] * yy;
+        yy = div_fast_guarded(n0, l[Q_BET], l[Q_DT]);
+        const_cast<double *>(l)[Q_YV] = yy;
         ad += dstep;
       }
       --left;
@@ -803,14 +853,14 @@ template <int XV, int SM>
 #define MCKPP_PS_MINW 4
 #endif
 __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_kparams *__restrict__ pp, const int ntime, const int L,
-                                                     const int W, const unsigned Lmagic)
+                                                     const int W, const unsigned Lmagic, const int SS /* ps_ss(L, XV, W) */)
 {
   // through the block typed with global pointers (mckpp_device.h): global_load / global_store, SGPR bases
   const mckpp_kparams_dev &p = *reinterpret_cast<const mckpp_kparams_dev *>(pp);
   extern __shared__ double lds[];
   constexpr bool EXT = XV != 0, DD = XV == 2;
   constexpr int ROWS = XV == 2 ? (int)Q_COUNT_EXT_DD : XV == 1 ? (int)Q_COUNT_EXT : (int)Q_COUNT;
-  const int NL = ps_nl(L), SS = ps_ss(L, XV);
+  const int NL = ps_nl(L);
   const int tid = threadIdx.x, lane = tid & 63, lane_k = lane;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nz = p.nz, nzp1 = p.nzp1;
@@ -953,6 +1003,11 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           msc[C_SREF] = cs[CS_SREF]; msc[C_SSURF] = cs[CS_SSURF]; msc[C_OCDEPTH] = cs[CS_OCDEPTH];
           msc[C_SFLUX1] = cs[CS_SFLUX1]; msc[C_SFLUX2] = cs[CS_SFLUX2]; msc[C_SFLUX3] = cs[CS_SFLUX3];
           msc[C_SFLUX4] = cs[CS_SFLUX4]; msc[C_SFLUX5] = cs[CS_SFLUX5]; msc[C_SFLUX6] = cs[CS_SFLUX6];
+          {   // (M3 evaluates swfrac at -hbl in every pass: its constants from LDS, not through a memory round trip)
+            const int jw = ci[CI_JERLOV];
+            msc[C_JRFAC] = jer_rfac_c[jw]; msc[C_JA1] = jer_a1_c[jw]; msc[C_JA2] = jer_a2_c[jw];
+            msc[C_JRA1] = jer_ra1_c[jw]; msc[C_JRA2] = jer_ra2_c[jw];
+          }
         }
         msi[I_STATE] = st;
       }
@@ -1023,7 +1078,16 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         const double B0 = msc[C_B0], B0sol = msc[C_B0SOL], ustar = msc[C_USTAR];
         wscale_u wu;
         wu.ju = msi[I_JU]; wu.ufrac = msc[C_UFRAC]; wu.ustar = ustar; wu.ucube = msc[C_UCUBE];
-        double bfsfc = swfrac_dev(-1.0, hbl, jer);
+        double bfsfc;
+        {   // swfrac_dev(-1.0, hbl, jer) with the slot's copies of the Jerlov constants (same operations)
+          const double rmin = -80.;
+          const double zf = hbl * -1.0;
+          const double r1 = dmax2(div_fast(zf, msc[C_JA1], msc[C_JRA1]), rmin);
+          const double r2 = dmax2(div_fast(zf, msc[C_JA2], msc[C_JRA2]), rmin);
+          const double rfac = msc[C_JRFAC];
+          bfsfc = rfac * mckpp_exp(r1) + (1. - rfac) * mckpp_exp(r2);
+          (void)jer;
+        }
         bfsfc = B0 + B0sol * (1. - bfsfc);
         const double stable = 0.5 + dsign(0.5, bfsfc);
         bfsfc = bfsfc + stable * epsln16;
@@ -1798,11 +1862,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         const strided<ROWS> aDt = row(ps_sysrows<XV>::dl6_t), aDs = row(ps_sysrows<XV>::dl6_s), aGh = row(Q_YV);
         const double f = sc[C_F];
         const size_t o = ro + (k - 1);
-#ifdef MCKPP_EXP_NOLOAD   // experiment (wrong numbers): what the loads of the old time level cost this phase
-        const double Uo = row(Q_YU)[k], Vo = row(Q_YV)[k], To = row(Q_YT)[k], So = row(Q_YS)[k]; (void)o;
-#else
         const double Uo = p.U[o], Vo = p.V[o], To = p.T[o], So = p.S[o];
-#endif
         const double dto = p.dto, tri1_nz = c_t1[nz];
         const double wX0_1 = sc[C_WX01], wX0_2 = sc[C_WX02];
         const strided<ROWS> yU = row(Q_YU), yT = row(Q_YT), yS = row(Q_YS);
@@ -1871,11 +1931,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       FOR_ITEMS
         if (!act) continue;
         const size_t o = ro + (k - 1);
-#ifdef MCKPP_EXP_NOLOAD
-        const double Uo = row(Q_YU)[k], Vo = row(Q_YV)[k]; (void)o;
-#else
         const double Uo = p.U[o], Vo = p.V[o];
-#endif
         const double dto = p.dto, f = sc[C_F];
         const strided<ROWS> yU = row(Q_YU), yV = row(Q_YV);
         if (actz) {
@@ -1903,12 +1959,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
             }
           }
           if (betk == 0.) betk = 1.E-12;
-          if constexpr (SM == 0) {
-            row(Q_BET)[k] = betk;
-            row(Q_DT)[k] = rcp_refine(betk);
-          } else {
-            row(Q_DT)[k] = ps_recip(betk);   // the sweep multiplies by the reciprocal the U sweep multiplied by
-          }
+          row(Q_BET)[k] = betk;
+          row(Q_DT)[k] = rcp_refine(betk);
           const double un = yU[k];
           double rhsV;
           if (k == 1) rhsV = Vo - dto * (f * .5 * (Uo + un) + div_fast(sc[C_WU02], c_hm[1], c_misc[0]));
@@ -2306,7 +2358,7 @@ hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kpa
   if (!p.scratch || p.scratch_doubles < (size_t)num_cu * g.per_cu * g.w * 4 * ps_scratch_ld(p.nzp1)) return hipErrorInvalidValue;
   const size_t lds = ps_lds_bytes(L, g.w, xv);
   if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
-  using kern_t = void (*)(const mckpp_kparams *, int, int, int, unsigned);
+  using kern_t = void (*)(const mckpp_kparams *, int, int, int, unsigned, int);
   static const kern_t kerns[2][3] = {{k_column_ps<0, 0>, k_column_ps<1, 0>, k_column_ps<2, 0>},
                                      {k_column_ps<0, 1>, k_column_ps<1, 1>, k_column_ps<2, 1>}};
   if (p.solver_mode < 0 || p.solver_mode > 1) return hipErrorInvalidValue;
@@ -2329,11 +2381,11 @@ hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kpa
       said = true;
       int nb = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * g.nw, lds) != hipSuccess) nb = -1;
-      fprintf(stderr, "[mckpp ps] L=%d: %d slots x %d waves x %d workgroups per CU, %zu B of LDS each, %d fit on a CU, %d workgroups\n",
-              L, g.w, g.nw, g.per_cu, lds, nb, nblocks);
+      fprintf(stderr, "[mckpp ps] L=%d: %d slots x %d waves x %d workgroups per CU, %zu B of LDS each (slot stride %d doubles = %d mod 32, %d of them padding), %d fit on a CU, %d workgroups\n",
+              L, g.w, g.nw, g.per_cu, lds, ps_ss(L, xv, g.w), ps_ss(L, xv, g.w) & 31, ps_ss(L, xv, g.w) - ps_rows(xv) * ps_nl(L), nb, nblocks);
     }
   }
   const unsigned Lmagic = (unsigned)(0x100000000ull / (unsigned long long)L) + 1u;   // it / L == umulhi(it, Lmagic) for it < 2^20
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(64 * g.nw), lds, stream, dp, p.ntime, L, g.w, Lmagic);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(64 * g.nw), lds, stream, dp, p.ntime, L, g.w, Lmagic, ps_ss(L, xv, g.w));
   return hipGetLastError();
 }

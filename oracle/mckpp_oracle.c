@@ -468,12 +468,10 @@ int orc_tridmat(const double *cu, const double *cc, const double *cl,
  * tridiagonal system, eliminated from both ends at once - downward from level 1 as tridmat does
  * (solvers.F90:135-154) for the levels 1..m, m = nzi/2, upward from level nzi by the mirrored recurrence for the
  * levels nzi..m+1 - then the two remaining unknowns y(m), y(m+1) from their 2x2 system, then the two back
- * substitutions away from the middle.  Each half is a chain of nzi/2 dependent steps instead of nzi, and a step
- * divides once: the (correctly rounded) reciprocal r of the pivot, by which both quotients of tridmat's step are
- * formed as products.  Every operation is one IEEE operation in the order written here; the HIP kernels' solver
- * mode 1 performs exactly these.
- *   upper half:  r = 1/bet, gam(i) = cl(i-1) r, bet = cc(i) - cu(i) gam(i), z(i) = (rhs(i) - cu(i) z(i-1)) (1/bet)
- *   lower half:  r = 1/bet, g(i+1) = cu(i+1) r, bet = cc(i) - cl(i) g(i+1), z(i) = (rhs(i) - cl(i) z(i+1)) (1/bet)
+ * substitutions away from the middle.  Each half is a chain of nzi/2 dependent steps instead of nzi.  Every
+ * operation is one IEEE operation in the order written here; the HIP kernels' solver mode 1 performs exactly these.
+ *   upper half:  gam(i) = cl(i-1)/bet, bet = cc(i) - cu(i) gam(i), z(i) = (rhs(i) - cu(i) z(i-1))/bet
+ *   lower half:  g(i+1) = cu(i+1)/bet, bet = cc(i) - cl(i) g(i+1), z(i) = (rhs(i) - cl(i) z(i+1))/bet
  *   middle:      y(m) = (z(m) - gam(m+1) z(m+1)) / (1 - gam(m+1) g(m+1)),  y(m+1) = z(m+1) - g(m+1) y(m)
  *   back:        y(i) = z(i) - gam(i+1) y(i+1), i = m-1..1;   y(i) = z(i) - g(i) y(i-1), i = m+2..nzi
  * A zero pivot is replaced as solvers.F90:140-151 does, in either half.  gam[2..m] holds the upper half's
@@ -485,30 +483,25 @@ int orc_tridmat_2e(const double *cu, const double *cc, const double *cl,
   const int m = nzi / 2;
   int bad = 0;
   double bet = cc[1];
-  if (bet == 0.) { bad = 1; bet = 1.E-12; }               /* (every pivot of this mode is checked, the first ones too) */
-  double r = 1. / bet;
-  yn[1] = rhs[1] * r;
+  yn[1] = rhs[1] / bet;
   for (int i = 2; i <= m; i++) {
-    gam[i] = cl[i - 1] * r;
+    gam[i] = cl[i - 1] / bet;
     bet = cc[i] - cu[i] * gam[i];
     if (bet == 0.) { bad = 1; bet = 1.E-12; }
-    r = 1. / bet;
-    yn[i] = (rhs[i] - cu[i] * yn[i - 1]) * r;
+    yn[i] = (rhs[i] - cu[i] * yn[i - 1]) / bet;
   }
-  const double gt = cl[m] * r;                            /* gam(m+1) */
+  const double gt = cl[m] / bet;                          /* gam(m+1) */
   double betb = cc[nzi];
-  if (betb == 0.) { bad = 1; betb = 1.E-12; }
-  double rb = 1. / betb;
-  yn[nzi] = rhs[nzi] * rb;
+  if (betb == 0.) { bad = 1; betb = 1.E-12; }             /* the lower half's first pivot is one of tridmat's checked ones */
+  yn[nzi] = rhs[nzi] / betb;
   for (int i = nzi - 1; i >= m + 1; i--) {
-    const double g = cu[i + 1] * rb;
+    const double g = cu[i + 1] / betb;
     gam[i + 1] = g;
     betb = cc[i] - cl[i] * g;
     if (betb == 0.) { bad = 1; betb = 1.E-12; }
-    rb = 1. / betb;
-    yn[i] = (rhs[i] - cl[i] * yn[i + 1]) * rb;
+    yn[i] = (rhs[i] - cl[i] * yn[i + 1]) / betb;
   }
-  const double gb = cu[m + 1] * rb;                       /* g(m+1) */
+  const double gb = cu[m + 1] / betb;                     /* g(m+1) */
   const double den = 1. - gt * gb;
   const double ym = (yn[m] - gt * yn[m + 1]) / den;
   const double ym1 = yn[m + 1] - gb * ym;

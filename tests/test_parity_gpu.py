@@ -203,8 +203,10 @@ def test_tolerance_vs_faithful_oracle(mk, nz, grid, dto, ncol, nsteps):
 @pytest.mark.parametrize("nz,grid,dto,ncol,nsteps", [(60, "uniform", 3600.0, 4000, 24), (69, "stretched", 1200.0, 2000, 24)])
 def test_two_ended_solver_within_rounding_of_the_reference_order(mk, nz, grid, dto, ncol, nsteps):
     """Solver mode 1 on the device against the oracle in the REFERENCE's order of operations (solver_mode=0): the
-    opt-in mode changes the rounding of the implicit solves, nothing else - same kmix and pass counts, profiles and
-    hmix within 1e-12 after a model day (1e5 x 72 on the CPU: <= 1.3e-14, profiles/r04/parity_tolerance.json)."""
+    opt-in mode changes the rounding of the implicit solves below the middle of the column and at its meeting point,
+    nothing else (its upper half performs tridmat's own operations, and what the meeting point perturbs decays upward
+    by a factor |gam| < 1 per level) - same kmix and pass counts, hmix identical, profiles within 1e-12 after a model
+    day (1e5 columns x 72 steps on the CPU: T, S <= 1.3e-14; profiles/r04/parity_tolerance.json, rows `hip_2e vs hip`)."""
     for nt, k3, ob, same in _diurnal_both(mk, ncol, nz, nsteps, grid, dto, {"exp_mode": 1, "solver_mode": 0},
                                           hip_solver_mode=1, every=(1, nsteps)):
         m = cm.tolerance_metrics(cm.hip_state(k3, nz), cm.oracle_state(ob, nz), same)
@@ -1059,8 +1061,8 @@ def test_tuned_residency_is_what_the_device_grants(mk, nz, ncol, want):
     ctx.close()
 
 
-@pytest.mark.parametrize("nz", [60, 100])
-def test_zero_pivot_on_device(mk, nz):
+@pytest.mark.parametrize("nz,solver_mode", [(60, None), (100, None), (60, 1), (61, 1)])
+def test_zero_pivot_on_device(mk, nz, solver_mode):
     """The reference STOPs when the Thomas pivot vanishes (src/mckpp_physics_solvers.F90:140-151); the
     device sets MCKPP_ST_ZERO_PIVOT, continues with bet = 1e-12 and lets the instability trap deal with
     whatever comes out.  A crafted tri() makes cc(i) - cu(i) gam(i) exactly zero for the momentum system - once at
@@ -1072,14 +1074,22 @@ def test_zero_pivot_on_device(mk, nz):
 
     ncol = 70
     hit = 0
+    two_ended = solver_mode == 1 or (solver_mode is None and os.environ.get("MCKPP_SOLVER_MODE", "0") == "1")
+    sm = {} if solver_mode is None else {"solver_mode": solver_mode}
     for level in (nz - 6, nz):
-        oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1)
+        oc, ob = cm.make_oracle(ncol, nz, init=False, exp_mode=1, **sm)
         kc, k3 = cm.make_hip_case(ncol, nz)
-        kc.tri[level, 0, 0] = 0.0
-        kc.tri[level, 1, 0] = -1.0e4
-        oc.tri0[level] = 0.0
-        oc.tri1[level] = -1.0e4
+        # the two-ended mode eliminates the lower half of the column upward: its pivot at an interior level there is
+        # cc(i) - cl(i) g(i+1), which vanishes for cl(i) = 0, cc(i) = 1 + tri(i,0) diff(i-1) = 0 - the mirrored
+        # crafting; at the last level (its first pivot, cc(nz)) the same crafting serves both modes
+        t0, t1 = (-1.0e4, 0.0) if (two_ended and level < nz) else (0.0, -1.0e4)
+        kc.tri[level, 0, 0] = t0
+        kc.tri[level, 1, 0] = t1
+        oc.tri0[level] = t0
+        oc.tri1[level] = t1
         ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+        if solver_mode is not None:
+            ctx.set_solver_mode(solver_mode)
         orc.init_ocean(oc, ob, 0)
         sf = cm.synth.forcing(ncol, "bench")
         ob["sflux"] = sf

@@ -12,11 +12,11 @@ const char *t_name[T_COUNT] = {"U,T,S forward", "back substitution U,T,S", "V fo
                                "two-ended V, all of it (one wave)"};
 
 template <int TEST>
-__global__ __launch_bounds__(1024, 4) void k_sweep(int W, int nz, int busy, unsigned long long *cyc, double *out)
+__global__ __launch_bounds__(1024, 4) void k_sweep(int W, int nz, int busy, unsigned long long *cyc, double *out, int SS)
 {
   extern __shared__ double lds[];
   constexpr int XV = 0, ROWS = Q_COUNT;
-  const int nzp1 = nz + 1, L = nzp1 + 2, NL = ps_nl(L), SS = ps_ss(L, XV);
+  const int nzp1 = nz + 1, L = nzp1 + 2, NL = ps_nl(L);
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   double *cst = lds, *slots = lds + K_STRIDE * NL + 2, *screc = slots + W * SS;
   int *sirec = reinterpret_cast<int *>(screc + W * C_COUNT), *s_flags = sirec + W * I_COUNT;
@@ -87,7 +87,7 @@ template <int TEST> void run(int W, int nz, int waves, int busy, unsigned long l
   hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<TEST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   unsigned long long best = ~0ull, h[2] = {0, 0};
   for (int rep = 0; rep < 5; ++rep) {
-    hipLaunchKernelGGL(k_sweep<TEST>, dim3(1), dim3(64 * waves), lds, 0, W, nz, busy, dc, dout);
+    hipLaunchKernelGGL(k_sweep<TEST>, dim3(1), dim3(64 * waves), lds, 0, W, nz, busy, dc, dout, ps_ss(L, 0, W));
     hipDeviceSynchronize();
     hipMemcpy(h, dc, sizeof h, hipMemcpyDeviceToHost);
     if (h[0] < best) best = h[0];
