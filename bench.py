@@ -195,7 +195,7 @@ def time_steps(ctx, nt_first, nsteps, barrier):
     ctx.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    kms, nlaunch = ctx.last_kernel_ms()
+    kms, nlaunch = ctx.last_kernel_ms()   # (nlaunch: the steps the call covered; step(nt, n) is one launch for all n)
     return dt, (kms / max(nlaunch, 1)) * 1e-3
 
 
@@ -657,6 +657,11 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": ctx.kernel_name + " (cooperative, persistent)",
                 "kernel_avg_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": balg * nocean,
+                "kernel_launches_in_the_timed_region": ctx.last_launch_count(),
+                "launch_note": ("kernel_avg_ms and algorithmic_bytes_per_launch are per model step; the timed region's "
+                                f"{a.steps} steps are {ctx.last_launch_count()} launch(es) of k_column_ps (mckpp_hip_step(nt, n): one "
+                                "launch takes every column through all n steps), so a kernel trace shows dispatches of "
+                                f"{a.steps // max(ctx.last_launch_count(), 1)} x kernel_avg_ms"),
                 "note": "fp64 instruction-issue / dependent-chain bound, not HBM-bound (DESIGN.md section 6)",
                 "issue": issue,
             },

@@ -298,9 +298,14 @@ int mckpp_hip_window_fetch(mckpp_hip_handle h, int field, int op, double *out);
 int mckpp_hip_status(mckpp_hip_handle h, int32_t *per_col, int64_t *n_flagged,
                      int32_t *npasses);
 
-/* Timing of the most recent step/init/vmix_pass launches on the context's
- * stream, from HIP events recorded around the kernel: total ms and launches. */
+/* Timing of the most recent step/init/vmix_pass call on the context's stream, from HIP events recorded around its
+ * kernel launches: total ms and the number of model steps (or passes) they covered.  mckpp_hip_step(nt, n > 1) with
+ * constant forcing is ONE launch that takes every column through all n steps (a column's step waits for that
+ * column's previous step only - no barrier across the device between steps, so a column that runs to itermax delays
+ * nothing but itself; same results bit for bit; MCKPP_MULTISTEP=0 restores a launch per step):
+ * mckpp_hip_last_launch_count tells how many kernel launches the call made. */
 int mckpp_hip_last_kernel_ms(mckpp_hip_handle h, double *ms, int32_t *nlaunch);
+int32_t mckpp_hip_last_launch_count(mckpp_hip_handle h);
 
 /* Name of the column kernel this context launches for its grid and switches
  * ("k_column_ps", "k_column_ps<EXT>"); static storage, never NULL. */

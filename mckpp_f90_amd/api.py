@@ -101,6 +101,8 @@ def _bind(lib):
     lib.mckpp_hip_upload.argtypes = [C.c_void_p, C.POINTER(_StateC)]
     lib.mckpp_hip_set_forcing.argtypes = [C.c_void_p, _dp]
     lib.mckpp_hip_set_diagnostics.argtypes = [C.c_void_p, C.c_int]
+    lib.mckpp_hip_last_launch_count.argtypes = [C.c_void_p]
+    lib.mckpp_hip_last_launch_count.restype = C.c_int32
     lib.mckpp_hip_set_solver_mode.argtypes = [C.c_void_p, C.c_int]
     lib.mckpp_hip_get_solver_mode.argtypes = [C.c_void_p]
     lib.mckpp_hip_window_reset.argtypes = [C.c_void_p]
@@ -454,6 +456,10 @@ class MckppHip:
         nl = C.c_int32(0)
         _chk(_lib().mckpp_hip_last_kernel_ms(self._h, C.byref(ms), C.byref(nl)))
         return ms.value, nl.value
+
+    def last_launch_count(self):
+        """kernel launches of the last step/init/vmix_pass call (step(nt, n > 1) is one launch for all n steps)"""
+        return int(_lib().mckpp_hip_last_launch_count(self._h))
 
     def kernel_residency(self):
         """(blocks per CU asked for, blocks per CU that fit, threads per block, LDS bytes per block)"""

@@ -64,6 +64,11 @@ struct mckpp_kparams_t {
   P<double> cs;
   P<int> ci;
   P<int> qhead;   // column queue head for the persistent cooperative kernel (zeroed per launch)
+  int nsteps_launch;   // model steps this launch takes every column through (1: the step-per-launch path)
+  int nqueues;         // nsteps_launch > 1: queues = XCDs of the device (qhead[0..nqueues-1]); column c is in queue c mod nqueues
+  int xcc_queue[16];   // hardware XCC id -> queue index
+  P<int> qowner;  // [16] per queue: 0 free, else hardware XCC id + 1 of the XCD whose workgroups serve it (zeroed per launch)
+  P<int> done;    // [ncol] steps of this launch a column has completed (zeroed per launch; nsteps_launch > 1 only)
   P<unsigned long long> dbg;   // optional [32] phase-cycle accumulators (diagnostic builds of a run only)
   // optional physics: ext != 0 selects the kernel build that carries it
   int ext, L_RELAX_SST, L_RELAX_CALCONLY, L_FCORR, L_FCORR_WITHZ, L_SFCORR, L_SFCORR_WITHZ;
@@ -97,6 +102,7 @@ struct mckpp_launch_info { int nblocks, threads, max_blocks_per_cu; size_t lds_b
 hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kparams *dp, int num_cu,
                                          hipStream_t stream, mckpp_launch_info *info);
 size_t mckpp_ps_scratch_doubles(int nzp1, int variant, int num_cu);   // what p.scratch must hold (variant: 0 default physics, 1 optional, 2 optional with double diffusion)
+hipError_t mckpp_launch_xcc_probe(unsigned *mask, hipStream_t stream);   // OR of 1 << XCC id over a 4096-workgroup grid
 hipError_t mckpp_launch_eos_batch(int64_t n, const double *s, const double *t, const double *p,
                                   double *alpha, double *beta, double *sig0, double *cp,
                                   hipStream_t stream);

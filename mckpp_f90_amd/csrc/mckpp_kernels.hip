@@ -189,6 +189,19 @@ __global__ void k_window_mean(const double *__restrict__ sum, double *__restrict
 }  // namespace
 
 
+// Which XCDs does this device have?  Every workgroup of a large grid ORs the bit of the XCC it runs on (read from
+// the hardware) into one word: the ids of the queues of a launch of several steps (k_column_ps, M0).
+__global__ void k_xcc_probe(unsigned *mask)
+{
+  if (threadIdx.x == 0) atomicOr(mask, 1u << (__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20 /* HW_REG_XCC_ID, bits 3:0 */) & 15));
+}
+
+hipError_t mckpp_launch_xcc_probe(unsigned *mask, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_xcc_probe, dim3(4096), dim3(64), 0, stream, mask);
+  return hipGetLastError();
+}
+
 hipError_t mckpp_launch_eos_batch(int64_t n, const double *s, const double *t, const double *p,
                                   double *alpha, double *beta, double *sig0, double *cp,
                                   hipStream_t stream)

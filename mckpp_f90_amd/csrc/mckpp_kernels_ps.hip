@@ -26,7 +26,7 @@ namespace {
 
 using namespace mckpp_dev;
 
-enum { PS_EMPTY = 0, PS_ACTIVE = 1, PS_DONE = 2 };
+enum { PS_EMPTY = 0, PS_ACTIVE = 1, PS_DONE = 2, PS_WAIT = 3 /* holds a ticket whose column's previous step is still running elsewhere */ };
 enum { F_NONE = 0, F_TRAP = 1, F_FINAL = 2 };
 
 // per-slot double record
@@ -46,7 +46,8 @@ enum {
   I_KBL, I_NRESET, I_FIN, I_MAYBE, I_LOAD /* 1: new column, 2: restart the iteration (trap retry) */, I_JU,
   I_KBLC, I_NVIOL, I_NOVER, I_NU, I_NV, I_NF, I_BAD, I_L1A /* L1 but for V done ahead, during the V sweep */,
   I_MAYBE_NEXT, I_LOCEAN, I_PAR /* which C_T1X holds the iterate's level-1 temperature */,
-  I_TINY /* some whole-layer term of the reference-level sums is a tiny non-zero number (L2) */, I_COUNT
+  I_TINY /* some whole-layer term of the reference-level sums is a tiny non-zero number (L2) */,
+  I_STEP /* which step of the launch this column is in (0 .. nsteps_launch-1) */, I_COUNT
 };
 // LDS rows of a slot and what each holds between which phases of a pass:
 //   Q_DM   (LDD talpha L1..L2; else the whole-layer terms of the reference-level sum of U, L2)  difm: interior L3;
@@ -890,6 +891,16 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // electing the wave that sits on a given SIMD, so that the serial chains of all workgroups of a CU share one
   // SIMD (0.8-0.9x), or one SIMD per workgroup chosen from blockIdx (0.97x); raising its s_setprio (0.97x).
   const int mgr = 0;
+  // the queue of the XCD this workgroup runs on (launches of several steps; M0)
+  const int my_xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20 /* HW_REG_XCC_ID, bits 3:0 */) & 15;
+  if (tid == 0 && p.nsteps_launch > 1) {   // claim the XCD's own queue (s_flags[7]: the queue M0 draws from)
+    int q = p.xcc_queue[my_xcc];
+    if (q >= 0) {
+      const int prev = atomicCAS((int *)p.qowner + q, 0, my_xcc + 1);
+      if (prev != 0 && prev != my_xcc + 1) q = -1;   // (another XCD has adopted it already: cannot happen while its own workgroups start with the rest)
+    }
+    s_flags[7] = q;
+  }
 
   // ---- work items (slot, level) ------------------------------------------------
   // Item `it` of the first trip belongs to thread `it`; the later trips are dealt to the waves other than the
@@ -968,29 +979,96 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     (void)sc; (void)actz; (void)is1; (void)isnz; (void)row;
 
   // =========================== manager phases (wave 0) ===========================
-  // M0: slots whose column has finished pull the next one from the queue 
+  // M0: slots whose column has finished pull the next one from the queue.
+  // A launch may cover several model steps (p.nsteps_launch; mckpp_hip_step with nsteps > 1): the queue then holds
+  // ncol x nsteps tickets in step-major order - ticket t is step t / ncol of column t mod ncol - and a column's step
+  // may start once its previous step has been finished, by whichever workgroup had it: there is no barrier across
+  // the chip between the steps.  One column that runs to itermax (200 passes where the others take 6: 4 ms more for
+  // the whole launch, in one step of seven of a long run - profiles/r04/step_series.txt) then delays nothing but
+  // its own next step.  p.done[c] counts the steps of the launch column c has completed: published after the
+  // barrier behind the stores of the finishing step (every wave's vmcnt drained), read - with an agent-scope acquire,
+  // which drops this CU's stale L1 lines - before the next step's loads.
+  // A COLUMN STAYS ON ONE XCD for the whole launch: the per-XCD L2s are not coherent with each other (two steps of a
+  // column on two XCDs would leave two dirty copies of its diagnostic rows, written back in any order; making every
+  // step's 200 KB of stores visible across XCDs cost 10 % as an L2 write-back per finish round).  There is a queue
+  // per XCD - column c belongs to queue c mod nq, a workgroup draws from the queue of the XCD it runs on, read from
+  // the hardware (HW_REG_XCC_ID, mapped to 0..nq-1 by a probe at mckpp_hip_init) - so a column's rows live in one L2,
+  // the coherence point of all CUs that ever touch them, and plain stores are enough.
+  // A slot whose ticket is not ready keeps it (PS_WAIT) and asks again at every later M0.
   auto M0 = [&]() {
     int lane = lane_k; asm volatile("" : "+v"(lane));
-    bool a = false;
+    bool a = false, wt = false;
+    const bool multi = p.nsteps_launch > 1;
+    if (multi) {
+      const bool pub = lane < W && sirec[lane * I_COUNT + I_STATE] == PS_ACTIVE && sirec[lane * I_COUNT + I_FIN] == F_FINAL;
+      if (pub) __hip_atomic_store(p.done + sirec[lane * I_COUNT + I_COL], sirec[lane * I_COUNT + I_STEP] + 1, __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+    }
+    int *msi = sirec + (lane < W ? lane : 0) * I_COUNT;
+    double *msc = screc + (lane < W ? lane : 0) * C_COUNT;
+    int st = PS_DONE, c = 0, step = 0;
+    bool want = false, ready = false, idle = false;
     if (lane < W) {
-      int *msi = sirec + lane * I_COUNT;
-      double *msc = screc + lane * C_COUNT;
-      int st = msi[I_STATE];
+      st = msi[I_STATE];
       if (st == PS_ACTIVE && msi[I_FIN] == F_FINAL) st = PS_EMPTY;   // its outputs are stored (barrier before M0)
+      if (st == PS_WAIT) { c = msi[I_COL]; step = msi[I_STEP]; want = true; }
       if (st == PS_EMPTY) {
-        const int c = atomicAdd((int *)p.qhead, 1);
         msi[I_FIN] = F_NONE;
-        if (c >= p.ncol) {
-          st = PS_DONE;
-          msi[I_ACT] = 0;
+        if (!multi) {
+          const int t = atomicAdd((int *)p.qhead, 1);
+          if (t >= p.ncol) { st = PS_DONE; msi[I_ACT] = 0; }
+          else { c = t; want = true; }
         } else {
+          // the queue this workgroup draws from: its XCD's own, later one it has adopted (below), or none
+          msi[I_ACT] = 0;
+          const int q = s_flags[7];
+          const int nloc = q < 0 ? 0 : (p.ncol - q + p.nqueues - 1) / p.nqueues;   // its columns: c = q + nq j
+          const int t = nloc > 0 ? atomicAdd((int *)p.qhead + q, 1) : 0;
+          if (nloc <= 0 || t >= nloc * p.nsteps_launch) idle = true;   // stays PS_EMPTY: the workgroup looks for another queue
+          else {
+            step = t / nloc;
+            c = q + p.nqueues * (t - step * nloc);
+            want = true;
+          }
+        }
+      }
+      if (want) ready = !(multi && step > 0) || __hip_atomic_load(p.done + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= step;
+    }
+    if (multi && __ballot(want && ready && step > 0) != 0ull)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // before anything of those columns is read (here, and by every thread after the barrier)
+    bool more = false;
+    if (multi && __ballot(idle) != 0ull) {
+      // This workgroup's queue is used up (or its XCD has none).  A queue nobody draws from - no workgroup of the
+      // launch runs on its XCD: HIP promises nothing about placement - must still be served, and by ONE XCD: the
+      // first to ask owns it (qowner: 0 free, else hardware XCC id + 1), and every workgroup of that XCD may then
+      // draw from it.  Own queues are claimed at the start of the kernel, so only a queue without workgroups of its
+      // own is ever adopted.
+      int newq = -1;
+      if (lane == 0) {
+        for (int qq = 0; qq < p.nqueues && newq < 0; ++qq) {
+          const int nl = (p.ncol - qq + p.nqueues - 1) / p.nqueues;
+          if (nl <= 0 || __hip_atomic_load((int *)p.qhead + qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nl * p.nsteps_launch) continue;
+          const int prev = atomicCAS((int *)p.qowner + qq, 0, my_xcc + 1);
+          if (prev == 0 || prev == my_xcc + 1) newq = qq;
+        }
+        s_flags[7] = newq;
+      }
+      more = __shfl(newq, 0) >= 0;   // the idle slots draw from it at the next M0 (which `waiting` asks for)
+      if (idle && !more) st = PS_DONE;
+    }
+    if (lane < W) {
+      if (want && !ready) {
+        st = PS_WAIT;
+        msi[I_ACT] = 0; msi[I_COL] = c; msi[I_STEP] = step;
+      } else if (want) {
+        {
           st = PS_ACTIVE;
           const auto ci = p.ci + (size_t)c * MCKPP_CI;
           const auto cs = p.cs + (size_t)c * MCKPP_CS;
           int old = ci[CI_OLD], newi = ci[CI_NEW], status = 0;
           if (old < 0 || old > 1) { old = newi; status |= 16; }
           if (newi < 0 || newi > 1) { newi = old; status |= 16; }
-          msi[I_ACT] = 1; msi[I_COL] = c; msi[I_OLD] = old; msi[I_NEW] = newi; msi[I_JER] = ci[CI_JERLOV];
+          msi[I_ACT] = 1; msi[I_COL] = c; msi[I_STEP] = step; msi[I_OLD] = old; msi[I_NEW] = newi; msi[I_JER] = ci[CI_JERLOV];
           msi[I_INITFLAG] = (p.mode == MCKPP_MODE_INIT) ? 1 : ci[CI_INITFLAG];   // initialize_ocean.F90:59
           msi[I_LOCEAN] = ci[CI_LOCEAN];
           msi[I_STATUS] = status; msi[I_NPASS] = 0; msi[I_NPASS_TRY] = 0; msi[I_ICONV] = 0; msi[I_COMP] = 1;
@@ -1009,12 +1087,14 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
             msc[C_JRA1] = jer_ra1_c[jw]; msc[C_JRA2] = jer_ra2_c[jw];
           }
         }
-        msi[I_STATE] = st;
       }
+      msi[I_STATE] = st;
       a = st == PS_ACTIVE;
+      wt = st == PS_WAIT || (idle && more);
     }
-    const unsigned long long m = __ballot(a);
-    if (lane == 0) { s_flags[0] = m != 0ull ? 1 : 0; s_flags[1] = 0; }
+    const unsigned long long m = __ballot(a), mw = __ballot(wt);
+    if (lane == 0) { s_flags[0] = m != 0ull ? 1 : 0; s_flags[1] = 0; s_flags[6] = mw != 0ull ? 1 : 0; }
+    if (multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the acquire's invalidate has completed before the barrier lets the other waves load
   };
 
   // M1: surface fluxes and friction velocity (verticalmixing_mod.F90:81-100), wXNT(0) (fluxes_mod.F90:110-116)
@@ -1538,10 +1618,15 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 #else
 #define STAMP(i)
 #endif
-  if (wv == mgr) M0();
-  __syncthreads();
+  // One iteration of the loop: a pass of the active slots (if any), the finish round (if some slot finishes), M0 (if
+  // a slot finished, or one holds a ticket it is waiting to start: several steps in one launch).  M0 has this one
+  // call site; the first iteration comes in as "no slot active, one waiting" and only fills the slots.
+  bool first_iteration = true;
   for (;;) {
-    if (!s_flags[0]) break;
+    const int any_active = first_iteration ? 0 : s_flags[0], any_waiting = first_iteration ? 1 : s_flags[6];
+    if (!any_active && !any_waiting) break;
+    int finishing = 0;
+    if (any_active) {
     STAMP(22);
 #ifdef MCKPP_PS_STAMPS
     tacc[23] += 1;
@@ -1579,14 +1664,21 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     if (wv == mgr) M1();
     if (kguess < nz) {
       // level-major order, rising: the waves that hold levels below the guess have the cheap part only
-      // (all items to the waves other than the manager's, which has M1 to do)
-      for (int it_ = tid2 >= 0 ? tid2 : nitems_lm; it_ < nitems_lm; it_ += nhelp) {
+      // (all items to the waves other than the manager's, which has M1 to do - but for a last trip of a few items:
+      // 915 items on 448 threads are two trips and nineteen items, which one wave would go a third time for while
+      // the manager, done with M1, waits; it takes them)
+      const int nfull = nthreads > 64 ? (nitems_lm / nhelp) * nhelp : nitems_lm, nrem = nitems_lm - nfull;
+      const bool mgr_rest = nfull > 0 && nrem > 0 && nrem <= 64;
+      const int nhelpers = mgr_rest ? nfull : nitems_lm;
+      auto l2_one = [&](const int it_) {
         const int k = (W == 1 ? it_ : (int)__umulhi((unsigned)it_, Wmagic)) + 1;
         const int slot = it_ - (k - 1) * W;
         int *const si = sirec + slot * I_COUNT;
-        if (!si[I_ACT]) continue;
+        if (!si[I_ACT]) return;
         L2_item(k, si, slots + slot * SS, screc + slot * C_COUNT, (size_t)si[I_COL] * p.ld, k <= nz, k == 1, k == nz, k == nzp1, k <= kguess);
-      }
+      };
+      for (int it_ = tid2 >= 0 ? tid2 : nhelpers; it_ < nhelpers; it_ += nhelp) l2_one(it_);
+      if (wv == mgr && mgr_rest && lane < nrem) l2_one(nfull + lane);
     } else if (nzp1 >= 50) {
       // measured: the level-major order (a deep and a shallow item per thread) pays from ~50 levels on (+2 % at 60,
       // +13 % on the stretched 69-level grid, -2 % at 40)
@@ -1998,7 +2090,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(20);
     __syncthreads();
     STAMP(21);
-    if (!s_flags[1]) continue;
+    finishing = s_flags[1];
+    if (finishing) {
 
     // =========================== finish round ===========================
     // instability trap (ocnstep_mod.F90:200-236), then retry or outputs + check_profile.  The profiles of a
@@ -2265,11 +2358,22 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         }
       }
     END_ITEMS
-    __syncthreads();   // every read of the finished slots' records is done: hand them to the queue
+    }   // finish round
+    }   // pass of the active slots
+    if (!finishing && !any_waiting) continue;
+    // (every read of the finished slots' records and of the flags M0 rewrites is done: hand the slots to the queue;
+    // every wave's stores of the finishing steps have left it - M0 publishes those steps)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     STAMP(29);
-    if (wv == mgr) M0();
+    if (wv == mgr) {
+      // nothing to work on but a ticket whose column another workgroup still has in its previous step: ask again in a while
+      if (!any_active && !first_iteration) __builtin_amdgcn_s_sleep(64);
+      M0();
+    }
     __syncthreads();
     STAMP(30);
+    first_iteration = false;
   }
 #ifdef MCKPP_PS_STAMPS
   if (p.dbg && wv == mgr && lane == 0) {

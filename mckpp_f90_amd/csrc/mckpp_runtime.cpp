@@ -84,6 +84,7 @@ struct mckpp_hip_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   int nlaunch = 0;
+  int nkernels = 0;   // kernel launches of the last call (a call of several steps may be one launch)
   mckpp_const_c c{};
   int nz = 0, nzp1 = 0, lpl = 1, ld = 64, ldc = 72;
   double Vtc = 0, cg = 0, dm_nz = 0;
@@ -111,6 +112,10 @@ struct mckpp_hip_ctx {
   double *d_cs = nullptr;
   int *d_ci = nullptr;
   int *d_qhead = nullptr;
+  int *d_done = nullptr;   // [ncol] steps of a multi-step launch each column has completed (mckpp_kparams_t::done)
+  bool multistep = true;   // mckpp_hip_step(nt, n > 1) as one launch (MCKPP_MULTISTEP=0: a launch per step)
+  int nqueues = 0;         // XCDs of the device, found by a probe at init: the queues of such a launch
+  int xcc_queue[16];       // hardware XCC id -> queue (-1: no workgroup of the probe ran there)
   int l3cap = 0;   // MCKPP_L3_CAP (tests): see mckpp_kparams_t::l3cap
   int solver_mode = 0;   // mckpp_hip_set_solver_mode / MCKPP_SOLVER_MODE
   unsigned long long *d_dbg = nullptr;
@@ -269,7 +274,17 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   h->ext_kernel = c->LDD || c->L_RELAX_SST || c->L_FCORR || c->L_FCORR_WITHZ || c->L_SFCORR || c->L_SFCORR_WITHZ ||
                   c->L_RELAX_SAL || c->L_RELAX_OCNT || c->L_NO_FREEZE || c->L_NO_ISOTHERM || c->L_DAMP_CURR || c->L_ADVECT;
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  HIPCHK(hipMalloc(&h->d_qhead, sizeof(int)));
+  HIPCHK(hipMalloc(&h->d_qhead, 32 * sizeof(int)));   // queue heads [16], queue owners [16]
+  {   // the device's XCDs (a column of a multi-step launch stays on one: mckpp_kernels_ps.hip, M0)
+    HIPCHK(hipMemsetAsync(h->d_qhead, 0, sizeof(int), h->stream));
+    HIPCHK(mckpp_launch_xcc_probe(reinterpret_cast<unsigned *>(h->d_qhead), h->stream));
+    unsigned mask = 0;
+    HIPCHK(hipMemcpyAsync(&mask, h->d_qhead, sizeof mask, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->nqueues = 0;
+    for (int i = 0; i < 16; ++i) h->xcc_queue[i] = (mask >> i & 1u) ? h->nqueues++ : -1;
+    if (h->nqueues == 0) h->multistep = false;
+  }
   HIPCHK(hipMalloc(&h->d_params, sizeof(mckpp_kparams)));
   h->scratch_doubles = mckpp_ps_scratch_doubles(nzp1, h->ext_kernel ? (c->LDD ? 2 : 1) : 0, h->num_cu);
   HIPCHK(hipMalloc(&h->d_scratch, h->scratch_doubles * sizeof(double)));
@@ -303,6 +318,7 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
     if (const char *e = getenv("MCKPP_L2PRE")) h->l2pre = (atoi(e) != 0 && !c->LDD) ? 1 : 0;
     if (const char *e = getenv("MCKPP_L3_CAP")) h->l3cap = atoi(e) > 0 ? atoi(e) : 0;
     h->solver_mode = solver_mode_env;
+    if (const char *e = getenv("MCKPP_MULTISTEP")) h->multistep = atoi(e) != 0 && h->nqueues > 0;
   }
   {
     std::vector<double> dm(ldc, 0.0), hs(ldc, 0.0);
@@ -380,6 +396,8 @@ static void free_state(mckpp_hip_ctx *h)
   h->d_cs = nullptr; h->d_ci = nullptr; h->d_ipt = nullptr; h->d_stage = nullptr;
   h->stage_elems = 0;
   for (int b = 0; b < 2; ++b) { if (h->d_xfer[b]) hipFree(h->d_xfer[b]); h->d_xfer[b] = nullptr; h->xfer_elems[b] = 0; }
+  if (h->d_done) hipFree(h->d_done);
+  h->d_done = nullptr;
   if (h->d_pack) hipFree(h->d_pack);
   if (h->h_pack) hipHostFree(h->h_pack);
   h->d_pack = nullptr; h->h_pack = nullptr;
@@ -816,6 +834,8 @@ static void fill_params(mckpp_hip_ctx *h, mckpp_kparams &p, int ntime, int mode)
   p.Ts[0] = h->d_prof[P_TS0]; p.Ts[1] = h->d_prof[P_TS1]; p.Ss[0] = h->d_prof[P_SS0]; p.Ss[1] = h->d_prof[P_SS1];
   p.U_init = h->d_prof[P_UINIT]; p.V_init = h->d_prof[P_VINIT];
   p.cs = h->d_cs; p.ci = h->d_ci; p.qhead = h->d_qhead; p.dbg = h->d_dbg;
+  p.nsteps_launch = 1; p.done = h->d_done; p.nqueues = h->nqueues; p.qowner = h->d_qhead + 16;
+  for (int i = 0; i < 16; ++i) p.xcc_queue[i] = h->xcc_queue[i];
   p.ext = h->ext_kernel ? 1 : 0;
   p.L_RELAX_SST = h->c.L_RELAX_SST; p.L_RELAX_CALCONLY = h->c.L_RELAX_CALCONLY; p.L_FCORR = h->c.L_FCORR;
   p.L_FCORR_WITHZ = h->c.L_FCORR_WITHZ; p.L_SFCORR = h->c.L_SFCORR; p.L_SFCORR_WITHZ = h->c.L_SFCORR_WITHZ;
@@ -854,6 +874,31 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode, const forced_r
     HIPCHK(hipEventRecord(h->ev_params[slot], h->stream));
   }
   HIPCHK(hipEventRecord(h->ev0, h->stream));
+  // Several steps of constant forcing (mckpp_hip_step with nsteps > 1): ONE launch takes every column through all of
+  // them - ncol x nsteps tickets, a column's step waiting only for that column's previous step (k_column_ps, M0) -
+  // instead of a launch per step, each of which would wait for its slowest column.  Same results bit for bit (the
+  // columns are independent; every step still stores its outputs and diagnostics).  Not for the forced run (its
+  // fluxes kernel rewrites every column's forcing between the steps), nor for a step at ntime = 0.
+  if (mode == MCKPP_MODE_STEP && !forced && nsteps > 1 && ntime >= 1 && h->multistep) {
+    if (!h->d_done) HIPCHK(hipMalloc(&h->d_done, (size_t)h->ncol * sizeof(int)));
+    const int per_launch = (int)std::max<int64_t>(1, ((int64_t)1 << 30) / h->ncol);   // tickets are 32-bit (per queue: fewer still)
+    for (int i = 0; i < nsteps; i += per_launch) {
+      const int n = nsteps - i < per_launch ? nsteps - i : per_launch;
+      const unsigned slot = h->params_seq++ & 1u;   // this launch's parameter block (its step count differs from the call's first)
+      HIPCHK(hipEventSynchronize(h->ev_params[slot]));
+      fill_params(h, h->h_params[slot], ntime + i, mode);
+      h->h_params[slot].nsteps_launch = n;
+      HIPCHK(hipMemcpyAsync(h->d_params, &h->h_params[slot], sizeof(mckpp_kparams), hipMemcpyHostToDevice, h->stream));
+      HIPCHK(hipEventRecord(h->ev_params[slot], h->stream));
+      HIPCHK(hipMemsetAsync(h->d_qhead, 0, 32 * sizeof(int), h->stream));
+      HIPCHK(hipMemsetAsync(h->d_done, 0, (size_t)h->ncol * sizeof(int), h->stream));
+      HIPCHK(mckpp_launch_column_kernel_ps(h->h_params[slot], h->d_params, h->num_cu, h->stream, &h->last_launch));
+    }
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->nlaunch = nsteps;   // (mckpp_hip_last_kernel_ms: time per STEP, whatever the number of launches)
+    h->timed = true;
+    return 0;
+  }
   for (int i = 0; i < nsteps; ++i) {
     mckpp_kparams p;
     fill_params(h, p, ntime + i, mode);
@@ -985,6 +1030,8 @@ int mckpp_hip_last_kernel_ms(mckpp_hip_handle h, double *ms, int32_t *nlaunch)
   if (nlaunch) *nlaunch = h->nlaunch;
   return 0;
 }
+
+int32_t mckpp_hip_last_launch_count(mckpp_hip_handle h) { return h && h->timed ? h->nkernels : 0; }
 
 // What a download moves, as a list: every row field of `mask` whose host pointer is set - the device rows it
 // comes from (of THIS context), the offset of its first element in them, its number of levels, and where it goes

@@ -626,6 +626,52 @@ def test_config4_100_levels_slice(mk):
     ctx.close()
 
 
+@pytest.mark.parametrize("ncol,nz,nsteps", [(64, 40, 12), (1, 60, 5), (9000, 60, 8), (700, 100, 6), (30000, 60, 5)])
+def test_several_steps_in_one_launch_equal_a_launch_per_step(mk, monkeypatch, ncol, nz, nsteps):
+    """mckpp_hip_step(nt, n > 1) is ONE launch that takes every column through all n steps, a column's step waiting
+    only for that column's previous step (no barrier across the chip between steps; k_column_ps M0, tickets in
+    step-major order).  Same results as a launch per step, bit for bit - state, saved levels, diagnostics, status and
+    pass counts of the last step - from the analytic start, whose second step has thousands of columns at itermax (so
+    that columns of several steps are in flight together), down to fewer columns than the chip has slots (a column's
+    next ticket is drawn while its previous step still runs: the waiting-ticket path) and a single column."""
+    res = {}
+    for tag, env in (("one launch", "1"), ("launch per step", "0")):
+        monkeypatch.setenv("MCKPP_MULTISTEP", env)
+        kc, k3 = cm.make_hip_case(ncol, nz)
+        ctx = mk.MckppHip(kc)
+        ctx.upload(k3)
+        ctx.init_ocean(0)
+        cm.set_forcing_3d(k3, cm.synth.forcing(ncol, "bench"))
+        ctx.set_forcing(k3.sflux)
+        ctx.step(1, nsteps)
+        ctx.download(k3)
+        st, nf, npass = ctx.status()
+        res[tag] = (k3, st.copy(), npass.copy())
+        ctx.close()
+    a, b = res["one launch"], res["launch per step"]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    for name in ("U", "X", "Us", "Xs", "hmixd", "hmix", "kmix", "Tref", "uref", "vref", "Ssurf", "old", "new_", "rho", "cp", "buoy",
+                 "difm", "difs", "dift", "ghat", "wU", "wX", "wXNT", "Rig", "dbloc", "Shsq"):
+        x, y = np.asarray(getattr(a[0], name)), np.asarray(getattr(b[0], name))
+        assert np.array_equal(x, y, equal_nan=True), name
+    if ncol >= 700:   # and against the oracle stepping one step at a time, on a sample
+        from oracle import orc
+
+        idx = np.arange(0, ncol, max(1, ncol // 60))
+        oc, ob = cm.make_oracle(len(idx), nz, exp_mode=1, index=idx, ntotal=ncol)
+        for nt in range(1, nsteps + 1):
+            orc.physics_driver(oc, ob, nt)
+
+        class _Sub:
+            pass
+
+        sub = _Sub()
+        for n in ("U", "X", "Us", "Xs", "hmixd", "hmix", "kmix", "Tref", "uref", "vref", "Ssurf", "reset_flag"):
+            setattr(sub, n, getattr(a[0], n)[idx])
+        _assert_bitexact(cm.compare(sub, ob, nz, cm.PROFILE_FIELDS + cm.SCALAR_FIELDS + ["hmixd0", "hmixd1"]), "several steps in one launch")
+        assert np.array_equal(a[2][idx], ob["npasses"])
+
+
 # ---- shapes of the column kernel ---------------------------------------------------------------
 # One kernel (k_column_ps) serves every depth: its level phases loop over (slot, level) items, so the shape of
 # a workgroup (slots, waves, trips of the item loop) changes with nz.  The cases below straddle those changes.
