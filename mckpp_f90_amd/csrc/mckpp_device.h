@@ -67,6 +67,10 @@ struct mckpp_kparams_t {
   int nsteps_launch;   // model steps this launch takes every column through (1: the step-per-launch path)
   int nqueues;         // nsteps_launch > 1: queues = XCDs of the device (qhead[0..nqueues-1]); column c is in queue c mod nqueues
   int xcc_queue[16];   // hardware XCC id -> queue index
+  // forced run in one launch (mckpp_hip_run_forced): the flux records and how a step finds its own
+  P<const double> series;   // [nrec][8][ncol]: taux, tauy, swf, lwf, lhf, shf, rain, snow; null: the forcing is what cs holds
+  int series_rec0, ndtocn, l_rest;
+  double flsn, el;
   P<int> qowner;  // [16] per queue: 0 free, else hardware XCC id + 1 of the XCD whose workgroups serve it (zeroed per launch)
   P<int> done;    // [ncol] steps of this launch a column has completed (zeroed per launch; nsteps_launch > 1 only)
   P<unsigned long long> dbg;   // optional [32] phase-cycle accumulators (diagnostic builds of a run only)

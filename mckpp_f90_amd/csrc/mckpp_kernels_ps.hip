@@ -1079,8 +1079,28 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           s_flags[3] = nz;   // no guess for a new column: L3 forms the bulk Richardson numbers of every level
           msc[C_F] = cs[CS_F]; msc[C_WXNT0] = 0.0; msc[C_HMIXE] = 0.0; msc[C_HMIXN] = 0.0;
           msc[C_SREF] = cs[CS_SREF]; msc[C_SSURF] = cs[CS_SSURF]; msc[C_OCDEPTH] = cs[CS_OCDEPTH];
-          msc[C_SFLUX1] = cs[CS_SFLUX1]; msc[C_SFLUX2] = cs[CS_SFLUX2]; msc[C_SFLUX3] = cs[CS_SFLUX3];
-          msc[C_SFLUX4] = cs[CS_SFLUX4]; msc[C_SFLUX5] = cs[CS_SFLUX5]; msc[C_SFLUX6] = cs[CS_SFLUX6];
+          double s1 = cs[CS_SFLUX1], s2 = cs[CS_SFLUX2], s3 = cs[CS_SFLUX3], s4 = cs[CS_SFLUX4], s5 = cs[CS_SFLUX5], s6 = cs[CS_SFLUX6];
+          if (multi && p.series && (p.ntime + step - 1) % p.ndtocn == 0 && ci[CI_LOCEAN]) {
+            // the forced run in one launch: this step is a flux update (mckpp_ocean_model_3D.F90:44-48) - mckpp_fluxes'
+            // assembly of sflux(1:6) (fluxes_mod.F90:55-77; k_fluxes of the launch-per-step path, same operations) from
+            // the step's record, kept in the column's record for the steps until the next update and for the host
+            const auto f8 = p.series + (size_t)((p.ntime + step - 1) / p.ndtocn - p.series_rec0) * 8 * (size_t)p.ncol + c;
+            const size_t n = (size_t)p.ncol;
+            double taux = f8[0];
+            const double tauy = f8[n], swf = f8[2 * n], lwf = f8[3 * n], lhf = f8[4 * n], shf = f8[5 * n], rain = f8[6 * n], snow = f8[7 * n];
+            if ((taux == 0.0) && (tauy == 0.0)) taux = 1.e-10;
+            if (!p.l_rest) {
+              s1 = taux; s2 = tauy; s3 = swf;
+              s4 = lwf + lhf + shf - snow * p.flsn;
+              s5 = 1e-10;
+              s6 = rain + snow + (lhf / p.el);
+            } else {
+              s1 = 1.e-10; s2 = 0.00; s3 = 300.00; s4 = -300.00; s5 = 0.00; s6 = 0.00;
+            }
+            cs[CS_SFLUX1] = s1; cs[CS_SFLUX2] = s2; cs[CS_SFLUX3] = s3; cs[CS_SFLUX4] = s4; cs[CS_SFLUX5] = s5; cs[CS_SFLUX6] = s6;
+          }
+          msc[C_SFLUX1] = s1; msc[C_SFLUX2] = s2; msc[C_SFLUX3] = s3;
+          msc[C_SFLUX4] = s4; msc[C_SFLUX5] = s5; msc[C_SFLUX6] = s6;
           {   // (M3 evaluates swfrac at -hbl in every pass: its constants from LDS, not through a memory round trip)
             const int jw = ci[CI_JERLOV];
             msc[C_JRFAC] = jer_rfac_c[jw]; msc[C_JA1] = jer_a1_c[jw]; msc[C_JA2] = jer_a2_c[jw];

@@ -877,9 +877,9 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode, const forced_r
   // Several steps of constant forcing (mckpp_hip_step with nsteps > 1): ONE launch takes every column through all of
   // them - ncol x nsteps tickets, a column's step waiting only for that column's previous step (k_column_ps, M0) -
   // instead of a launch per step, each of which would wait for its slowest column.  Same results bit for bit (the
-  // columns are independent; every step still stores its outputs and diagnostics).  Not for the forced run (its
-  // fluxes kernel rewrites every column's forcing between the steps), nor for a step at ntime = 0.
-  if (mode == MCKPP_MODE_STEP && !forced && nsteps > 1 && ntime >= 1 && h->multistep) {
+  // columns are independent; every step still stores its outputs and diagnostics).  The forced run too: a step
+  // that is a flux update assembles its column's forcing from the resident record itself.  Not for a step at ntime = 0.
+  if (mode == MCKPP_MODE_STEP && nsteps > 1 && ntime >= 1 && h->multistep) {
     if (!h->d_done) HIPCHK(hipMalloc(&h->d_done, (size_t)h->ncol * sizeof(int)));
     const int per_launch = (int)std::max<int64_t>(1, ((int64_t)1 << 30) / h->ncol);   // tickets are 32-bit (per queue: fewer still)
     for (int i = 0; i < nsteps; i += per_launch) {
@@ -888,6 +888,11 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode, const forced_r
       HIPCHK(hipEventSynchronize(h->ev_params[slot]));
       fill_params(h, h->h_params[slot], ntime + i, mode);
       h->h_params[slot].nsteps_launch = n;
+      if (forced) {   // the forced run: every step finds its flux record itself (k_column_ps, M0)
+        mckpp_kparams &q = h->h_params[slot];
+        q.series = h->d_series; q.series_rec0 = h->series_rec0; q.ndtocn = forced->ndtocn; q.l_rest = forced->l_rest;
+        q.flsn = forced->flsn; q.el = forced->el;
+      }
       HIPCHK(hipMemcpyAsync(h->d_params, &h->h_params[slot], sizeof(mckpp_kparams), hipMemcpyHostToDevice, h->stream));
       HIPCHK(hipEventRecord(h->ev_params[slot], h->stream));
       HIPCHK(hipMemsetAsync(h->d_qhead, 0, 32 * sizeof(int), h->stream));
