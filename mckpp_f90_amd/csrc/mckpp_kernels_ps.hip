@@ -1012,8 +1012,20 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       st = msi[I_STATE];
       if (st == PS_ACTIVE && msi[I_FIN] == F_FINAL) st = PS_EMPTY;   // its outputs are stored (barrier before M0)
       if (st == PS_WAIT) { c = msi[I_COL]; step = msi[I_STEP]; want = true; }
-      if (st == PS_EMPTY) {
-        msi[I_FIN] = F_NONE;
+    }
+    // Refills come in rounds.  A workgroup's slots that start together finish together - every column takes the
+    // same six passes in the steady state - and each refill costs the whole workgroup a finish round, a pass that
+    // forms every level's Richardson numbers (no guess for a new column) and a cold L1; a slot that finishes out of
+    // step - its column needed seven passes, or two hundred - would from then on cause all that in a pass of its
+    // own, for the rest of the launch (a launch of ten steps measured 7.5 ms per step at 100 levels where its steps
+    // one by one took 6.0).  So a slot that comes free alone waits, empty, for the next round: slots are refilled
+    // when at least half of them are free, or when none is left working.
+    const int n_empty = __popcll(__ballot(lane < W && st == PS_EMPTY));
+    const int n_busy = __popcll(__ballot(lane < W && st == PS_ACTIVE));
+    const bool refill = 2 * n_empty >= W || n_busy == 0;
+    if (lane < W) {
+      if (st == PS_EMPTY) { msi[I_FIN] = F_NONE; msi[I_ACT] = 0; }
+      if (st == PS_EMPTY && refill) {
         if (!multi) {
           const int t = atomicAdd((int *)p.qhead, 1);
           if (t >= p.ncol) { st = PS_DONE; msi[I_ACT] = 0; }

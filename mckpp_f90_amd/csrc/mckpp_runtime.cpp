@@ -901,6 +901,7 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode, const forced_r
     }
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     h->nlaunch = nsteps;   // (mckpp_hip_last_kernel_ms: time per STEP, whatever the number of launches)
+    h->nkernels = (nsteps + per_launch - 1) / per_launch;
     h->timed = true;
     return 0;
   }
@@ -917,6 +918,7 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode, const forced_r
   }
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   h->nlaunch = nsteps;
+  h->nkernels = nsteps;
   h->timed = true;
   return 0;
 }
