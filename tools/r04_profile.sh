@@ -11,9 +11,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 be
 echo "stats done"
 SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
 SQ2="SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS"
-for cfg in 60:0 60:1 69s:0 69s:1 100:0 100:1; do
+for cfg in 60:0 60:1 69s:0 69s:1 69sfree:0 100:0 100:1; do
   IFS=: read shape sm <<< "$cfg"
-  if [ "$shape" = "69s" ]; then args="--nz 69 --grid stretched --dto 1200 --land 0.35"; else args="--nz $shape"; fi
+  unset MCKPP_PS_CONFLICT_FREE
+  if [ "$shape" = "69s" ]; then args="--nz 69 --grid stretched --dto 1200 --land 0.35";
+  elif [ "$shape" = "69sfree" ]; then args="--nz 69 --grid stretched --dto 1200 --land 0.35"; export MCKPP_PS_CONFLICT_FREE=1;   # the slot stride without bank conflicts (experiment)
+  else args="--nz $shape"; fi
   export MCKPP_SOLVER_MODE=$sm
   B="python3 bench.py --steps 3 --warmup 2 --settle 0 --no-cpu-baseline --no-extras $args"
   t=${shape}_sm$sm
@@ -23,7 +26,7 @@ for cfg in 60:0 60:1 69s:0 69s:1 100:0 100:1; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write_$t -- $B > $OUT/write_$t.json 2> $OUT/write_$t.err
   echo "pmc $t done"
 done
-unset MCKPP_SOLVER_MODE
+unset MCKPP_SOLVER_MODE MCKPP_PS_CONFLICT_FREE
 python3 tools/r04_profile_digest.py $OUT
 find $OUT -name "*.csv" -size +3M -delete
 du -sh $OUT

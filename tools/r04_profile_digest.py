@@ -24,11 +24,12 @@ except Exception as e:   # noqa: BLE001
     res["build_id"] = f"unknown ({e})"
 res["collected"] = "rocprofv3 --kernel-trace --pmc <counters> (separate passes: two SQ groups, FETCH_SIZE, WRITE_SIZE) on bench.py --steps 3 --warmup 2 --settle 0 --no-extras --no-cpu-baseline (MCKPP_SOLVER_MODE per record), last column-kernel dispatch; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B), KB x 1024"
 
-for shape, nz, sm in (("60", 60, 0), ("60", 60, 1), ("69s", 69, 0), ("69s", 69, 1), ("100", 100, 0), ("100", 100, 1)):
+for shape, nz, sm in (("60", 60, 0), ("60", 60, 1), ("69s", 69, 0), ("69s", 69, 1), ("69sfree", 69, 0), ("100", 100, 0), ("100", 100, 1)):
     t = f"{shape}_sm{sm}"
     rec = {"ncol": 100000, "nz": nz, "solver_mode": sm, "passes_per_column": 6.0}
-    if shape == "69s":
-        rec["shape"] = "stretched grid, 35 % land (65,000 ocean columns), dto 1200 s"
+    if shape.startswith("69s"):
+        rec["shape"] = "stretched grid, 35 % land (65,000 ocean columns), dto 1200 s" + (
+            "; MCKPP_PS_CONFLICT_FREE=1 (slot stride without LDS bank conflicts in the level-major phases: experiment)" if shape == "69sfree" else "")
     for tag in ("sq1", "sq2", "fetch", "write"):
         files = find(f"{tag}_{t}/**/*counter_collection.csv")
         if not files:
