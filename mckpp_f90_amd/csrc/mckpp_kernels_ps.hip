@@ -38,7 +38,10 @@ enum {
   C_SREF = C_DKM1 + 3, C_SSURF, C_OCDEPTH, C_SFLUX1, C_SFLUX2, C_SFLUX3, C_SFLUX4, C_SFLUX5, C_SFLUX6,
   C_T1X /* + parity: the level-1 temperature of the iterate, for the two EOS items */,
   C_JRFAC = C_T1X + 2, C_JA1, C_JA2, C_JRA1, C_JRA2 /* the column's Jerlov constants (swfrac_mod.F90:59-61), fetched once per column */,
-  C_COUNT
+  C_COUNT_USED,
+  // the manager's lanes read one field of fifteen records at once: an ODD record length spreads them over the banks
+  // (52 doubles put eight lanes on every bank: 8x the bank-conflict cycles of round 3's 47, profiles/r04)
+  C_COUNT = C_COUNT_USED | 1
 };
 // per-slot int record
 enum {
@@ -47,7 +50,8 @@ enum {
   I_KBLC, I_NVIOL, I_NOVER, I_NU, I_NV, I_NF, I_BAD, I_L1A /* L1 but for V done ahead, during the V sweep */,
   I_MAYBE_NEXT, I_LOCEAN, I_PAR /* which C_T1X holds the iterate's level-1 temperature */,
   I_TINY /* some whole-layer term of the reference-level sums is a tiny non-zero number (L2) */,
-  I_STEP /* which step of the launch this column is in (0 .. nsteps_launch-1) */, I_COUNT
+  I_STEP /* which step of the launch this column is in (0 .. nsteps_launch-1) */, I_COUNT_USED,
+  I_COUNT = I_COUNT_USED | 1   // odd, like C_COUNT: 32 ints would put every lane's record on the same two banks
 };
 // LDS rows of a slot and what each holds between which phases of a pass:
 //   Q_DM   (LDD talpha L1..L2; else the whole-layer terms of the reference-level sum of U, L2)  difm: interior L3;

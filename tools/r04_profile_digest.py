@@ -44,8 +44,16 @@ for shape, nz, sm in (("60", 60, 0), ("60", 60, 1), ("69s", 69, 0), ("69s", 69, 
                 rec[r["Counter_Name"]] = float(r["Counter_Value"])
                 name = r["Kernel_Name"]
                 rec["kernel_symbol"] = name[:120]
+    nsteps = 1
     try:
         j = json.loads(open(os.path.join(out, f"sq1_{t}.json")).read().strip().splitlines()[-1])
+        # the timed region of the counter runs is ONE dispatch of `steps` model steps (mckpp_hip_step(nt, n)): the
+        # counters of that dispatch are divided by its steps, so that every figure is per model step like round 3's
+        nsteps = max(1, j["steps"] // max(1, j["roofline"].get("kernel_launches_in_the_timed_region", j["steps"])))
+        rec["steps_in_the_dispatch"] = nsteps
+        for k in list(rec):
+            if k.startswith("SQ_") or k in ("FETCH_SIZE", "WRITE_SIZE"):
+                rec[k] = rec[k] / nsteps
         rec["kernel"] = j["roofline"]["kernel"].split(" ")[0]
         rec["algorithmic_bytes_per_launch"] = j["roofline"]["algorithmic_bytes_per_launch"]
         rec["ocean_columns"] = j["config"]["ocean_columns_per_gpu"]
