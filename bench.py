@@ -27,8 +27,8 @@ plus (N=1 only, never part of `value`):
                        eliminated from both ends at once; `value` itself is the reference-order solver)
   config1_pass         BASELINE configs[1]: 1e4 x 60, one kppmix + tridiagonal pass per launch (mckpp_hip_vmix_pass),
                        with its own algorithmic bytes per column-pass
-  tail                 the headline columns with 1 % of them knocked out of balance (storm forcing switched on at
-                       the timed steps): the data-dependent tail of the iteration in a timed region
+  tail                 24 steps of the settled headline run, a launch per step with the pass counts of each (one step
+                       in seven has a column at itermax: the data-dependent tail), and the same steps as one launch
   drop_in              the reference-shaped host loop through the C-ABI, per step: mckpp_hip_set_forcing +
                        mckpp_hip_step + mckpp_hip_download of the scalar group / the restart set / every
                        field (PCIe-inclusive; never `value`)
@@ -235,9 +235,8 @@ def side_shape(mk, cm, ncol, nz, grid, dto, land_frac, steps, warmup, diag, dev_
 
 def headline_variant(mk, cm, ncol, nz, idx, ntotal, a, dev_index, solver_mode=0, tail_frac=0.0):
     """The headline workload once more in a context of its own: spin-up, warmup and settle steps as the headline,
-    then a timed region - with another solver mode, or (tail_frac > 0) with that fraction of the columns knocked out
-    of balance at the timed steps (storm forcing: taux 1.0 N/m2, 1200 W/m2 of surface cooling, no sun), so that the
-    iteration's data-dependent tail - tens of passes, the instability trap - is inside a timed region."""
+    then a timed region - with another solver mode, or (tail_frac > 0) stepped one launch at a time with the pass
+    counts of every step, so that the iteration's data-dependent tail is inside a timed region and visible."""
     kc, k3 = cm.make_hip_case(ncol, nz, grid=a.grid, dto=a.dto, index=idx, ntotal=ntotal)
     ctx = mk.MckppHip(kc, device=dev_index)
     ctx.set_solver_mode(solver_mode)
@@ -260,39 +259,46 @@ def headline_variant(mk, cm, ncol, nz, idx, ntotal, a, dev_index, solver_mode=0,
                "kernel_avg_ms": kern_s * 1e3, "roofline_frac": balg * nocean / kern_s / 1e9 / HBM_PEAK_GBS,
                "mean_passes_per_column_step_last_step": float(npass.mean()), "flagged_columns_last_step": int(nflag)}
     else:
-        # the hit columns' OLD time level goes back to the analytic start profile, so that the extrapolated first guess
-        # of their iteration is far off, and they get storm forcing on top
-        every = max(1, int(round(1.0 / tail_frac)))
-        hit = np.arange(ncol) % every == every // 2
-        ctx.download(k3, mk.api.F_RESTART)
-        zm = cm.grid_for(nz, a.grid)[0]
-        col = cm.synth.columns(ncol, nz, zm=zm, index=idx, ntotal=ntotal)
-        hidx = np.nonzero(hit)[0]
-        for l, (u, x) in enumerate((("U", "T"), ("V", "S"))):
-            # the OLD time level goes back to the analytic start, the new one stays: the step's first guess,
-            # 2 Xs(new) - Xs(old) (ocnstep_mod.F90:91-112), is then far from anything the forcing supports
-            k3.Us[hidx, :, l, k3.old[hidx]] = col[u][hit]
-            k3.Xs[hidx, :, l, k3.old[hidx]] = col[x][hit]
-        ctx.upload(k3)
-        sf[hit, 0] = 1.0; sf[hit, 2] = 0.0; sf[hit, 3] = -1200.0; sf[hit, 5] = 6e-5 - 1200.0 / cm.synth.EL
-        cm.set_forcing_3d(k3, sf)
-        ctx.set_forcing(k3.sflux)
-        ctx.synchronize()
+        # The data-dependent tail of the iteration, as the workload itself produces it: in a long run one step in seven
+        # has a column that iterates to itermax (200 passes where the others take 6).  24 steps, first a launch per
+        # step with the pass counts read after each (what a host that touches the state between steps gets), then -
+        # in a second context brought to the same state - the same 24 steps as ONE launch (mckpp_hip_step(nt, 24)).
+        # (Knocking columns out of balance does not produce a tail: 1 % of the columns with their old time level
+        # pushed 3 m/s and 5 K away from the new one and storm forcing on top converged in 8.4 passes on average,
+        # 12 at most - measured, r04.)
+        nsingle = 24
         per_step, tsum, ksum = [], 0.0, 0.0
-        for _ in range(6):
+        for _ in range(nsingle):
             dt, kern_s = time_steps(ctx, nt, 1, lambda: None)
             nt += 1
             st, nflag, npass = ctx.status()
             tsum += dt; ksum += kern_s
-            per_step.append({"ms": dt * 1e3, "mean_passes": float(npass.mean()), "max_passes": int(npass.max()),
-                             "mean_passes_of_the_hit_columns": float(npass[hit].mean()),
-                             "columns_with_status_bits": int(nflag), "trap_fired": int(((st & 4) != 0).sum())})
-        out = {"value": nocean * 6 / tsum, "unit": "column-steps/s", "ms_per_step": tsum / 6 * 1e3, "steps": 6,
-               "kernel_avg_ms": ksum / 6 * 1e3, "columns_hit": int(hit.sum()),
-               "column_passes_per_s": sum(p["mean_passes"] for p in per_step) * nocean / tsum, "per_step": per_step,
-               "what": f"every {every}th column has its old time level put back to the analytic start profile (its iteration "
-                       "starts from 2 Xs(new) - Xs(old)) and gets storm forcing from the first timed step on; six single-step "
-                       "launches, status read after each (outside the timing)"}
+            per_step.append({"ms": round(dt * 1e3, 3), "mean_passes": float(npass.mean()), "max_passes": int(npass.max()),
+                             "columns_over_12_passes": int((npass > 12).sum()), "trap_fired": int(((st & 4) != 0).sum())})
+        ctx.close()
+        kc, k3 = cm.make_hip_case(ncol, nz, grid=a.grid, dto=a.dto, index=idx, ntotal=ntotal)
+        ctx = mk.MckppHip(kc, device=dev_index)
+        ctx.upload(k3)
+        ctx.set_diagnostics(a.diag)
+        ctx.init_ocean(0)
+        cm.set_forcing_3d(k3, sf)
+        ctx.set_forcing(k3.sflux)
+        ctx.step(1, SPINUP + a.warmup + a.settle)
+        ctx.synchronize()
+        dt1, kern1 = time_steps(ctx, 1 + SPINUP + a.warmup + a.settle, nsingle, lambda: None)
+        slow = [p for p in per_step if p["max_passes"] > 50]
+        out = {"value": nocean * nsingle / tsum, "unit": "column-steps/s", "ms_per_step": tsum / nsingle * 1e3, "steps": nsingle,
+               "kernel_avg_ms": ksum / nsingle * 1e3,
+               "column_passes_per_s": sum(p["mean_passes"] for p in per_step) * nocean / tsum,
+               "steps_with_a_column_over_50_passes": len(slow),
+               "ms_of_those_steps": [p["ms"] for p in slow],
+               "ms_of_the_other_steps_mean": float(np.mean([p["ms"] for p in per_step if p["max_passes"] <= 50])),
+               "max_passes": max(p["max_passes"] for p in per_step),
+               "the_same_steps_as_one_launch": {"value": nocean * nsingle / dt1, "ms_per_step": dt1 / nsingle * 1e3,
+                                                "kernel_avg_ms": kern1 * 1e3},
+               "per_step": per_step,
+               "what": f"model steps {nt - nsingle}-{nt - 1} of the headline run, a launch per step (status read after each, outside "
+                       "the timing), and again in a second context as one launch of all of them"}
     ctx.close()
     del ctx, k3, kc
     gc.collect()
@@ -429,6 +435,12 @@ def single_process_block(mk, cm, sharding, kc_args, ncol_per_gpu, world, devices
 
     ntotal = strong_total if strong_total else ncol_per_gpu * world
     note = None
+    # bounded: this block runs on rank 0 while the other ranks wait, inside the driver's time limit for the whole
+    # line - at 8 GPUs the ranks' 8e5 columns would be 23 GB of host arrays and ~25 s of uploads through one process
+    cap = 200000
+    if ntotal > cap:
+        ntotal = cap
+        note = f"{cap} columns in all ({cap // world} per GPU) instead of the ranks' total: bounded run time"
     need = ntotal * (kc_args["nz"] + 1) * 8 * 60          # host arrays of Kpp3dFields, generously
     avail = psutil.virtual_memory().available
     if need > 0.4 * avail:
@@ -492,6 +504,8 @@ def main():
     ap.add_argument("--sustained-steps", type=int, default=400)
     ap.add_argument("--settle", type=int, default=SETTLE,
                     help="untimed steps of the same work before the timed region (0: time the cold device's burst)")
+    ap.add_argument("--legs", default="all", help="comma list of the extra legs to run (two_ended_solver, tail, config1_pass, ...): "
+                                                 "for experiments; default all")
     ap.add_argument("--print-launch", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
 
@@ -691,6 +705,19 @@ def main():
         barrier()
 
     extras = world == 1 and not a.no_extras
+    if extras and a.legs != "all":   # experiments: only the named legs of the second block below
+        ctx.close()
+        del ctx, k3, kc
+        gc.collect()
+        legs = a.legs.split(",")
+        if "two_ended_solver" in legs:
+            out["two_ended_solver"] = headline_variant(mk, cm, ncol, nz, idx, ntotal, a, dev_index, solver_mode=1)
+        if "tail" in legs:
+            out["tail"] = headline_variant(mk, cm, ncol, nz, idx, ntotal, a, dev_index, tail_frac=0.01)
+        if "config1_pass" in legs:
+            out["config1_pass"] = config1_pass(mk, cm, dev_index, a)
+        print(json.dumps(out), flush=True)
+        return
     if extras:
         nt_s = nt_next - 1
         # ---- drop-in host loop: forcing up, one step, field groups down, every step ----

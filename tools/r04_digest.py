@@ -14,8 +14,9 @@ for k in ("two_ended_solver", "sustained"):
         print(f"  {k}: {d[k]['value']:.4g}, {d[k]['ms_per_step']:.3f} ms/step" + (f", x{d[k]['config']['ratio_to_value']:.3f} of value" if k == "two_ended_solver" else ""))
 if "tail" in d:
     t = d["tail"]
-    print(f"  tail: {t['value']:.4g} column-steps/s, {t['column_passes_per_s']:.4g} column-passes/s; per step (ms, mean, max passes, trap): "
-          + "; ".join(f"{p['ms']:.2f} {p['mean_passes']:.2f} {p['max_passes']} {p['trap_fired']}" for p in t["per_step"]))
+    print(f"  tail: a launch per step {t['value']:.4g} ({t['ms_per_step']:.3f} ms/step; {t['steps_with_a_column_over_50_passes']} of {t['steps']} steps "
+          f"have a column over 50 passes: {t['ms_of_those_steps']} ms, the others {t['ms_of_the_other_steps_mean']:.3f}); the same steps as one launch "
+          f"{t['the_same_steps_as_one_launch']['value']:.4g} ({t['the_same_steps_as_one_launch']['ms_per_step']:.3f} ms/step)")
 if "config1_pass" in d:
     c = d["config1_pass"]
     print(f"  configs[1]: {c['value']:.4g} column-passes/s, kernel {c['kernel_avg_ms']:.4f} ms, roofline frac {c['roofline']['frac']:.4f}")
