@@ -1023,10 +1023,11 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     // step - its column needed seven passes, or two hundred - would from then on cause all that in a pass of its
     // own, for the rest of the launch (a launch of ten steps measured 7.5 ms per step at 100 levels where its steps
     // one by one took 6.0).  So a slot that comes free alone waits, empty, for the next round: slots are refilled
-    // when at least half of them are free, or when none is left working.
+    // when at least half of those that take part in the rounds are free - a column past its twelfth pass does not
+    // (it is on its way to itermax: nobody waits for it, and when it ends its slot waits for the others).
     const int n_empty = __popcll(__ballot(lane < W && st == PS_EMPTY));
-    const int n_busy = __popcll(__ballot(lane < W && st == PS_ACTIVE));
-    const bool refill = 2 * n_empty >= W || n_busy == 0;
+    const int n_busy = __popcll(__ballot(lane < W && st == PS_ACTIVE && sirec[lane * I_COUNT + I_NPASS_TRY] <= 12));
+    const bool refill = 2 * n_empty >= n_empty + n_busy;
     if (lane < W) {
       if (st == PS_EMPTY) { msi[I_FIN] = F_NONE; msi[I_ACT] = 0; }
       if (st == PS_EMPTY && refill) {
