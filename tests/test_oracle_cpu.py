@@ -207,6 +207,70 @@ def test_exp_mode_only_changes_last_bits():
         assert d.max() < 1e-10, (k, d.max())
 
 
+@pytest.mark.parametrize("nz", [1, 2, 3, 5, 40, 61])
+def test_two_ended_elimination_solves_the_same_system(nz):
+    """orc_tridmat_2e (solver mode 1: levels 1..nz/2 eliminated downward as tridmat does, nz..nz/2+1 upward, a 2x2
+    system in the middle) against tridmat in the reference's order (solvers.F90:112-161): the same system, the
+    same solution to rounding, its upper levels - where a perturbation from the meeting point has decayed - to the
+    bit; a zero pivot met on the way up is reported like one met on the way down."""
+    L = orc.lib()
+    oc = orc.Const(max(nz, 2))
+    rng = np.random.default_rng(nz)
+    n = nz + 4
+    diff = np.zeros(n); diff[1:nz + 1] = rng.uniform(1e-5, 5e-2, nz)
+    cu, cc, cl, rhs, yo, y0, y1, g0, g1 = (np.zeros(n) for _ in range(9))
+    if nz >= 2:
+        L.orc_tridcof(oc.ptr, dp(diff), nz, dp(cu), dp(cc), dp(cl))
+    else:
+        cc[1] = 1.5
+    rhs[1:nz + 1] = 10.0 + rng.normal(size=nz)
+    yo[nz + 1] = 3.25
+    assert L.orc_tridmat(dp(cu), dp(cc), dp(cl), dp(rhs), dp(yo), nz, dp(y0), dp(g0)) == 0
+    assert L.orc_tridmat_2e(dp(cu), dp(cc), dp(cl), dp(rhs), dp(yo), nz, dp(y1), dp(g1)) == 0
+    assert y1[nz + 1] == 3.25
+    res = cc[1:nz + 1] * y1[1:nz + 1]
+    res[1:] += cu[2:nz + 1] * y1[1:nz]
+    res[:-1] += cl[1:nz] * y1[2:nz + 1]
+    assert np.max(np.abs(res - rhs[1:nz + 1])) < 1e-12
+    assert np.max(np.abs(y1[1:nz + 1] - y0[1:nz + 1])) < 1e-13 * np.abs(y0[1:nz + 1]).max()
+    if nz == 1:
+        assert y1[1] == y0[1]
+    if nz >= 40:   # the meeting point's rounding has decayed long before the top of the column
+        assert np.array_equal(y1[1:6], y0[1:6])
+        # a pivot that vanishes in the upward elimination: cc(i) = 0 with cl(i) = 0
+        i = nz - 6
+        cc2, cl2 = cc.copy(), cl.copy()
+        cc2[i] = 0.0; cl2[i] = 0.0
+        assert L.orc_tridmat_2e(dp(cu), dp(cc2), dp(cl2), dp(rhs), dp(yo), nz, dp(y1), dp(g1)) == 1
+        cc2 = cc.copy(); cc2[nz] = 0.0        # its first pivot
+        assert L.orc_tridmat_2e(dp(cu), dp(cc2), dp(cl), dp(rhs), dp(yo), nz, dp(y1), dp(g1)) == 1
+
+
+def test_solver_mode_and_pow_lowering_only_change_last_bits():
+    """The oracle's two switches beside exp_mode: solver_mode=1 (two-ended elimination) and half_pow_mode=1 (wst built
+    with pow(x, .5), as a compiler without amdflang's square-root rewrite of x**(1./2.) lowers lookup_mod.F90:60-62).
+    Both are rounding-level variants: a few steps on the bench columns agree to 1e-12 (the tables over every shape and
+    up to 1000 steps: profiles/r04/parity_tolerance.json)."""
+    a = orc.Const(60)
+    b = orc.Const(60, half_pow_mode=1)
+    assert np.array_equal(a.wmt, b.wmt)
+    d = a.wst != b.wst
+    assert 0 < d.sum() < 200, d.sum()      # (27 entries with this libm, 28 with flang's)
+    assert np.max(np.abs(a.wst[d] - b.wst[d]) / np.abs(a.wst[d])) < 5e-16
+    oc0, r0 = cm.make_oracle(128, 60, exp_mode=1, solver_mode=0)
+    oc1, r1 = cm.make_oracle(128, 60, exp_mode=1, solver_mode=1)
+    oc2, r2 = cm.make_oracle(128, 60, exp_mode=1, solver_mode=0, half_pow_mode=1)
+    for nt in (1, 2, 3):
+        for oc, r in ((oc0, r0), (oc1, r1), (oc2, r2)):
+            orc.physics_driver(oc, r, nt)
+    for r in (r1, r2):
+        assert np.array_equal(r["npasses"], r0["npasses"]) and np.array_equal(r["kmix"], r0["kmix"])
+        m = cm.tolerance_metrics(cm.oracle_state(r, 60), cm.oracle_state(r0, 60))
+        assert m["off_path_columns"] == 0
+        assert all(v["max"] < 1e-12 for v in m["same_path"].values()), m["same_path"]
+    assert not np.array_equal(r1["T"], r0["T"])     # (it IS another order of operations)
+
+
 def test_fluxes_assembly():
     """mckpp_fluxes restatement: defaults of the no-flux-file branch (fluxes_mod.F90:41-49) reproduce
     synth.forcing("baseline"); calm points get taux=1e-10; wXNT follows swdk_opt."""
