@@ -438,7 +438,10 @@ __device__ __forceinline__ void ps_thomas_uts_fwd(int W, double *slots, int SS, 
         ynum = rhs + q * yprev;
         pm1 = p;
       };
-      bool f_in = tiny_nonzero(ynum);   // of the state the next level starts from
+      // (the votes as wave masks, one ballot per compare - each is the compare's own scalar result - so that the trip's
+      // test is scalar arithmetic: a bool carried round the loop comes back as a VGPR and two more vector instructions)
+      auto rare = [&]() { return __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum)) | __builtin_amdgcn_ballot_w64(bet == 0.); };
+      unsigned long long f_in = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum));   // of the state the next level starts from
       {   // two levels per trip; each half's operands are fetched while the other half runs
         int i = 2;
         double a_p = pb[(2) * KS], a_q = qq[(2) * KS], a_r = y[(2) * KS];
@@ -446,18 +449,18 @@ __device__ __forceinline__ void ps_thomas_uts_fwd(int W, double *slots, int SS, 
           const double b_p = pb[(i + 1) * KS], b_q = qq[(i + 1) * KS], b_r = y[(i + 1) * KS];
           const double s_pm1 = pm1, s_bet = bet, s_ynum = ynum;
           level(i, a_p, a_q, a_r, std::false_type{});
-          const bool f_mid = tiny_nonzero(ynum) || bet == 0.;
+          const unsigned long long f_mid = rare();
           level(i + 1, b_p, b_q, b_r, std::false_type{});
-          if (__builtin_expect(__builtin_amdgcn_ballot_w64(f_in || f_mid) != 0ull, 0)) {
+          if (__builtin_expect((f_in | f_mid) != 0ull, 0)) {
             pm1 = s_pm1; bet = s_bet; ynum = s_ynum;
             level(i, a_p, a_q, a_r, std::true_type{});
             level(i + 1, b_p, b_q, b_r, std::true_type{});
           }
-          f_in = tiny_nonzero(ynum) || bet == 0.;
-          if (i + 2 <= nz) { a_p = pb[(i + 2) * KS]; a_q = qq[(i + 2) * KS]; a_r = y[(i + 2) * KS]; }
+          f_in = rare();
+          a_p = pb[(i + 2) * KS]; a_q = qq[(i + 2) * KS]; a_r = y[(i + 2) * KS];   // (i + 2 <= nzp1: inside the rows; unused after the last trip)
         }
         if (i <= nz) {
-          if (__builtin_expect(__builtin_amdgcn_ballot_w64(f_in) != 0ull, 0)) level(i, a_p, a_q, a_r, std::true_type{});
+          if (__builtin_expect(f_in != 0ull, 0)) level(i, a_p, a_q, a_r, std::true_type{});
           else level(i, a_p, a_q, a_r, std::false_type{});
         }
       }
@@ -527,7 +530,8 @@ __device__ __forceinline__ void ps_thomas2_uts_fwd(int W, double *slots, int SS,
         ynum = rhs + mult * yprev;
         carry = DIR > 0 ? p : q;
       };
-      bool f_in = tiny_nonzero(ynum);
+      auto rare = [&]() { return __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum)) | __builtin_amdgcn_ballot_w64(bet == 0.); };   // (as ps_thomas_uts_fwd)
+      unsigned long long f_in = __builtin_amdgcn_ballot_w64(tiny_nonzero(ynum));
       {   // two levels per trip; each half's operands are fetched while the other half runs
         int i = i0 + DIR, left = (DIR > 0 ? m : nz - m) - 1;
         double a_p = 0., a_q = 0., a_r = 0.;
@@ -536,18 +540,18 @@ __device__ __forceinline__ void ps_thomas2_uts_fwd(int W, double *slots, int SS,
           const double b_p = pb[(i + DIR) * KS], b_q = qq[(i + DIR) * KS], b_r = y[(i + DIR) * KS];
           const double s_carry = carry, s_bet = bet, s_ynum = ynum;
           level(i, a_p, a_q, a_r, std::false_type{});
-          const bool f_mid = tiny_nonzero(ynum) || bet == 0.;
+          const unsigned long long f_mid = rare();
           level(i + DIR, b_p, b_q, b_r, std::false_type{});
-          if (__builtin_expect(__builtin_amdgcn_ballot_w64(f_in || f_mid) != 0ull, 0)) {
+          if (__builtin_expect((f_in | f_mid) != 0ull, 0)) {
             carry = s_carry; bet = s_bet; ynum = s_ynum;
             level(i, a_p, a_q, a_r, std::true_type{});
             level(i + DIR, b_p, b_q, b_r, std::true_type{});
           }
-          f_in = tiny_nonzero(ynum) || bet == 0.;
+          f_in = rare();
           if (left >= 3) { a_p = pb[(i + 2 * DIR) * KS]; a_q = qq[(i + 2 * DIR) * KS]; a_r = y[(i + 2 * DIR) * KS]; }
         }
         if (left == 1) {
-          if (__builtin_expect(__builtin_amdgcn_ballot_w64(f_in) != 0ull, 0)) level(i, a_p, a_q, a_r, std::true_type{});
+          if (__builtin_expect(f_in != 0ull, 0)) level(i, a_p, a_q, a_r, std::true_type{});
           else level(i, a_p, a_q, a_r, std::false_type{});
         }
       }
@@ -1176,52 +1180,60 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   };
 
   // M3: boundary-layer depth from the first level with hmin < -zm(k) (bldepth_mod.F90:161-201) and the
-  //     slot-uniform part of blmix (blmix_mod.F90:62-100, 136-149)
+  //     slot-uniform part of blmix (blmix_mod.F90:62-100, 136-149).
+  // One lane per (slot, species): momentum and temperature (= salinity without double diffusion: the same numbers), with
+  // double diffusion all three.  The phase is 600 instructions at six cycles apiece on one wave whatever the number of
+  // lanes, and most of it comes in pairs - swfrac's two exponentials, the two wscale look-ups (sigma = 1 | epsilon and the
+  // grid level above kbl), and per species the gradient of the interior diffusivity at kn, gat1, dat1, dkm1 - so the
+  // lanes of a slot each take one of a pair (the same instructions on their own operands), exchange the three values
+  // the others need through the crossbar, and store their own species' results; what is common to the species every
+  // lane forms for itself.  Same operations on the same operands as one lane per slot.
   auto M3 = [&]() {
     int lane = lane_k; asm volatile("" : "+v"(lane));
-    if (lane < W) {
-      int *msi = sirec + lane * I_COUNT;
-      double *msc = screc + lane * C_COUNT;
+    constexpr int NSP = DD ? 3 : 2;
+    const int sl = NSP == 2 ? lane >> 1 : (int)__umulhi((unsigned)lane, 0x55555556u), j = lane - sl * NSP;
+    if (lane < NSP * W) {
+      int *msi = sirec + sl * I_COUNT;
+      double *msc = screc + sl * C_COUNT;
       if (msi[I_ACT]) {
-        double *mrow = slots + lane * SS;
+        double *mrow = slots + sl * SS;
         const int kc = msi[I_KBLC];
-        msi[I_KBLC] = 0x7fffffff;
+        if (j == 0) msi[I_KBLC] = 0x7fffffff;
         int kbl = nz;
         double hbl = -c_zm[nz];
         if (kc <= nz) { kbl = kc; hbl = mrow[kc * ROWS + Q_YS]; }
-        msi[I_KBL] = kbl;
-        msc[C_HBL] = hbl;
-        const int jer = msi[I_JER];
         const double B0 = msc[C_B0], B0sol = msc[C_B0SOL], ustar = msc[C_USTAR];
         wscale_u wu;
         wu.ju = msi[I_JU]; wu.ufrac = msc[C_UFRAC]; wu.ustar = ustar; wu.ucube = msc[C_UCUBE];
         double bfsfc;
-        {   // swfrac_dev(-1.0, hbl, jer) with the slot's copies of the Jerlov constants (same operations)
+        {   // swfrac_dev(-1.0, hbl, jer) with the slot's copies of the Jerlov constants (same operations): this lane's
+            // exponential of the two
           const double rmin = -80.;
           const double zf = hbl * -1.0;
-          const double r1 = dmax2(div_fast(zf, msc[C_JA1], msc[C_JRA1]), rmin);
-          const double r2 = dmax2(div_fast(zf, msc[C_JA2], msc[C_JRA2]), rmin);
+          const double aj = msc[j == 0 ? (int)C_JA1 : (int)C_JA2], raj = msc[j == 0 ? (int)C_JRA1 : (int)C_JRA2];
+          const double ej = mckpp_exp(dmax2(div_fast(zf, aj, raj), rmin));
+          const double e1 = __shfl(ej, lane - j), e2 = __shfl(ej, lane - j + 1);
           const double rfac = msc[C_JRFAC];
-          bfsfc = rfac * mckpp_exp(r1) + (1. - rfac) * mckpp_exp(r2);
-          (void)jer;
+          bfsfc = rfac * e1 + (1. - rfac) * e2;
         }
         bfsfc = B0 + B0sol * (1. - bfsfc);
         const double stable = 0.5 + dsign(0.5, bfsfc);
         bfsfc = bfsfc + stable * epsln16;
         const double caseA = 0.5 + dsign(0.5, -c_zm[kbl] - 0.5 * c_hm[kbl] - hbl);
-        double gat1[3], dat1[3];
         const double r_hbl = rcp_refine(hbl);
         // the two look-ups of this phase (blmix_mod.F90:64-66 at sigma = 1 | epsilon, :136-141 at the grid level
-        // above kbl) depend on hbl only: both sets of table entries are requested before either is used
+        // above kbl): lane 0 of the slot the first, the others the second; momentum wants wm of both, the scalars ws
         const double sig_k = div_fast(-c_zm[kbl - 1], hbl, r_hbl);
-        const wscale_t wt1 = wscale_fetch(p, wu, stable * 1.0 + (1. - stable) * eps01, hbl, bfsfc);
-        const wscale_t wt2 = wscale_fetch(p, wu, stable * sig_k + (1. - stable) * dmin2(sig_k, eps01), hbl, bfsfc);
-        double wm_1, ws_1, wm_k, ws_k;
-        wscale_finish(p, wu, wt1, wm_1, ws_1);
-        wscale_finish(p, wu, wt2, wm_k, ws_k);
-        // without double diffusion the interior difs and dift are the same numbers, and so is everything formed
-        // from them here (index 1: salinity, 2: temperature)
-        constexpr int MS = DD ? 1 : 2;   // first of the scalar systems to evaluate
+        const double sg_a = j == 0 ? 1.0 : sig_k, sg_b = j == 0 ? eps01 : dmin2(sig_k, eps01);
+        double wm_j, ws_j;
+        wscale_finish(p, wu, wscale_fetch(p, wu, stable * sg_a + (1. - stable) * sg_b, hbl, bfsfc), wm_j, ws_j);
+        const double got = __shfl(j == 0 ? ws_j : wm_j, j == 0 ? lane + 1 : lane - j);
+        const double w_1 = j == 0 ? wm_j : got;   // this species' velocity scale at sigma = 1 | epsilon ...
+        const double w_k = j == 0 ? got : ws_j;   // ... and at the grid level above kbl
+        // this lane's species: 0 momentum, 1 salinity, 2 temperature (without double diffusion the interior difs and dift
+        // are the same numbers, and so is everything formed from them here: the temperature lane stores both)
+        const int m = j == 0 ? 0 : DD ? j : 2;
+        double gat1, dat1;
         {
           int ifx = (int)(caseA + epsln20);
           int kn = ifx * (kbl - 1) + (1 - ifx) * kbl;
@@ -1229,54 +1241,35 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           const double r_hmkn = rcp_refine(hmkn), r_hmkn1 = rcp_refine(hmkn1);
           double delhat = 0.5 * hmkn - c_zm[kn] - hbl;
           double R = 1.0 - div_fast(delhat, hmkn, r_hmkn);
-          const strided<ROWS> dd[3] = {{mrow + Q_DM}, {mrow + Q_DS}, {mrow + Q_DT}};
-          double dp[3], dh[3];
-#pragma unroll
-          for (int m = 0; m < 3; ++m) {
-            if (m != 0 && m < MS) continue;
-            double dvdzup = div_fast(dd[m][kn - 1] - dd[m][kn], hmkn, r_hmkn);
-            double dvdzdn = div_fast(dd[m][kn] - dd[m][kn + 1], hmkn1, r_hmkn1);
-            dp[m] = 0.5 * ((1. - R) * (dvdzup + __builtin_fabs(dvdzup)) + R * (dvdzdn + __builtin_fabs(dvdzdn)));
-            dh[m] = dd[m][kn] + dp[m] * delhat;
-          }
+          const strided<ROWS> dd{mrow + (m == 0 ? (int)Q_DM : m == 1 ? (int)Q_DS : (int)Q_DT)};
+          const double dvdzup = div_fast(dd[kn - 1] - dd[kn], hmkn, r_hmkn);
+          const double dvdzdn = div_fast(dd[kn] - dd[kn + 1], hmkn1, r_hmkn1);
+          const double dp = 0.5 * ((1. - R) * (dvdzup + __builtin_fabs(dvdzup)) + R * (dvdzdn + __builtin_fabs(dvdzdn)));
+          const double dh = dd[kn] + dp * delhat;
           double u4 = ((ustar * ustar) * ustar) * ustar;
           const double u4e = u4 + epsln20;
           double f1 = div_fast(stable * 5.0 * bfsfc, u4e, rcp_refine(u4e));
-          const double wm = wm_1, ws = ws_1;
-          const double wme = wm + epsln20, wse = ws + epsln20;
-          const double r_wme = rcp_refine(wme), r_wse = rcp_refine(wse);
-          gat1[0] = div_fast(div_fast(dh[0], hbl, r_hbl), wme, r_wme);
-          dat1[0] = div_fast(-dp[0], wme, r_wme) + f1 * dh[0];
-          dat1[0] = dmin2(dat1[0], 0.);
-#pragma unroll
-          for (int m = MS; m < 3; ++m) {
-            gat1[m] = div_fast(div_fast(dh[m], hbl, r_hbl), wse, r_wse);
-            dat1[m] = div_fast(-dp[m], wse, r_wse) + f1 * dh[m];
-            dat1[m] = dmin2(dat1[m], 0.);
-          }
-          if (!DD) { gat1[1] = gat1[2]; dat1[1] = dat1[2]; }
+          const double we = w_1 + epsln20, r_we = rcp_refine(we);
+          gat1 = div_fast(div_fast(dh, hbl, r_hbl), we, r_we);
+          dat1 = div_fast(-dp, we, r_we) + f1 * dh;
+          dat1 = dmin2(dat1, 0.);
         }
+        double dkm1;
         {
-          const double wm = wm_k, ws = ws_k;
           const double sig = sig_k;
           double a1 = sig - 2.;
           double a2 = 3. - 2. * sig;
           double a3 = sig - 1.;
-          double Gm = a1 + a2 * gat1[0] + a3 * dat1[0];
-          double Gt = a1 + a2 * gat1[2] + a3 * dat1[2];
-          msc[C_DKM1 + 0] = hbl * wm * sig * (1. + sig * Gm);
-          const double dkm1_t = hbl * ws * sig * (1. + sig * Gt);
-          msc[C_DKM1 + 2] = dkm1_t;
-          if (DD) {
-            double Gs = a1 + a2 * gat1[1] + a3 * dat1[1];
-            msc[C_DKM1 + 1] = hbl * ws * sig * (1. + sig * Gs);
-          } else {
-            msc[C_DKM1 + 1] = dkm1_t;
-          }
+          double G = a1 + a2 * gat1 + a3 * dat1;
+          dkm1 = hbl * w_k * sig * (1. + sig * G);
         }
-        msc[C_RHBL] = r_hbl; msc[C_STABLE] = stable; msc[C_BFSFC] = bfsfc; msc[C_CASEA] = caseA;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) { msc[C_GAT1 + m] = gat1[m]; msc[C_DAT1 + m] = dat1[m]; }
+        msc[C_GAT1 + m] = gat1; msc[C_DAT1 + m] = dat1; msc[C_DKM1 + m] = dkm1;
+        if (!DD && j == 1) { msc[C_GAT1 + 1] = gat1; msc[C_DAT1 + 1] = dat1; msc[C_DKM1 + 1] = dkm1; }
+        if (j == 0) {
+          msi[I_KBL] = kbl;
+          msc[C_HBL] = hbl;
+          msc[C_RHBL] = r_hbl; msc[C_STABLE] = stable; msc[C_BFSFC] = bfsfc; msc[C_CASEA] = caseA;
+        }
       }
     }
   };
@@ -2041,9 +2034,12 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         ps_thomas_uts_back<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, lane);
       }
     } else if (do_ocnint) {
-      // solver mode 1: the upper half of every system on the manager wave, the lower half on the wave next to it
+      // solver mode 1: the upper half of every system on the manager wave, the lower half on another wave
       // (a workgroup of one wave: one after the other); the 2x2 system in the middle needs both
-      const int wv2 = nthreads > 64 ? 1 : 0;
+      // Which wave: the hardware deals the waves of the two 8-wave workgroups of a CU to SIMDs 2,1,3,0,2,1,3,0 and
+      // 1,3,0,2,1,3,0,2 (tools/ubench/hwid.hip) - wave 1 of the first shares a SIMD with the manager wave of the second,
+      // wave 2 does not (+0.5 ... 0.7 % at 60 and 69 levels; with one 16-wave workgroup per CU wave 1 is the better one)
+      const int wv2 = nthreads == 512 ? 2 : nthreads > 64 ? 1 : 0;
       if (wv == mgr) ps_thomas2_uts_fwd<XV, 1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
       if (wv == wv2) ps_thomas2_uts_fwd<XV, -1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
       STAMP(24);
