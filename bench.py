@@ -790,10 +790,10 @@ def main():
         out["sustained"] = {"steps": a.sustained_steps, "value": nocean * a.sustained_steps / dts, "unit": "column-steps/s",
                             "ms_per_step": dts / a.sustained_steps * 1e3, "kernel_avg_ms": kern_ss * 1e3,
                             "ms_per_step_of_the_next_%d_steps" % quarter: dtq / quarter * 1e3,
-                            "note": "same workload and state as the headline, one call; the difference to the headline is the "
-                                    "device's clock under sustained fp64 load, not the work (6 passes per column-step either way)"}
-        # the drop-in loop once more, now that the device is in its sustained state (a long model run's condition;
-        # the first measurement above follows a 0.14 s burst, and the host's waits between steps let the clock sag)
+                            "note": "same workload and state as the headline, one call (one launch): a column that iterates to "
+                                    "itermax delays its own next step only; the headline's 40-step window ends on such columns "
+                                    "more often per step than a 400-step one (DESIGN.md section 6)"}
+        # the drop-in loop once more, later in the run (a long model run's condition: the columns past their spin-up)
         again, _ = drop_in_block(mk, ctx, k3, 1 + SPINUP + a.warmup + a.sustained_steps + quarter, nocean,
                                  (("scalars", mk.api.F_SCALARS, 40), ("restart_set", mk.api.F_RESTART, 8)))
         out["drop_in"]["scalars_after_the_sustained_leg"] = again["scalars"]
