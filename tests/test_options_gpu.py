@@ -108,6 +108,21 @@ def test_double_diffusion(mk):
     _case(mk, 64, 40, dict(LDD=1), prep, nsteps=3)
 
 
+def test_double_diffusion_with_the_most_slots_a_workgroup_takes(mk, monkeypatch):
+    """21 slots x 3 species = 63 lanes of the manager wave in M3 (hbl, blmix scalars: one lane per (slot, species));
+    the launcher's own choice for this depth has fewer"""
+    monkeypatch.setenv("MCKPP_PS", "21x4x1")
+
+    def prep(k3, ob):
+        nzp1 = k3.X.shape[1]
+        z = np.linspace(0, 1, nzp1)[None, :]
+        S = np.asarray(k3.X[:, :, 1]).copy()
+        S[::2] = 0.4 - 0.8 * z
+        k3.X[:, :, 1] = S
+        ob.a["S"][:, 1:nzp1 + 1] = S
+    _case(mk, 150, 20, dict(LDD=1), prep, nsteps=3)
+
+
 def test_current_damping(mk):
     _case(mk, 64, 40, dict(L_DAMP_CURR=1, dt_uvdamp=360), lambda k3, ob: None)
 
