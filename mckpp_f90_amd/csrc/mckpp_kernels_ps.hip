@@ -1275,8 +1275,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   };
 
   // G: ocnstep control of a pass (ocnstep_mod.F90:122-192), one lane per slot.  Whether a column goes on
-  // iterating depends on this pass's boundary-layer depth only, so the decision is taken as soon as M3 has it
-  // (G_early) - a slot that goes on can then start the next pass's L1 while its V sweep still runs - and what
+  // iterating depends on this pass's boundary-layer depth only, so the decision is taken well before the sweeps
+  // (G_early: behind the manager's L6 items, in what would be its wait at that barrier) - a slot that goes on can
+  // then start the next pass's L1 while its V sweep still runs - and what
   // the sweeps and the rest of this pass still need (zero-pivot flag, this pass's `maybe last` flag) is settled
   // after them (G_late).
   // (not with double diffusion: its L1 stages neighbour values in rows the V sweep is reading)
@@ -1898,7 +1899,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(9);
 
     // ---- M3: hbl, kbl, slot-uniform part of blmix
-    if (wv == mgr) { M3(); G_early(); }
+    if (wv == mgr) M3();   // (the ocnstep control, G_early, follows behind the manager's own L6 items, where it would wait)
     STAMP(10);
     __syncthreads();
     STAMP(11);
@@ -2022,6 +2023,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         }
       END_ITEMS
     }
+    // The ocnstep control of this pass: nothing in L5 / L6 reads what it writes, and here the manager wave - one trip of
+    // items where the others have two - would only wait at the barrier.
+    if (wv == mgr) G_early();
     STAMP(14);
     __syncthreads();
     STAMP(15);
