@@ -1899,7 +1899,34 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(9);
 
     // ---- M3: hbl, kbl, slot-uniform part of blmix
+    // The right-hand side of U (ocnint_mod.F90:51-54, tridrhs solvers.F90:53-107) needs nothing of this pass's mixing:
+    // the old time level, the iterate's V, the surface stress.  The waves other than the manager's form it for their
+    // items here, while M3 runs (the row is free: the Monin-Obukhov depths are used up); the manager's own items get
+    // theirs in L6.
+    auto rhs_u = [&](int k, bool actz, bool isnzp1, size_t ro, const double *sc, double *my, int first_, auto xs_) {
+      const size_t o = ro + (k - 1);
+      const double Uo = p.U[o];
+      if (actz) {
+        const double Vo = p.V[o];
+        double Ubot = 0.0;
+        if (k == nz) Ubot = p.U[ro + (nzp1 - 1)];
+        const double V = first_ == 0 ? rV : first_ == 1 ? r2V : xs_[LS];   // of the iterate
+        const double dto = p.dto, f = sc[C_F];
+        double rhsU;
+        if (k == 1) rhsU = Uo + dto * (f * .5 * (Vo + V) - div_fast(sc[C_WU01], c_hm[1], c_misc[0]));
+        else rhsU = Uo + dto * f * .5 * (Vo + V);
+        if (k == nz) rhsU = rhsU + c_t1[nz] * 0.0001 /* difm(nz): kppmix / L5 */ * Ubot;
+        my[k * ROWS + Q_YU] = rhsU;
+      }
+      if (isnzp1) my[k * ROWS + Q_YU] = Uo;   // solvers.F90:159
+    };
     if (wv == mgr) M3();   // (the ocnstep control, G_early, follows behind the manager's own L6 items, where it would wait)
+    else if (do_ocnint) {
+      FOR_ITEMS
+        if (!act) continue;
+        rhs_u(k, actz, isnzp1, ro, sc, my, first_, xs_);
+      END_ITEMS
+    }
     STAMP(10);
     __syncthreads();
     STAMP(11);
@@ -1983,15 +2010,14 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       FOR_ITEMS
         if (!act) continue;
         const strided<ROWS> aDt = row(ps_sysrows<XV>::dl6_t), aDs = row(ps_sysrows<XV>::dl6_s), aGh = row(Q_YV);
-        const double f = sc[C_F];
         const size_t o = ro + (k - 1);
-        const double Uo = p.U[o], Vo = p.V[o], To = p.T[o], So = p.S[o];
-        const double dto = p.dto, tri1_nz = c_t1[nz];
+        const double To = p.T[o], So = p.S[o];
+        if (wv == mgr) rhs_u(k, actz, isnzp1, ro, sc, my, first_, xs_);   // (the others': under M3)
+        const double tri1_nz = c_t1[nz];
         const double wX0_1 = sc[C_WX01], wX0_2 = sc[C_WX02];
-        const strided<ROWS> yU = row(Q_YU), yT = row(Q_YT), yS = row(Q_YS);
+        const strided<ROWS> yT = row(Q_YT), yS = row(Q_YS);
         if (actz) {
-          const double V = first_ == 0 ? rV : first_ == 1 ? r2V : xs_[LS];   // of the iterate (its row holds ghat by now)
-          const double difm = 0.0001 /* only level nz asks: kppmix / L5 */, difs = aDs[k], dift = aDt[k], ghat = aGh[k];
+          const double difs = aDs[k], dift = aDt[k], ghat = aGh[k];
           const int jer = si[I_JER];
           const double rho0cp0 = sc[C_RHO0CP0], r_rc = sc[C_RRC], sflux3 = sc[C_SFLUX3];
           const double dt_m1 = aDt[k - 1], ds_m1 = aDs[k - 1];
@@ -2001,10 +2027,6 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
             wxnt = div_fast(-sflux3 * p.swdk_tab[jer * p.ldc + k], rho0cp0, r_rc);
             wxnt_m1 = div_fast(-sflux3 * p.swdk_tab[jer * p.ldc + k - 1], rho0cp0, r_rc);
           }
-          double rhsU;
-          if (k == 1) rhsU = Uo + dto * (f * .5 * (Vo + V) - div_fast(sc[C_WU01], c_hm[1], c_misc[0]));
-          else rhsU = Uo + dto * f * .5 * (Vo + V);
-          if (k == nz) rhsU = rhsU + tri1_nz * difm * p.U[ro + (nzp1 - 1)];
           double rhsT;
           const double dtohk = c_dtohk[k];
           if (k == 1) rhsT = To + dtohk * (wX0_1 * dift * ghat - wX0_1 * 1.0 + wxnt - sc[C_WXNT0]);
@@ -2015,10 +2037,10 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           else rhsS = So + dtohk * (wX0_2 * (difs * ghat - ds_m1 * gh_m1) + 0.0 - 0.0);
           if (k == nz && nz > 1) rhsS = rhsS + p.S[ro + (nzp1 - 1)] * tri1_nz * difs;
           if constexpr (EXT) ext_rhs(my, si, col, k, si[I_KBL], To, So, rhsT, rhsS);
-          yU[k] = rhsU; yT[k] = rhsT; yS[k] = rhsS;
+          yT[k] = rhsT; yS[k] = rhsS;
         }
         if (isnzp1) {
-          yU[k] = Uo; yT[k] = To; yS[k] = So;   // solvers.F90:159
+          yT[k] = To; yS[k] = So;   // solvers.F90:159
           if constexpr (EXT) { double t = 0.0, s2 = 0.0; ext_rhs(my, si, col, k, si[I_KBL], To, So, t, s2); }   // ocnint_mod.F90:153-160, 207-213
         }
       END_ITEMS
