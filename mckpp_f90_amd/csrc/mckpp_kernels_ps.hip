@@ -933,7 +933,11 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   const auto scr0 = p.scratch + (size_t)blockIdx.x * (size_t)W * (size_t)(4 * LS);
 
 // one level-parallel phase: every active (slot, level) item, strided by the workgroup's threads
+// (not unrolled: the compiler peeled and unrolled L1's item loop - equation of state and all - into 2.5 copies, 14 KB
+// of an 88 KB kernel and 26 more VGPRs, for nothing in the reference-order mode and -1.5 % in the two-ended one)
+#define PS_ITEMS_PRAGMA _Pragma("clang loop unroll(disable)")
 #define FOR_ITEMS                                                                         \
+  PS_ITEMS_PRAGMA                                                                         \
   for (int it_ = tid, t_ = 0; it_ < nitems; it_ = tid2 >= 0 ? nthreads + t_ * nhelp + tid2 : nitems, ++t_) { \
     const int slot = (int)__umulhi((unsigned)it_, Lmagic);                                \
     const int k = it_ - slot * L + 1;                                                     \
