@@ -484,6 +484,31 @@ def single_process_block(mk, cm, sharding, kc_args, ncol_per_gpu, world, devices
     return out
 
 
+def run_single_process_leg(a, devs):
+    """The one-handle leg in a child process of rank 0: its peer copies and cross-device waits have never run on more
+    than one physical device (no multi-GPU node was available to this build), and whatever happens to it - an
+    exception, a crash of the process, a hang - the ranks' own line must still be printed."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR",
+                        "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--single-process-leg", ",".join(str(d) for d in devs),
+           "--steps", str(a.steps), "--warmup", str(a.warmup), "--ncol", str(a.ncol), "--nz", str(a.nz),
+           "--grid", a.grid, "--dto", str(a.dto), "--diag", str(a.diag), "--total-ncol", str(a.total_ncol)]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        return {"error": "the child process did not finish within 240 s"}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"child process exit code {r.returncode}: {(r.stderr or r.stdout).strip()[-400:]}"}
+    try:
+        return json.loads(lines[-1])
+    except ValueError as e:
+        return {"error": f"unreadable result of the child process: {e}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -507,7 +532,18 @@ def main():
     ap.add_argument("--legs", default="all", help="comma list of the extra legs to run (two_ended_solver, tail, config1_pass, ...): "
                                                  "for experiments; default all")
     ap.add_argument("--print-launch", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--single-process-leg", default="", help=argparse.SUPPRESS)   # internal: see run_single_process_leg
     a = ap.parse_args()
+
+    if a.single_process_leg:   # child of rank 0: the one-handle leg alone, its JSON on stdout
+        import common as cm
+        import mckpp_f90_amd as mk
+        from mckpp_f90_amd import sharding
+
+        devs = [int(x) for x in a.single_process_leg.split(",")]
+        print(json.dumps(single_process_block(mk, cm, sharding, {"nz": a.nz, "grid": a.grid, "dto": a.dto}, a.ncol,
+                                              len(devs), devs, a.steps, a.warmup, a.diag, a.total_ncol)), flush=True)
+        return
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:   # started plainly: become the launcher of the N ranks
         argv = [x for x in sys.argv[1:] if x != "--print-launch"]
@@ -696,12 +732,7 @@ def main():
         barrier()
         if rank == 0:
             devs = [0] * world if os.environ.get("MCKPP_BENCH_SHARE_GPU") else list(range(world))
-            try:
-                out["multi_gpu"]["single_process"] = single_process_block(
-                    mk, cm, sharding, {"nz": nz, "grid": a.grid, "dto": a.dto}, a.ncol, world, devs, a.steps, a.warmup,
-                    a.diag, a.total_ncol)
-            except Exception as e:   # noqa: BLE001 - the ranks' own result stands without it
-                out["multi_gpu"]["single_process"] = {"error": f"{type(e).__name__}: {e}"}
+            out["multi_gpu"]["single_process"] = run_single_process_leg(a, devs)
         barrier()
 
     extras = world == 1 and not a.no_extras

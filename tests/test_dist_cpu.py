@@ -98,3 +98,18 @@ def test_bench_starts_its_own_ranks_without_touching_the_gpu():
                        text=True, env=env, timeout=300)
     assert r.returncode != 0
     assert "MI355X" in r.stderr and '"metric"' not in r.stdout
+
+
+def test_one_handle_leg_of_the_bench_cannot_take_the_line_down():
+    """At N>1 rank 0 also drives all shards through ONE handle of the C-ABI (peer copies, cross-device waits): that leg
+    runs in a child process, and whatever becomes of it the parent gets a dictionary to put into its line.  Here the
+    child has no GPU: it fails, and the failure comes back as text."""
+    import argparse
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(cm.ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = argparse.Namespace(steps=2, warmup=1, ncol=64, nz=40, grid="uniform", dto=3600.0, diag=1, total_ncol=0)
+    out = bench.run_single_process_leg(a, [0, 1])
+    assert isinstance(out, dict) and "error" in out and "child process" in out["error"]
