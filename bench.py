@@ -640,38 +640,45 @@ def main():
         ncols_all = int(c.item())
         ones = torch.ones(1, dtype=torch.float64, device=cdev)
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)     # ranks that took part in a collective on `cdev` tensors
-        # diagnostics gather (not timed into `value`): hmix and T of every rank's columns to rank 0
-        barrier()
-        t0 = time.perf_counter()
-        ctx.download(k3, mk.api.F_SCALARS | mk.api.F_PROFILES)
-        t_down = time.perf_counter() - t0
-        barrier()
-        t0 = time.perf_counter()
-        parts = sharding.gather_to_root(k3.hmix, dist, device=coll_dev)
-        if coll_dev is not None:
-            torch.cuda.synchronize()
-        t_h = time.perf_counter() - t0
-        barrier()
-        t0 = time.perf_counter()
-        tparts = sharding.gather_to_root(np.ascontiguousarray(k3.X[:, :, 0]), dist, device=coll_dev)
-        if coll_dev is not None:
-            torch.cuda.synchronize()
-        t_T = time.perf_counter() - t0
         multi = {
             "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
             "backend": dist.get_backend(), "rccl_ranks": int(round(float(ones.item()))) if backend == "nccl" else None,
             "collective_ranks": int(round(float(ones.item()))), "world_size": dist.get_world_size(),
-            "gather": {"what": "hmix (8 B/column) and T (8 (nz+1) B/column) of every rank to rank 0, torch.distributed.gather on "
-                               + ("device tensors (RCCL over xGMI)" if backend == "nccl" else "host tensors (gloo rehearsal)"),
-                       "download_scalars_and_profiles_ms": t_down * 1e3, "hmix_ms": t_h * 1e3, "T_ms": t_T * 1e3,
-                       "T_bytes_per_rank": int(ncol * (nz + 1) * 8)},
         }
-        if rank == 0:
-            hmix_all = sharding.unshard(parts, ntotal)
-            T_all = sharding.unshard(tparts, ntotal)
-            assert np.isfinite(hmix_all).all() and hmix_all.shape == (ntotal,)
-            assert np.isfinite(T_all).all() and T_all.shape == (ntotal, nz + 1)
-            multi["gather"]["checked"] = "hmix and T of all ranks finite and complete on rank 0"
+        # diagnostics gather (not timed into `value`): hmix and T of every rank's columns to rank 0.  The line does not
+        # depend on it: if the collective fails here (it has run on gloo and on a one-rank RCCL group only), the
+        # failure is what the block says.
+        try:
+            barrier()
+            t0 = time.perf_counter()
+            ctx.download(k3, mk.api.F_SCALARS | mk.api.F_PROFILES)
+            t_down = time.perf_counter() - t0
+            barrier()
+            t0 = time.perf_counter()
+            parts = sharding.gather_to_root(k3.hmix, dist, device=coll_dev)
+            if coll_dev is not None:
+                torch.cuda.synchronize()
+            t_h = time.perf_counter() - t0
+            barrier()
+            t0 = time.perf_counter()
+            tparts = sharding.gather_to_root(np.ascontiguousarray(k3.X[:, :, 0]), dist, device=coll_dev)
+            if coll_dev is not None:
+                torch.cuda.synchronize()
+            t_T = time.perf_counter() - t0
+            multi["gather"] = {
+                "what": "hmix (8 B/column) and T (8 (nz+1) B/column) of every rank to rank 0, torch.distributed.gather on "
+                        + ("device tensors (RCCL over xGMI)" if backend == "nccl" else "host tensors (gloo rehearsal)"),
+                "download_scalars_and_profiles_ms": t_down * 1e3, "hmix_ms": t_h * 1e3, "T_ms": t_T * 1e3,
+                "T_bytes_per_rank": int(ncol * (nz + 1) * 8)}
+            if rank == 0:
+                hmix_all = sharding.unshard(parts, ntotal)
+                T_all = sharding.unshard(tparts, ntotal)
+                ok = (np.isfinite(hmix_all).all() and hmix_all.shape == (ntotal,) and np.isfinite(T_all).all()
+                      and T_all.shape == (ntotal, nz + 1))
+                multi["gather"]["checked"] = ("hmix and T of all ranks finite and complete on rank 0" if ok else
+                                              "FAILED: hmix / T gathered on rank 0 incomplete or not finite")
+        except Exception as e:   # noqa: BLE001
+            multi["gather"] = {"error": f"{type(e).__name__}: {e}"}
 
     out = None
     if rank == 0:
