@@ -396,6 +396,63 @@ double orc_swdk(const orc_const *c, double z, int j)
   return jer_rfac[j] * orc_exp(c, z / jer_a1[j]) + (1.0 - jer_rfac[j]) * orc_exp(c, z / jer_a2[j]);
 }
 
+/* Round 5: the intrinsics this file lowers to libm calls and C operators, through the very helpers the physics
+ * below uses (exp as orc_exp does with exp_mode 0, sqrt, fabs, fsign, fmax2 / fmin2 left to right, int casts),
+ * against conv_probe.F90's conv_probe_unary / _swfrac / _binary / _casts. */
+void orc_conv_unary(int n, const double *x, double *e, double *s, double *a, double *q)
+{
+  orc_const c;
+  memset(&c, 0, sizeof c);   /* exp_mode 0: libm exp, "the reference's EXP" */
+  for (int i = 0; i < n; ++i) {
+    const double y = x[i];
+    e[i] = orc_exp(&c, y);
+    s[i] = sqrt(fabs(y));
+    a[i] = fabs(y);
+    q[i] = y * y;
+  }
+}
+void orc_conv_swfrac(int n, const double *z, double fact, int jwtype, double *sw, double *sk)
+{
+  orc_const c;
+  memset(&c, 0, sizeof c);
+  for (int i = 0; i < n; ++i) {
+    sw[i] = orc_swfrac(&c, fact, z[i], jwtype);
+    sk[i] = orc_swdk(&c, z[i], jwtype);
+  }
+}
+void orc_conv_jerlov(int jwtype, double *out) { out[0] = jer_a1[jwtype]; out[1] = jer_a2[jwtype]; out[2] = jer_rfac[jwtype]; }
+void orc_conv_binary(int n, const double *a, const double *b, const double *c, const double *d, double *sg, double *sh,
+                     double *se, double *mx, double *mn, double *ax, double *an, double *m3, double *m4, double *x3)
+{
+  const double epsln = 1.e-16;
+  for (int i = 0; i < n; ++i) {
+    sg[i] = fsign(a[i], b[i]);
+    sh[i] = 0.5 + fsign(0.5, b[i]);
+    se[i] = 0.5 + fsign(0.5, b[i] + epsln);
+    mx[i] = fmax2(a[i], b[i]);
+    mn[i] = fmin2(a[i], b[i]);
+    ax[i] = fmax2(a[i], b[i]);
+    an[i] = fmin2(a[i], b[i]);
+    m3[i] = fmin2(fmin2(a[i], b[i]), c[i]);
+    m4[i] = fmin2(fmin2(fmin2(a[i], b[i]), c[i]), d[i]);
+    x3[i] = fmax2(fmax2(a[i], b[i]), c[i]);
+  }
+}
+void orc_conv_casts(int n, const double *x, int *ifx, int *itr, int *icl, double *fl)
+{
+  const double epsln = 1.e-20;
+  for (int i = 0; i < n; ++i) {
+    ifx[i] = (int)(x[i] + epsln);
+    itr[i] = (int)x[i];
+    int iz = (int)x[i];
+    iz = iz < 890 ? iz : 890;
+    iz = iz > 0 ? iz : 0;
+    icl[i] = iz;
+    fl[i] = x[i] - (double)iz;
+  }
+}
+
+
 /* ------------------------------------------------------------------------
  * Tridiagonal pieces.  mckpp_physics_solvers.F90
  * ---------------------------------------------------------------------- */

@@ -116,6 +116,12 @@ void orc_cpsw_batch(int n, const double *s, const double *t, const double *p, do
 void orc_z121(int kmp1, double vlo, double vhi, double *V, double *w);
 void orc_conv_probe(int n, const double *x, double *p3, double *p4, double *ph, double *pt, double *pq);
 void orc_conv_literals(double *out);
+void orc_conv_unary(int n, const double *x, double *e, double *s, double *a, double *q);
+void orc_conv_swfrac(int n, const double *z, double fact, int jwtype, double *sw, double *sk);
+void orc_conv_jerlov(int jwtype, double *out);
+void orc_conv_binary(int n, const double *a, const double *b, const double *c, const double *d, double *sg, double *sh,
+                     double *se, double *mx, double *mn, double *ax, double *an, double *m3, double *m4, double *x3);
+void orc_conv_casts(int n, const double *x, int *ifx, int *itr, int *icl, double *fl);
 void orc_lookup(double vonk, double *wmt, double *wst);
 /* half_pow_mode 0: x**(1./2.) is a square root (amdflang, the compiler the oracle is pinned to);
  * 1: it is pow(x, 0.5) (how a compiler without that rewrite lowers lookup_mod.F90:60-62) */

@@ -72,6 +72,11 @@ def lib():
         L.orc_lookup_mode.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
         L.orc_conv_probe.argtypes = [C.c_int] + [C.POINTER(C.c_double)] * 6
         L.orc_conv_literals.argtypes = [C.POINTER(C.c_double)]
+        L.orc_conv_unary.argtypes = [C.c_int] + [C.POINTER(C.c_double)] * 5
+        L.orc_conv_swfrac.argtypes = [C.c_int, C.POINTER(C.c_double), C.c_double, C.c_int] + [C.POINTER(C.c_double)] * 2
+        L.orc_conv_jerlov.argtypes = [C.c_int, C.POINTER(C.c_double)]
+        L.orc_conv_binary.argtypes = [C.c_int] + [C.POINTER(C.c_double)] * 14
+        L.orc_conv_casts.argtypes = [C.c_int, C.POINTER(C.c_double)] + [C.POINTER(C.c_int)] * 3 + [C.POINTER(C.c_double)]
         L.orc_wscale.argtypes = [C.POINTER(OrcConst)] + [C.c_double] * 4 + [C.POINTER(C.c_double)] * 2
         L.orc_swfrac.restype = C.c_double
         L.orc_swfrac.argtypes = [C.POINTER(OrcConst), C.c_double, C.c_double, C.c_int]
@@ -107,13 +112,19 @@ def conv_probe():
     """amdflang build of oracle/conv_probe.F90 (own source; needs the compiler only), or None."""
     global _probe
     if _probe is None:
-        if not os.path.exists(PROBELIB) and os.path.exists("/opt/rocm/bin/amdflang"):
+        if os.path.exists("/opt/rocm/bin/amdflang") and (
+                not os.path.exists(PROBELIB) or os.path.getmtime(PROBELIB) < os.path.getmtime(os.path.join(HERE, "conv_probe.F90"))):
             subprocess.check_call(["make", "-C", HERE, "probe"], stdout=subprocess.DEVNULL)
         if not os.path.exists(PROBELIB):
             return None
         P = C.CDLL(PROBELIB)
         P.conv_probe_powers.argtypes = [C.c_int] + [C.POINTER(C.c_double)] * 6
         P.conv_probe_literals.argtypes = [C.POINTER(C.c_double)]
+        if hasattr(P, "conv_probe_unary"):   # (a library built from the round-4 source has only the two above)
+            P.conv_probe_unary.argtypes = [C.c_int] + [C.POINTER(C.c_double)] * 5
+            P.conv_probe_swfrac.argtypes = [C.c_int, C.POINTER(C.c_double)] + [C.c_double] * 4 + [C.POINTER(C.c_double)] * 2
+            P.conv_probe_binary.argtypes = [C.c_int] + [C.POINTER(C.c_double)] * 14
+            P.conv_probe_casts.argtypes = [C.c_int, C.POINTER(C.c_double)] + [C.POINTER(C.c_int)] * 3 + [C.POINTER(C.c_double)]
         _probe = P
     return _probe
 

@@ -3,6 +3,7 @@ golden vectors produced by the compiled reference, and (when oracle/_ref is
 present) to the compiled reference itself on a million points."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -343,3 +344,53 @@ def test_compiler_conventions_live():
     lit = np.zeros(12)
     P.conv_probe_literals(dp(lit))
     _conv_check(x, *o, lit)
+
+
+def _conv2_compare(want, got):
+    """amdflang's results (`want`) against the oracle's C lowering (`got`): bit for bit, integers equal."""
+    assert set(want) == set(got)
+    for name in sorted(want):
+        w, g = np.asarray(want[name]), np.asarray(got[name])
+        if w.dtype.kind == "i":
+            bad = w != g
+        else:
+            bad = np.ascontiguousarray(w).view(np.int64) != np.ascontiguousarray(g).view(np.int64)
+        assert not bad.any(), (f"{name}: the oracle's C lowering differs from amdflang's on {int(bad.sum())} of {bad.size} values, "
+                               f"first at index {int(np.flatnonzero(bad)[0])}")
+
+
+def _conv2_module():
+    sys.path.insert(0, GOLD)
+    import make_conv_golden2 as g2
+    return g2
+
+
+def test_compiler_conventions_intrinsics_golden():
+    """EXP (>= 1e4 arguments in [-80, 0] and the model's own -dm(k)/a1, -hbl/a2 of every BASELINE grid and Jerlov type),
+    SQRT, ABS, x**2, swfrac / swdk as the reference writes them (swfrac_mod.F90:74-77, fluxes_mod.F90:134-135),
+    SIGN(a, b) incl. SIGN(0.5, +-0.0) and SIGN(0.5, x + epsln) near zero (bldepth_mod.F90:123,196,201), MAX / MIN /
+    AMAX1 / AMIN1 with 2-4 arguments incl. equal and signed-zero operands, ifix / int / float (blmix_mod.F90:68,
+    wscale_mod.F90:65-77): what amdflang returned for them under the reference's flags
+    (tests/golden/conv_probe_intrinsics.npz, made by tests/golden/make_conv_golden2.py from oracle/conv_probe.F90)
+    against the oracle's lowering - exp(), sqrt(), fabs(), copysign, a > b ? a : b left to right, (int) - bit for bit.
+    exp_mode = 0 of the oracle is therefore amdflang's EXP, not an assumption about it."""
+    g2 = _conv2_module()
+    z = np.load(os.path.join(GOLD, "conv_probe_intrinsics.npz"))
+    inp = {k[3:]: np.ascontiguousarray(z[k]) for k in z.files if k.startswith("in_")}
+    want = {k[4:]: z[k] for k in z.files if k.startswith("out_")}
+    assert (inp["x"] <= 0).sum() >= 10000 and len(inp["z"]) > 3000
+    _conv2_compare(want, g2.run_oracle(inp))
+    # what the probe says about the lowering itself
+    assert np.array_equal(want["sign_half"][np.signbit(inp["b"])], np.zeros(int(np.signbit(inp["b"]).sum())))   # SIGN(0.5, -0.0) = -0.5
+    assert np.array_equal(want["amax1"].view(np.int64), want["max"].view(np.int64))
+    assert np.array_equal(want["amin1"].view(np.int64), want["min"].view(np.int64))
+
+
+def test_compiler_conventions_intrinsics_live():
+    """The same against a fresh amdflang build of the probe on other random arguments, where the compiler is installed."""
+    P = orc.conv_probe()
+    if P is None or not hasattr(P, "conv_probe_unary"):
+        pytest.skip("amdflang not installed here")
+    g2 = _conv2_module()
+    inp = g2.inputs(seed=7, n=20000)
+    _conv2_compare(g2.run_probe(P, inp), g2.run_oracle(inp))
