@@ -91,6 +91,11 @@ struct mckpp_kparams_t {
   // k_column_ps: the iterate's scratch rows, one block per (workgroup, slot) (mckpp_ps_scratch_doubles)
   P<double> scratch;
   size_t scratch_doubles;
+  // Stragglers (k_column_ps, M0 / G_late): columns on their way to itermax are left alone in their workgroup.
+  P<int> sync;        // [0] stragglers the device holds right now (zeroed per launch)
+  int solo_after;     // a column past this many passes of a try is one (default 12; MCKPP_SOLO_AFTER)
+  int solo_limit;     // workgroups leave their other slots empty for a straggler while the device holds at most this many
+                      // (0: never - MCKPP_SOLO=0; default: workgroups / 32, at least 2; MCKPP_SOLO_LIMIT)
 };
 using mckpp_kparams = mckpp_kparams_t<mckpp_ptr_plain>;
 using mckpp_kparams_dev = mckpp_kparams_t<mckpp_ptr_global>;

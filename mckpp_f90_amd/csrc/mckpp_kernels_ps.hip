@@ -50,7 +50,8 @@ enum {
   I_KBLC, I_NVIOL, I_NOVER, I_NU, I_NV, I_NF, I_BAD, I_L1A /* L1 but for V done ahead, during the V sweep */,
   I_MAYBE_NEXT, I_LOCEAN, I_PAR /* which C_T1X holds the iterate's level-1 temperature */,
   I_TINY /* some whole-layer term of the reference-level sums is a tiny non-zero number (L2) */,
-  I_STEP /* which step of the launch this column is in (0 .. nsteps_launch-1) */, I_COUNT_USED,
+  I_STEP /* which step of the launch this column is in (0 .. nsteps_launch-1) */,
+  I_STRAG /* counted as a straggler: past its solo_after-th pass of a try, or at itermax in its previous step (M0) */, I_COUNT_USED,
   I_COUNT = I_COUNT_USED | 1   // odd, like C_COUNT: 32 ints would put every lane's record on the same two banks
 };
 // LDS rows of a slot and what each holds between which phases of a pass:
@@ -137,7 +138,7 @@ __host__ __device__ inline int ps_scratch_ld(int nzp1) { return (nzp1 + 7) & ~7;
 __host__ inline size_t ps_lds_bytes(int L, int W, int xv)
 {
   return (size_t)(K_STRIDE * ps_nl(L) + 2 + W * ps_ss(L, xv, W) + W * C_COUNT) * sizeof(double) +
-         (size_t)(W * I_COUNT + 8) * sizeof(int);
+         (size_t)(W * I_COUNT + 16) * sizeof(int);
 }
 
 
@@ -862,7 +863,7 @@ template <int XV, int SM>
 #define MCKPP_PS_MINW 4
 #endif
 __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_kparams *__restrict__ pp, const int ntime, const int L,
-                                                     const int W, const unsigned Lmagic, const int SS /* ps_ss(L, XV, W) */)
+                                                     const int W0, const unsigned Lmagic, const int SS /* ps_ss(L, XV, W0) */)
 {
   // through the block typed with global pointers (mckpp_device.h): global_load / global_store, SGPR bases
   const mckpp_kparams_dev &p = *reinterpret_cast<const mckpp_kparams_dev *>(pp);
@@ -877,12 +878,27 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   const strided<K_STRIDE> c_zm{cst + K_ZM}, c_hm{cst + K_HM}, c_t0{cst + K_T0}, c_t1{cst + K_T1}, c_rdz{cst + K_RDZ},
       c_dtohk{cst + K_DTOHK};
   double *c_misc = lds + K_STRIDE * NL;
-  double *slots = c_misc + 2;
-  double *screc = slots + W * SS;
-  int *sirec = reinterpret_cast<int *>(screc + W * C_COUNT);
+  double *const slots0 = c_misc + 2;
+  double *const screc0 = slots0 + W0 * SS;
+  int *const sirec0 = reinterpret_cast<int *>(screc0 + W0 * C_COUNT);
   // [0] some slot active, [1] some slot finishing, [2] the level the bulk-Ri scan of this pass ended at, [3] the level
-  // down to which L3 forms the bulk Richardson numbers (a guess from the pass before), [4] the guess was too shallow
-  int *s_flags = sirec + W * I_COUNT;
+  // down to which L3 forms the bulk Richardson numbers (a guess from the pass before), [4] the guess was too shallow,
+  // [5] the scan stopped early, [6] some slot waits for its ticket, [7] the queue M0 draws from,
+  // [S_SOLO] the slot the workgroup works on ALONE (-1: none), [S_GOSOLO] the slot to go on alone with from this pass's
+  // L2 on (-1: none), [S_DRAIN] M0 does not refill for now (a straggler is being left alone, or the queue is used up)
+  enum { S_SOLO = 8, S_GOSOLO = 9, S_DRAIN = 10 };
+  int *s_flags = sirec0 + W0 * I_COUNT;
+  // ---- the VIEW a pass works in.  Normally every slot of the workgroup, the items of the first trip dealt from thread 0
+  // on.  A column that iterates towards itermax (200 passes where the others take 6) bounds a long run by its own chain
+  // of passes, so a workgroup that holds one lets its other slots run empty (M0) and then goes on with that slot ALONE:
+  // the same code on a view of one slot (W = 1, the slot's rows and records as slot 0), its level items dealt to the
+  // waves other than the manager's - so that everything the full workgroup overlaps with the manager's serial phases
+  // (M1 | L2, the right-hand side of U under M3, the next L1 under the V sweep, the control under L6) overlaps for the
+  // lone column too, which with its items on the manager wave itself ran one after the other.  Same operations, same
+  // operands: a view changes who works on an item, never what is done to it.
+  int W = W0;
+  double *slots = slots0, *screc = screc0;
+  int *sirec = sirec0;
 
   for (int i = tid; i < NL; i += blockDim.x) {
     c_zm[i] = p.zm[i];
@@ -893,8 +909,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     c_dtohk[i] = p.dto / p.hm[i];
   }
   if (tid == 0) { c_misc[0] = rcp_refine(p.hm[1]); c_misc[1] = rcp_refine(p.vonk); }
-  for (int i = tid; i < W * I_COUNT; i += blockDim.x) sirec[i] = 0;   // every slot PS_EMPTY
-  if (tid < 8) s_flags[tid] = tid == 3 ? nz : 0;
+  for (int i = tid; i < W0 * I_COUNT; i += blockDim.x) sirec0[i] = 0;   // every slot PS_EMPTY
+  if (tid < 16) s_flags[tid] = tid == 3 ? nz : (tid == S_SOLO || tid == S_GOSOLO) ? -1 : 0;
   // The manager is wave 0 (the item map below gives it items in the first trip only).  Measured and dropped:
   // electing the wave that sits on a given SIMD, so that the serial chains of all workgroups of a CU share one
   // SIMD (0.8-0.9x), or one SIMD per workgroup chosen from blockIdx (0.97x); raising its s_setprio (0.97x).
@@ -913,10 +929,24 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // ---- work items (slot, level) ------------------------------------------------
   // Item `it` of the first trip belongs to thread `it`; the later trips are dealt to the waves other than the
   // manager's only (it has its serial phases to run): item nthreads + t*(nthreads-64) + (tid-64) in trip t+1.
-  const int nthreads = blockDim.x, nitems = W * L;
+  const int nthreads = blockDim.x;
+  int nitems = W0 * L;
   const int nhelp = nthreads > 64 ? nthreads - 64 : 64, tid2 = nthreads > 64 ? tid - 64 : tid;
-  const int nitems_lm = W * nzp1;
-  const unsigned Wmagic = W > 1 ? 0xFFFFFFFFu / (unsigned)W + 1u : 0u;   // it / W == umulhi(it, Wmagic) for it < 2^16
+  int nitems_lm = W0 * nzp1;
+  const unsigned Wmagic = W0 > 1 ? 0xFFFFFFFFu / (unsigned)W0 + 1u : 0u;   // it / W == umulhi(it, Wmagic) for it < 2^16 (a view of one slot: W == 1, not used)
+  // a view of one slot needs a wave for the manager and lanes for every item of a column beside it
+  const bool solo_ok = nthreads > 64 && nthreads - 64 >= L;
+  const bool solo_perm = W0 == 1 && solo_ok;   // a workgroup of one slot works in that view from the start (and refills it as ever)
+  int it0 = tid;   // this thread's item of the first trip
+  auto set_view = [&](int s) {   // s < 0: every slot; else: slot s alone
+    const bool one = s >= 0;
+    const int so = one ? s : 0;
+    W = one ? 1 : W0;
+    slots = slots0 + so * SS; screc = screc0 + so * C_COUNT; sirec = sirec0 + so * I_COUNT;
+    nitems = W * L; nitems_lm = W * nzp1;
+    it0 = one ? (tid >= 64 ? tid - 64 : 0x3fffffff) : tid;
+  };
+  if (solo_perm) { set_view(0); if (tid == 0) s_flags[S_SOLO] = 0; }
   __syncthreads();
 
   const double lambda = 0.5;
@@ -930,7 +960,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // geometries the launcher chooses has a third trip)
   double rU = 0.0, rV = 0.0, rT = 0.0, rS = 0.0, r2U = 0.0, r2V = 0.0, r2T = 0.0, r2S = 0.0;
   const int LS = ps_scratch_ld(nzp1);
-  const auto scr0 = p.scratch + (size_t)blockIdx.x * (size_t)W * (size_t)(4 * LS);
+  const auto scr0 = p.scratch + (size_t)blockIdx.x * (size_t)W0 * (size_t)(4 * LS);
 
 // one level-parallel phase: every active (slot, level) item, strided by the workgroup's threads
 // (not unrolled: the compiler peeled and unrolled L1's item loop - equation of state and all - into 2.5 copies, 14 KB
@@ -938,7 +968,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 #define PS_ITEMS_PRAGMA _Pragma("clang loop unroll(disable)")
 #define FOR_ITEMS                                                                         \
   PS_ITEMS_PRAGMA                                                                         \
-  for (int it_ = tid, t_ = 0; it_ < nitems; it_ = tid2 >= 0 ? nthreads + t_ * nhelp + tid2 : nitems, ++t_) { \
+  for (int it_ = it0, t_ = 0; it_ < nitems; it_ = tid2 >= 0 ? nthreads + t_ * nhelp + tid2 : nitems, ++t_) { \
     const int slot = (int)__umulhi((unsigned)it_, Lmagic);                                \
     const int k = it_ - slot * L + 1;                                                     \
     int *const si = sirec + slot * I_COUNT;                                               \
@@ -961,7 +991,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 // - its lanes loop equally long - and a thread's first item comes from the top of the columns, its later ones
 // from the bottom, so every thread gets a deep and a shallow item.
 #define FOR_ITEMS_BY_LEVEL                                                                \
-  for (int j_ = tid, t_ = 0; j_ < nitems_lm; j_ = tid2 >= 0 ? nthreads + t_ * nhelp + tid2 : nitems_lm, ++t_) { \
+  for (int j_ = it0, t_ = 0; j_ < nitems_lm; j_ = tid2 >= 0 ? nthreads + t_ * nhelp + tid2 : nitems_lm, ++t_) { \
     const int it_ = t_ == 0 ? j_ : nitems_lm - 1 - (j_ - nthreads);                       \
     const int k = (W == 1 ? it_ : (int)__umulhi((unsigned)it_, Wmagic)) + 1;   /* the magic of W = 1 is 2^32 */ \
     const int slot = it_ - (k - 1) * W;                                                   \
@@ -979,7 +1009,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 // Level-major order again, plainly rising (item = (level-1)*W + slot, a thread's later items are deeper): for the
 // phases that only have work down to some level - the waves that hold deeper levels fall through.
 #define FOR_ITEMS_RISING                                                                  \
-  for (int it_ = tid, t_ = 0; it_ < nitems_lm; it_ = tid2 >= 0 ? nthreads + t_ * nhelp + tid2 : nitems_lm, ++t_) { \
+  for (int it_ = it0, t_ = 0; it_ < nitems_lm; it_ = tid2 >= 0 ? nthreads + t_ * nhelp + tid2 : nitems_lm, ++t_) { \
     const int k = (W == 1 ? it_ : (int)__umulhi((unsigned)it_, Wmagic)) + 1;              \
     const int slot = it_ - (k - 1) * W;                                                   \
     int *const si = sirec + slot * I_COUNT;                                               \
@@ -1009,7 +1039,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // A slot whose ticket is not ready keeps it (PS_WAIT) and asks again at every later M0.
   auto M0 = [&]() {
     int lane = lane_k; asm volatile("" : "+v"(lane));
-    bool a = false, wt = false;
+    bool a = false, wt = false, sticky = false;
     const bool multi = p.nsteps_launch > 1;
     if (multi) {
       const bool pub = lane < W && sirec[lane * I_COUNT + I_STATE] == PS_ACTIVE && sirec[lane * I_COUNT + I_FIN] == F_FINAL;
@@ -1020,10 +1050,14 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     double *msc = screc + (lane < W ? lane : 0) * C_COUNT;
     int st = PS_DONE, c = 0, step = 0;
     bool want = false, ready = false, idle = false;
+    // the workgroup is in the view of one slot and that column goes on (a retry after the trap): nothing else starts here
+    // until it is done - a ticket held for another column waits that long (its column's later steps wait for it anyway)
+    const int ss = solo_perm ? -1 : s_flags[S_SOLO];
+    const bool solo_on = ss >= 0 && sirec[ss * I_COUNT + I_STATE] == PS_ACTIVE && sirec[ss * I_COUNT + I_FIN] != F_FINAL;
     if (lane < W) {
       st = msi[I_STATE];
       if (st == PS_ACTIVE && msi[I_FIN] == F_FINAL) st = PS_EMPTY;   // its outputs are stored (barrier before M0)
-      if (st == PS_WAIT) { c = msi[I_COL]; step = msi[I_STEP]; want = true; }
+      if (st == PS_WAIT && !solo_on) { c = msi[I_COL]; step = msi[I_STEP]; want = true; }
     }
     // Refills come in rounds.  A workgroup's slots that start together finish together - every column takes the
     // same six passes in the steady state - and each refill costs the whole workgroup a finish round, a pass that
@@ -1035,7 +1069,35 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     // (it is on its way to itermax: nobody waits for it, and when it ends its slot waits for the others).
     const int n_empty = __popcll(__ballot(lane < W && st == PS_EMPTY));
     const int n_busy = __popcll(__ballot(lane < W && st == PS_ACTIVE && sirec[lane * I_COUNT + I_NPASS_TRY] <= 12));
-    const bool refill = 2 * n_empty >= n_empty + n_busy;
+    bool refill = 2 * n_empty >= n_empty + n_busy;
+    // Stragglers.  A column past its solo_after-th pass of a try - or one that went to itermax in its previous step: they
+    // do so step after step - is on its way to itermax: its chain of ~200 passes, each as long as a pass of the whole
+    // workgroup, is what a long run waits for in the end (a launch of many steps: that column's steps follow each other;
+    // a launch per step: the launch ends with it).  While the device holds few of them (p.sync[0]: their number, kept by
+    // every workgroup's M0), a workgroup that has one does not refill its other slots: they run empty within a step, and
+    // the pass - now of one column, in a view of its own (G_late) - takes 0.6 of the time.  The slots left idle are
+    // a workgroup's share of the device per straggler; with many stragglers (the second step from an analytic start:
+    // 14 % of the columns) nothing is left idle.
+    bool drain = false;
+    if (p.solo_limit > 0 && p.mode == MCKPP_MODE_STEP) {
+      const int after = p.solo_after;
+      const bool was = lane < W && msi[I_STRAG] != 0;
+      const bool gone = was && st != PS_ACTIVE;                                             // finished (its outputs are stored)
+      const bool is = lane < W && st == PS_ACTIVE && (was || msi[I_NPASS_TRY] > after);
+      if (is && !was) msi[I_STRAG] = 1;
+      if (gone) msi[I_STRAG] = 0;
+      const int delta = __popcll(__ballot(is && !was)) - __popcll(__ballot(gone));
+      int glob = 0;
+      if (__ballot(is) != 0ull || delta != 0) {
+        if (lane == 0) glob = delta != 0 ? atomicAdd((int *)p.sync, delta) + delta
+                                         : __hip_atomic_load((int *)p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        glob = __shfl(glob, 0);
+      }
+      drain = __ballot(is) != 0ull && glob <= p.solo_limit;
+      if (solo_on) drain = true;
+      else if (ss >= 0 && lane == 0) s_flags[S_SOLO] = -1;   // that column is done: back to the view of every slot
+      if (drain) refill = false;
+    }
     if (lane < W) {
       if (st == PS_EMPTY) { msi[I_FIN] = F_NONE; msi[I_ACT] = 0; }
       if (st == PS_EMPTY && refill) {
@@ -1101,6 +1163,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           msi[I_MAYBE] = (p.mode != MCKPP_MODE_STEP) ? 1 : 0;
           msi[I_KBLC] = 0x7fffffff; msi[I_NVIOL] = 0; msi[I_NU] = 0; msi[I_NV] = 0; msi[I_NF] = 0; msi[I_PAR] = 0;
           msi[I_L1A] = 0; msi[I_MAYBE_NEXT] = msi[I_MAYBE]; msi[I_TINY] = 0;
+          // (at itermax in its previous step - ci holds that step's pass count: a straggler from its first pass on)
+          sticky = p.solo_limit > 0 && p.mode == MCKPP_MODE_STEP && ci[CI_NPASS] > 50;
+          msi[I_STRAG] = sticky ? 1 : 0;
           s_flags[3] = nz;   // no guess for a new column: L3 forms the bulk Richardson numbers of every level
           msc[C_F] = cs[CS_F]; msc[C_WXNT0] = 0.0; msc[C_HMIXE] = 0.0; msc[C_HMIXN] = 0.0;
           msc[C_SREF] = cs[CS_SREF]; msc[C_SSURF] = cs[CS_SSURF]; msc[C_OCDEPTH] = cs[CS_OCDEPTH];
@@ -1138,6 +1203,13 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       wt = st == PS_WAIT || (idle && more);
     }
     const unsigned long long m = __ballot(a), mw = __ballot(wt);
+    {
+      const int nsticky = __popcll(__ballot(sticky));
+      if (nsticky > 0 && lane == 0) atomicAdd((int *)p.sync, nsticky);
+      // nothing will be refilled for now: stragglers are being left alone, or the queue has nothing more (G_late)
+      const bool used_up = __ballot(lane < W && st == PS_DONE) != 0ull;
+      if (lane == 0) s_flags[S_DRAIN] = (drain || used_up) ? 1 : 0;
+    }
     if (lane == 0) { s_flags[0] = m != 0ull ? 1 : 0; s_flags[1] = 0; s_flags[6] = mw != 0ull ? 1 : 0; }
     if (multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the acquire's invalidate has completed before the barrier lets the other waves load
   };
@@ -1344,6 +1416,20 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         msi[I_BAD] = 0;
         msi[I_TINY] = 0;
         msi[I_MAYBE] = msi[I_MAYBE_NEXT];
+      }
+    }
+    // One column left in a workgroup that does not refill for now, and that column on its way to itermax (or at itermax
+    // in its previous step): from the next pass on the workgroup works in a view of that slot alone (the iterate changes
+    // hands after that pass's L1, below).  (A slot that holds a ticket it waits to start keeps it until this column is
+    // done, M0: mostly it is this very column's next step.)
+    if (p.mode == MCKPP_MODE_STEP && solo_ok && !solo_perm && p.solo_limit > 0 && s_flags[S_SOLO] < 0 && s_flags[S_DRAIN]) {
+      const int stt = lane < W ? sirec[lane * I_COUNT + I_STATE] : PS_DONE;
+      const bool on = lane < W && stt == PS_ACTIVE && sirec[lane * I_COUNT + I_ACT];
+      const unsigned long long m_on = __ballot(on);
+      if (__popcll(m_on) == 1) {
+        const int s1 = __builtin_ctzll(m_on);
+        const int *msi = sirec + s1 * I_COUNT;
+        if (lane == 0 && msi[I_FIN] == F_NONE && (msi[I_STRAG] || msi[I_NPASS_TRY] > p.solo_after)) s_flags[S_GOSOLO] = s1;
       }
     }
   };
@@ -1661,6 +1747,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     const int any_active = first_iteration ? 0 : s_flags[0], any_waiting = first_iteration ? 1 : s_flags[6];
     if (!any_active && !any_waiting) break;
     int finishing = 0;
+    // the view of this iteration (M0 and G_late change it between iterations only), and whether this pass ends in another
+    const int gosolo = solo_perm ? -1 : __builtin_amdgcn_readfirstlane(s_flags[S_GOSOLO]);
+    if (!solo_perm) set_view(__builtin_amdgcn_readfirstlane(s_flags[S_SOLO]));
     if (any_active) {
     STAMP(22);
 #ifdef MCKPP_PS_STAMPS
@@ -1676,6 +1765,26 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(0);
     __syncthreads();
     STAMP(1);
+    if (gosolo >= 0) {
+      // From here on the workgroup works on slot `gosolo` alone (G_late of the pass before).  The slot's rows and records
+      // stay where they are; what changes hands is the iterate of the under-relaxation, which lives in the registers of
+      // the threads that own the slot's items: through the rows of a neighbour slot (empty: this is the only active one).
+      double *const stage = slots0 + (gosolo + 1 == W0 ? 0 : gosolo + 1) * SS;
+      FOR_ITEMS
+        if (slot != gosolo || !act) continue;
+        stage[4 * k + 0] = first_ == 0 ? rU : first_ == 1 ? r2U : xs_[0];
+        stage[4 * k + 1] = first_ == 0 ? rV : first_ == 1 ? r2V : xs_[LS];
+        stage[4 * k + 2] = first_ == 0 ? rT : first_ == 1 ? r2T : xs_[2 * LS];
+        stage[4 * k + 3] = first_ == 0 ? rS : first_ == 1 ? r2S : xs_[3 * LS];
+      END_ITEMS
+      __syncthreads();
+      if (tid == 0) { s_flags[S_SOLO] = gosolo; s_flags[S_GOSOLO] = -1; }
+      set_view(gosolo);
+      FOR_ITEMS
+        if (!act) continue;
+        rU = stage[4 * k + 0]; rV = stage[4 * k + 1]; rT = stage[4 * k + 2]; rS = stage[4 * k + 3];
+      END_ITEMS
+    }
 
     // ---- L2a: the whole-layer terms of the reference-level sums (verticalmixing_mod.F90:122-127 with wz = dz,
     // del = 0.5), once per layer instead of once per (level, layer)
@@ -2423,7 +2532,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     END_ITEMS
     }   // finish round
     }   // pass of the active slots
-    if (!finishing && !any_waiting) continue;
+    if (!finishing && !(any_waiting && (solo_perm || W == W0))) continue;   // (a workgroup in the view of one slot asks for its waiting tickets when that column is done)
     // (every read of the finished slots' records and of the flags M0 rewrites is done: hand the slots to the queue;
     // every wave's stores of the finishing steps have left it - M0 publishes those steps)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2432,6 +2541,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     if (wv == mgr) {
       // nothing to work on but a ticket whose column another workgroup still has in its previous step: ask again in a while
       if (!any_active && !first_iteration) __builtin_amdgcn_s_sleep(64);
+      if (!solo_perm) set_view(-1);   // M0 looks at every slot
       M0();
     }
     __syncthreads();
@@ -2484,7 +2594,8 @@ ps_geom ps_choose(int L, int xv, size_t cu_lds_bytes, int cols_per_cu, int *max_
       if (rate > best_rate * 1.0001) { best_rate = rate; best = {nw, w, per_cu}; }
     }
   }
-  const int need = (best.w * L + 63) / 64;
+  int need = (best.w * L + 63) / 64;
+  if (best.w == 1) ++need;   // a workgroup of one slot: a wave for the manager beside the waves of the level items (the view of one slot)
   if (need < best.nw) best.nw = need;
   if (max_slots_per_cu) *max_slots_per_cu = most;
   return best;

@@ -78,6 +78,8 @@ const double jer_a2[6] = {0, 23.0, 20.0, 17.0, 14.0, 7.9};
 
 }  // namespace
 
+enum { QBLOCK_INTS = 64 };
+
 struct mckpp_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -111,7 +113,8 @@ struct mckpp_hip_ctx {
   int window_count = 0;
   double *d_cs = nullptr;
   int *d_ci = nullptr;
-  int *d_qhead = nullptr;
+  int *d_qhead = nullptr;  // QBLOCK_INTS ints, zeroed before every launch: [0..15] queue heads, [16..31] queue owners, [32] stragglers on the device
+  int solo_after = 12, solo_limit = 8;   // mckpp_kparams_t::solo_after / solo_limit (MCKPP_SOLO=0, MCKPP_SOLO_AFTER, MCKPP_SOLO_LIMIT)
   int *d_done = nullptr;   // [ncol] steps of a multi-step launch each column has completed (mckpp_kparams_t::done)
   bool multistep = true;   // mckpp_hip_step(nt, n > 1) as one launch (MCKPP_MULTISTEP=0: a launch per step)
   int nqueues = 0;         // XCDs of the device, found by a probe at init: the queues of such a launch
@@ -274,7 +277,12 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   h->ext_kernel = c->LDD || c->L_RELAX_SST || c->L_FCORR || c->L_FCORR_WITHZ || c->L_SFCORR || c->L_SFCORR_WITHZ ||
                   c->L_RELAX_SAL || c->L_RELAX_OCNT || c->L_NO_FREEZE || c->L_NO_ISOTHERM || c->L_DAMP_CURR || c->L_ADVECT;
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  HIPCHK(hipMalloc(&h->d_qhead, 32 * sizeof(int)));   // queue heads [16], queue owners [16]
+  HIPCHK(hipMalloc(&h->d_qhead, QBLOCK_INTS * sizeof(int)));   // queue heads [16], queue owners [16], straggler count and spare [32]
+  h->solo_after = 12;
+  h->solo_limit = std::max(2, h->num_cu / 32);
+  if (const char *e = getenv("MCKPP_SOLO")) { if (atoi(e) == 0) h->solo_limit = 0; }
+  if (const char *e = getenv("MCKPP_SOLO_LIMIT")) h->solo_limit = std::max(0, atoi(e));
+  if (const char *e = getenv("MCKPP_SOLO_AFTER")) h->solo_after = std::max(0, atoi(e));
   {   // the device's XCDs (a column of a multi-step launch stays on one: mckpp_kernels_ps.hip, M0)
     HIPCHK(hipMemsetAsync(h->d_qhead, 0, sizeof(int), h->stream));
     HIPCHK(mckpp_launch_xcc_probe(reinterpret_cast<unsigned *>(h->d_qhead), h->stream));
@@ -835,6 +843,7 @@ static void fill_params(mckpp_hip_ctx *h, mckpp_kparams &p, int ntime, int mode)
   p.U_init = h->d_prof[P_UINIT]; p.V_init = h->d_prof[P_VINIT];
   p.cs = h->d_cs; p.ci = h->d_ci; p.qhead = h->d_qhead; p.dbg = h->d_dbg;
   p.nsteps_launch = 1; p.done = h->d_done; p.nqueues = h->nqueues; p.qowner = h->d_qhead + 16;
+  p.sync = h->d_qhead + 32; p.solo_after = h->solo_after; p.solo_limit = h->solo_limit;
   for (int i = 0; i < 16; ++i) p.xcc_queue[i] = h->xcc_queue[i];
   p.ext = h->ext_kernel ? 1 : 0;
   p.L_RELAX_SST = h->c.L_RELAX_SST; p.L_RELAX_CALCONLY = h->c.L_RELAX_CALCONLY; p.L_FCORR = h->c.L_FCORR;
@@ -895,7 +904,7 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode, const forced_r
       }
       HIPCHK(hipMemcpyAsync(h->d_params, &h->h_params[slot], sizeof(mckpp_kparams), hipMemcpyHostToDevice, h->stream));
       HIPCHK(hipEventRecord(h->ev_params[slot], h->stream));
-      HIPCHK(hipMemsetAsync(h->d_qhead, 0, 32 * sizeof(int), h->stream));
+      HIPCHK(hipMemsetAsync(h->d_qhead, 0, QBLOCK_INTS * sizeof(int), h->stream));
       HIPCHK(hipMemsetAsync(h->d_done, 0, (size_t)h->ncol * sizeof(int), h->stream));
       HIPCHK(mckpp_launch_column_kernel_ps(h->h_params[slot], h->d_params, h->num_cu, h->stream, &h->last_launch));
     }
@@ -913,7 +922,7 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode, const forced_r
       HIPCHK(mckpp_launch_fluxes(p, ntime + i, h->d_series + (size_t)rec * 8 * (size_t)h->ncol, forced->l_rest,
                                  forced->flsn, forced->el, h->stream));
     }
-    HIPCHK(hipMemsetAsync(h->d_qhead, 0, sizeof(int), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_qhead, 0, QBLOCK_INTS * sizeof(int), h->stream));
     HIPCHK(mckpp_launch_column_kernel_ps(p, h->d_params, h->num_cu, h->stream, &h->last_launch));
   }
   HIPCHK(hipEventRecord(h->ev1, h->stream));
