@@ -886,7 +886,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // [5] the scan stopped early, [6] some slot waits for its ticket, [7] the queue M0 draws from,
   // [S_SOLO] the slot the workgroup works on ALONE (-1: none), [S_GOSOLO] the slot to go on alone with from this pass's
   // L2 on (-1: none), [S_DRAIN] M0 does not refill for now (a straggler is being left alone, or the queue is used up)
-  enum { S_SOLO = 8, S_GOSOLO = 9, S_DRAIN = 10 };
+  enum { S_SOLO = 8, S_DRAIN = 9, S_GOSOLO = 10 };
   int *s_flags = sirec0 + W0 * I_COUNT;
   // ---- the VIEW a pass works in.  Normally every slot of the workgroup, the items of the first trip dealt from thread 0
   // on.  A column that iterates towards itermax (200 passes where the others take 6) bounds a long run by its own chain
@@ -937,6 +937,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // a view of one slot needs a wave for the manager and lanes for every item of a column beside it
   const bool solo_ok = nthreads > 64 && nthreads - 64 >= L;
   const bool solo_perm = W0 == 1 && solo_ok;   // a workgroup of one slot works in that view from the start (and refills it as ever)
+  const bool solo_dyn = p.mode == MCKPP_MODE_STEP && solo_ok && !solo_perm && p.solo_limit > 0;   // ... others may go into it
   int it0 = tid;   // this thread's item of the first trip
   auto set_view = [&](int s) {   // s < 0: every slot; else: slot s alone
     const bool one = s >= 0;
@@ -1406,6 +1407,22 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     }
     const unsigned long long m = __ballot(f_any);
     if (lane == 0) s_flags[1] = m != 0ull ? 1 : 0;
+    // One column left in a workgroup that does not refill for now, and that column on its way to itermax (or at itermax
+    // in its previous step): from the next pass on the workgroup works in a view of that slot alone (the iterate changes
+    // hands after that pass's L1, below).  (A slot that holds a ticket it waits to start keeps it until this column is
+    // done, M0: mostly it is this very column's next step.)  Decided here, in the manager's wait behind its L6 items.
+    if (solo_dyn && W == W0) {
+      const int f_solo = s_flags[S_SOLO], f_drain = s_flags[S_DRAIN];
+      if (f_solo < 0 && f_drain) {
+        const bool on = lane < W && sirec[lane * I_COUNT + I_STATE] == PS_ACTIVE && sirec[lane * I_COUNT + I_ACT];
+        const unsigned long long m_on = __ballot(on);
+        if (__popcll(m_on) == 1) {
+          const int s1 = __builtin_ctzll(m_on);
+          const int *msi = sirec + s1 * I_COUNT;
+          if (lane == 0 && msi[I_FIN] == F_NONE && (msi[I_STRAG] || msi[I_NPASS_TRY] > p.solo_after)) s_flags[S_GOSOLO] = s1;
+        }
+      }
+    }
   };
   auto G_late = [&]() {
     int lane = lane_k; asm volatile("" : "+v"(lane));
@@ -1416,20 +1433,6 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         msi[I_BAD] = 0;
         msi[I_TINY] = 0;
         msi[I_MAYBE] = msi[I_MAYBE_NEXT];
-      }
-    }
-    // One column left in a workgroup that does not refill for now, and that column on its way to itermax (or at itermax
-    // in its previous step): from the next pass on the workgroup works in a view of that slot alone (the iterate changes
-    // hands after that pass's L1, below).  (A slot that holds a ticket it waits to start keeps it until this column is
-    // done, M0: mostly it is this very column's next step.)
-    if (p.mode == MCKPP_MODE_STEP && solo_ok && !solo_perm && p.solo_limit > 0 && s_flags[S_SOLO] < 0 && s_flags[S_DRAIN]) {
-      const int stt = lane < W ? sirec[lane * I_COUNT + I_STATE] : PS_DONE;
-      const bool on = lane < W && stt == PS_ACTIVE && sirec[lane * I_COUNT + I_ACT];
-      const unsigned long long m_on = __ballot(on);
-      if (__popcll(m_on) == 1) {
-        const int s1 = __builtin_ctzll(m_on);
-        const int *msi = sirec + s1 * I_COUNT;
-        if (lane == 0 && msi[I_FIN] == F_NONE && (msi[I_STRAG] || msi[I_NPASS_TRY] > p.solo_after)) s_flags[S_GOSOLO] = s1;
       }
     }
   };
