@@ -43,6 +43,7 @@ plus (N=1 only, never part of `value`):
   strong_scaling_proxy the 12,500-column long run's rate relative to the 1e5-column long run's
 """
 import argparse
+import datetime
 import gc
 import json
 import os
@@ -284,6 +285,82 @@ def long_run(mk, cm, ncol, nz, ntotal, dev_index, diag, settle=60, steps=300, ce
             "mean_passes_per_column_step": float(np.mean([q[4] for q in per_step])),
         },
     }
+
+
+def config3_n1_reference():
+    """The N = 1 figure config3_strong is to be compared with: config3_long of the last recorded N = 1 bench line
+    (profiles/config3_long_n1.json, written from it with the library's build id)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "config3_long_n1.json")))
+    except Exception as e:   # noqa: BLE001
+        return {"error": f"profiles/config3_long_n1.json: {type(e).__name__}: {e}"}
+
+
+def config3_strong_block(mk, cm, sharding, dist, rank, world, dev_index, diag, coll_dev, backend, barrier,
+                         ntotal=100000, nz=100, settle=60, steps=200):
+    """BASELINE configs[3] on the N ranks of this run: `ntotal` x `nz` columns dealt round-robin (strong scaling),
+    `settle` untimed model steps, then `steps` more in ONE call per rank between barriers.  ms per step of the slowest
+    rank, every rank's own time, and the N = 1 figure it is to be compared with.  A failure on any rank - or of a
+    collective - becomes the block's text on every rank (sharding.guarded_block); it cannot take the line down."""
+    import torch
+
+    state = {}
+
+    def _local():
+        if os.environ.get("MCKPP_BENCH_FAIL_RANK3") == str(rank):   # (tests)
+            raise RuntimeError("MCKPP_BENCH_FAIL_RANK3")
+        idx = sharding.shard_indices(ntotal, rank, world)
+        kc, k3 = cm.make_hip_case(len(idx), nz, index=idx, ntotal=ntotal)
+        ctx = mk.MckppHip(kc, device=dev_index)
+        ctx.upload(k3)
+        ctx.set_diagnostics(diag)
+        ctx.init_ocean(0)
+        cm.set_forcing_3d(k3, cm.synth.forcing(len(idx), "bench", index=idx))
+        ctx.set_forcing(k3.sflux)
+        ctx.step(1, settle)
+        ctx.synchronize()
+        state["ctx"], state["n"] = ctx, int(ctx.ncolumns)
+        return ctx
+
+    def _timed(ctx):
+        barrier()
+        t0 = time.perf_counter()
+        ctx.step(settle + 1, steps)
+        ctx.synchronize()
+        mine_s = time.perf_counter() - t0
+        barrier()
+        dt = time.perf_counter() - t0
+        st, nflag, npass = ctx.status()
+        cdev = coll_dev if coll_dev is not None else "cpu"
+        v = torch.tensor([mine_s, dt, float(state["n"]), float(npass.max()), float((npass > 50).sum())], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(v) for _ in range(world)]
+        dist.all_gather(every, v)
+        rows = [[float(x) for x in e.tolist()] for e in every]
+        tmax = max(r[1] for r in rows)
+        ncols = int(sum(r[2] for r in rows))
+        return {
+            "workload": f"{ntotal} columns x {nz} levels in all, dealt round-robin over {world} ranks ({state['n']} on rank 0), model steps "
+                        f"{settle + 1}-{settle + steps} in one call per rank after {settle} settle steps (BASELINE configs[3], strong scaling)",
+            "value": ncols * steps / tmax, "unit": "column-steps/s", "ms_per_step": tmax / steps * 1e3,
+            "per_rank_ms_per_step": [r[0] / steps * 1e3 for r in rows],
+            "columns_over_50_passes_last_step_per_rank": [int(r[4]) for r in rows], "max_passes_last_step": int(max(r[3] for r in rows)),
+            "backend": backend, "ranks": world,
+            "n1_reference": config3_n1_reference(),
+            "note": "a column that is at itermax step after step runs its steps one after the other: its chain of ~201 passes "
+                    "per step bounds every rank alike, so the time per step falls with N only down to that chain",
+        }
+
+    try:
+        out, err = sharding.guarded_block(dist, _local, _timed, device=coll_dev)
+    except sharding.AgreementError as e:
+        print(f"bench.py rank {rank}: {e}", file=sys.stderr, flush=True)
+        os._exit(3)
+    try:
+        if "ctx" in state:
+            state["ctx"].close()
+    except Exception:   # noqa: BLE001
+        pass
+    return out if err is None else {"error": err}
 
 
 def headline_variant(mk, cm, ncol, nz, idx, ntotal, a, dev_index, solver_mode=0, tail_frac=0.0):
@@ -624,9 +701,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(dev_index)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index),
+                                    timeout=datetime.timedelta(seconds=180))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
 
     import common as cm
     import mckpp_f90_amd as mk
@@ -699,13 +777,17 @@ def main():
             "collective_ranks": int(round(float(ones.item()))), "world_size": dist.get_world_size(),
         }
         # diagnostics gather (not timed into `value`): hmix and T of every rank's columns to rank 0.  The line does not
-        # depend on it: if the collective fails here (it has run on gloo and on a one-rank RCCL group only), the
-        # failure is what the block says.
-        try:
-            barrier()
+        # depend on it - but every rank must take the same way through it: a rank whose download fails must not leave
+        # the others inside a gather (sharding.guarded_block: the ranks agree on failures before and after the
+        # collectives; if they cannot, the job ends with a non-zero code instead of hanging).
+        def _local_download():
+            if os.environ.get("MCKPP_BENCH_FAIL_RANK") == str(rank):   # (tests: a failure on one rank alone)
+                raise RuntimeError("MCKPP_BENCH_FAIL_RANK")
             t0 = time.perf_counter()
             ctx.download(k3, mk.api.F_SCALARS | mk.api.F_PROFILES)
-            t_down = time.perf_counter() - t0
+            return time.perf_counter() - t0
+
+        def _gathers(t_down):
             barrier()
             t0 = time.perf_counter()
             parts = sharding.gather_to_root(k3.hmix, dist, device=coll_dev)
@@ -718,20 +800,28 @@ def main():
             if coll_dev is not None:
                 torch.cuda.synchronize()
             t_T = time.perf_counter() - t0
-            multi["gather"] = {
-                "what": "hmix (8 B/column) and T (8 (nz+1) B/column) of every rank to rank 0, torch.distributed.gather on "
-                        + ("device tensors (RCCL over xGMI)" if backend == "nccl" else "host tensors (gloo rehearsal)"),
-                "download_scalars_and_profiles_ms": t_down * 1e3, "hmix_ms": t_h * 1e3, "T_ms": t_T * 1e3,
-                "T_bytes_per_rank": int(ncol * (nz + 1) * 8)}
+            g = {"what": "hmix (8 B/column) and T (8 (nz+1) B/column) of every rank to rank 0, torch.distributed.gather on "
+                         + ("device tensors (RCCL over xGMI)" if backend == "nccl" else "host tensors (gloo rehearsal)"),
+                 "download_scalars_and_profiles_ms": t_down * 1e3, "hmix_ms": t_h * 1e3, "T_ms": t_T * 1e3,
+                 "T_bytes_per_rank": int(ncol * (nz + 1) * 8)}
             if rank == 0:
                 hmix_all = sharding.unshard(parts, ntotal)
                 T_all = sharding.unshard(tparts, ntotal)
-                ok = (np.isfinite(hmix_all).all() and hmix_all.shape == (ntotal,) and np.isfinite(T_all).all()
-                      and T_all.shape == (ntotal, nz + 1))
-                multi["gather"]["checked"] = ("hmix and T of all ranks finite and complete on rank 0" if ok else
-                                              "FAILED: hmix / T gathered on rank 0 incomplete or not finite")
-        except Exception as e:   # noqa: BLE001
-            multi["gather"] = {"error": f"{type(e).__name__}: {e}"}
+                g["complete_and_finite"] = bool(np.isfinite(hmix_all).all() and hmix_all.shape == (ntotal,)
+                                                and np.isfinite(T_all).all() and T_all.shape == (ntotal, nz + 1))
+                g["checked"] = ("hmix and T of all ranks finite and complete on rank 0" if g["complete_and_finite"] else
+                                "FAILED: hmix / T gathered on rank 0 incomplete or not finite")
+            return g
+
+        try:
+            g, gerr = sharding.guarded_block(dist, _local_download, _gathers, device=coll_dev)
+        except sharding.AgreementError as e:
+            print(f"bench.py rank {rank}: {e}", file=sys.stderr, flush=True)
+            os._exit(3)
+        multi["gather"] = g if gerr is None else {"error": gerr}
+        # BASELINE configs[3] itself, inside the one command the driver runs: 1e5 x 100 columns dealt round-robin over
+        # the N ranks (strong scaling), model steps 61-260 in ONE call per rank
+        multi["config3_strong"] = config3_strong_block(mk, cm, sharding, dist, rank, world, dev_index, a.diag, coll_dev, backend, barrier)
 
     out = None
     if rank == 0:
@@ -790,6 +880,9 @@ def main():
                                              "its shard - per-rank step times in multi_gpu.per_rank_ms_per_step")
         if multi is not None:
             out["multi_gpu"] = multi
+            # the state gathered on rank 0 must be complete and finite: anything else fails the run (transport errors of
+            # the diagnostics alone do not)
+            out["ok"] = not (isinstance(multi.get("gather"), dict) and multi["gather"].get("complete_and_finite") is False)
 
     if dist is not None:   # the same shards behind one handle, from rank 0's process; the other ranks wait
         barrier()
@@ -930,6 +1023,8 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if out is not None and out.get("ok") is False:
+        raise SystemExit("bench.py: the state gathered on rank 0 is incomplete or not finite")
 
 
 if __name__ == "__main__":

@@ -45,3 +45,53 @@ def gather_to_root(local, dist, device=None, dst=0):
     if rank != dst:
         return None
     return [b[: int(s.item())].cpu().numpy() for b, s in zip(bufs, sizes)]
+
+
+class AgreementError(RuntimeError):
+    """The ranks could not even agree on whether a block of collectives may run: the job must end."""
+
+
+def agree(dist, ok, device=None, timeout_s=120.0):
+    """Collective: True when EVERY rank calls it with ok=True.  An all_reduce(MAX) of a failed flag, waited for with a
+    timeout; if the reduction itself fails or does not complete, AgreementError - nothing that follows could be
+    matched up with the other ranks any more."""
+    import datetime
+
+    import torch
+
+    t = torch.tensor([0.0 if ok else 1.0], dtype=torch.float64, device=device if device is not None else "cpu")
+    try:
+        work = dist.all_reduce(t, op=dist.ReduceOp.MAX, async_op=True)
+        done = work.wait(timeout=datetime.timedelta(seconds=timeout_s))
+        if done is False:
+            raise AgreementError(f"all_reduce of the failure flag did not complete within {timeout_s:.0f} s")
+        return float(t.item()) == 0.0
+    except AgreementError:
+        raise
+    except Exception as e:   # noqa: BLE001
+        raise AgreementError(f"all_reduce of the failure flag failed: {type(e).__name__}: {e}") from e
+
+
+def guarded_block(dist, local, collective, device=None, timeout_s=120.0):
+    """A block of a bench line that must not be able to take the line down, made of a part that only touches this
+    rank (`local()`: downloads, kernel runs - it may fail on one rank alone) and a part of collectives
+    (`collective(x)`, x what local returned - a failure there reaches every rank, or none ever returns).  Every rank
+    learns whether ANY rank's local part failed before the first collective is entered (one that skipped them would
+    leave the others inside a gather until the process group's timeout), and again after the collectives.  Returns
+    (result, None) or (None, error text); raises AgreementError when the ranks cannot agree (the caller exits
+    non-zero: better no line than a hung job)."""
+    err, x = None, None
+    try:
+        x = local()
+    except Exception as e:   # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    if not agree(dist, err is None, device, timeout_s):
+        return None, err or "another rank failed in the local part of this block (collectives skipped on every rank)"
+    out = None
+    try:
+        out = collective(x)
+    except Exception as e:   # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    if not agree(dist, err is None, device, timeout_s):
+        return None, err or "another rank failed in the collectives of this block"
+    return out, None

@@ -113,3 +113,81 @@ def test_one_handle_leg_of_the_bench_cannot_take_the_line_down():
     a = argparse.Namespace(steps=2, warmup=1, ncol=64, nz=40, grid="uniform", dto=3600.0, diag=1, total_ncol=0)
     out = bench.run_single_process_leg(a, [0, 1])
     assert isinstance(out, dict) and "error" in out and "child process" in out["error"]
+
+
+def _guard_worker(rank, world, port, fail_rank, fail_where, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, cm.ROOT)
+    from mckpp_f90_amd import sharding
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    entered = []
+
+    def local():
+        if fail_where == "local" and rank == fail_rank:
+            raise RuntimeError("download failed on this rank alone")
+        return rank * 10
+
+    def collective(x):
+        entered.append(x)
+        t = torch.tensor([float(x)])
+        dist.all_reduce(t)
+        if fail_where == "collective":
+            raise RuntimeError("collective failed everywhere")
+        return float(t.item())
+
+    out, err = sharding.guarded_block(dist, local, collective, timeout_s=30.0)
+    # whatever happened in the block, the ranks are still in step: the next collective matches up
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    q.put((rank, out, err, len(entered), float(t.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_guard(fail_rank, fail_where):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_guard_worker, args=(r, world, port, fail_rank, fail_where, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_a_failure_on_one_rank_cannot_leave_the_others_inside_a_collective():
+    """bench.py's N>1 diagnostics (the gather to rank 0, the config3_strong block) run under sharding.guarded_block:
+    when the part that touches only one rank (a download, a kernel run) fails on ONE rank, every rank skips the
+    collectives - none is left waiting inside a gather until the process group's timeout - and all of them go on in
+    step; when nothing fails the result comes back; a failure inside the collectives is reported on every rank."""
+    res = _run_guard(fail_rank=1, fail_where="local")
+    for rank, out, err, entered, after in res:
+        assert out is None and err is not None and entered == 0 and after == 2.0
+    assert "this rank alone" in res[1][2] and "another rank" in res[0][2]
+    res = _run_guard(fail_rank=-1, fail_where="none")
+    for rank, out, err, entered, after in res:
+        assert err is None and out == 10.0 and entered == 1 and after == 2.0
+    res = _run_guard(fail_rank=-1, fail_where="collective")
+    for rank, out, err, entered, after in res:
+        assert out is None and "collective failed" in err and after == 2.0
+
+
+def test_bench_has_the_config3_block_and_guards_it():
+    """The N>1 line carries BASELINE configs[3] itself (config3_strong: 1e5 x 100 dealt over the ranks, 200 steps in one
+    call past step 60) and the diagnostics gather, both through sharding.guarded_block, and a state gathered on rank 0
+    that is incomplete or not finite fails the run ("ok": false, non-zero exit)."""
+    src = open(os.path.join(cm.ROOT, "bench.py")).read()
+    assert "def config3_strong_block(" in src and 'multi["config3_strong"] = config3_strong_block(' in src
+    assert src.count("sharding.guarded_block(") >= 2 and "os._exit(3)" in src
+    assert 'out["ok"] = not' in src and "incomplete or not finite" in src

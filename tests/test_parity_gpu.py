@@ -672,6 +672,64 @@ def test_several_steps_in_one_launch_equal_a_launch_per_step(mk, monkeypatch, nc
         assert np.array_equal(a[2][idx], ob["npasses"])
 
 
+@pytest.mark.parametrize("ncol,nz,solver", [(1, 60, 0), (700, 100, 0), (9000, 60, 0), (2500, 40, 0), (9000, 60, 1), (700, 100, 1), (300, 69, 0)])
+@pytest.mark.parametrize("forced", [True, False])
+def test_columns_left_alone_in_their_workgroup(mk, monkeypatch, ncol, nz, solver, forced):
+    """A column on its way to itermax is left alone in its workgroup - the other slots are not refilled - and then
+    worked on in a view of that one slot: its level items on the waves other than the manager's, the iterate handed
+    over through LDS, the U,T,S forward sweep as two instruction streams on two waves (k_column_ps: M0, G_early,
+    ps_solo_pivots / ps_solo_solve).  Who works on an item changes, not what is done to it: from the analytic
+    start (second step: 14 % of the columns at itermax - src/mckpp_physics_ocnstep_mod.F90:140-192) every field,
+    status word and pass count must equal the oracle's bit for bit, stepped one launch at a time and as one launch of
+    several steps.  `forced`: every column counts as a straggler from its first pass and every workgroup may leave
+    slots empty (MCKPP_SOLO_AFTER=0, MCKPP_SOLO_LIMIT=1000000) - the view is entered and left all the time, also by
+    columns that finish in it after six passes; otherwise the library's defaults (the 12th pass; few on the device)."""
+    from oracle import orc
+
+    if forced:
+        monkeypatch.setenv("MCKPP_SOLO_AFTER", "0")
+        monkeypatch.setenv("MCKPP_SOLO_LIMIT", "1000000")
+    grid = "stretched" if nz == 69 else "uniform"
+    dto = 1200.0 if nz == 69 else 3600.0
+    nsteps = 4
+    idx = np.arange(0, ncol, max(1, ncol // 150))
+    oc, ob = cm.make_oracle(len(idx), nz, exp_mode=1, index=idx, ntotal=ncol, grid=grid, dto=dto, solver_mode=solver)
+    seen_long = 0
+    for one_launch in (False, True):
+        kc, k3 = cm.make_hip_case(ncol, nz, grid=grid, dto=dto)
+        ctx = mk.MckppHip(kc)
+        ctx.set_solver_mode(solver)
+        ctx.upload(k3)
+        ctx.init_ocean(0)
+        cm.set_forcing_3d(k3, cm.synth.forcing(ncol, "bench"))
+        ctx.set_forcing(k3.sflux)
+        if one_launch:
+            ctx.step(1, nsteps)
+        else:
+            for nt in range(1, nsteps + 1):
+                ctx.step(nt, 1)
+                if not one_launch and nt == 2:
+                    st2, _nf, np2 = ctx.status()
+                    seen_long += int((np2 > 12).sum())
+        ctx.download(k3)
+        st, nf, npass = ctx.status()
+        ctx.close()
+        if not one_launch:
+            for nt in range(1, nsteps + 1):
+                orc.physics_driver(oc, ob, nt)
+
+        class _Sub:
+            pass
+
+        sub = _Sub()
+        for n, v in vars(k3).items():   # the sampled columns of every per-column array of the 3-D fields
+            if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == ncol:
+                setattr(sub, n, v[idx])
+        _assert_bitexact(cm.compare(sub, ob, nz, ALL_FIELDS), f"columns left alone, ncol={ncol} nz={nz} solver={solver} forced={forced} one_launch={one_launch}")
+        assert np.array_equal(st[idx], ob["status"]) and np.array_equal(npass[idx], ob["npasses"])
+    assert seen_long > 0 or ncol == 1 or nz < 60, "no column went past its 12th pass in step 2"
+
+
 # ---- shapes of the column kernel ---------------------------------------------------------------
 # One kernel (k_column_ps) serves every depth: its level phases loop over (slot, level) items, so the shape of
 # a workgroup (slots, waves, trips of the item loop) changes with nz.  The cases below straddle those changes.
