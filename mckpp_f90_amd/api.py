@@ -321,19 +321,30 @@ class MckppHip:
         # array at the same address would be transferred through stale page mappings).  So every array - or object
         # holding arrays - handed to upload / download / set_forcing / gather / window_fetch stays referenced here
         # for exactly that long.
-        self._held = []
+        self._held = {}
         cc = kpp_const_fields.as_c()
         _chk(_lib().mckpp_hip_init(C.byref(cc), int(device), C.byref(self._h)))
 
     def _hold(self, obj):
-        if not any(o is obj for o in self._held):
-            self._held.append(obj)
+        """Keep `obj` referenced while the library may have it pinned.  Arrays are keyed by their address range (the
+        library pins arrays of at least 256 KiB only: smaller ones are not kept), objects holding arrays by identity;
+        a loop that hands over fresh arrays step after step is bounded: at 64 entries everything is unpinned and
+        released first (a caller that wants no re-pinning reuses its arrays, or calls release_host_arrays() itself)."""
+        if isinstance(obj, np.ndarray):
+            if obj.nbytes < 256 * 1024:
+                return
+            key = (obj.ctypes.data, obj.nbytes)
+        else:
+            key = id(obj)
+        if key not in self._held and len(self._held) >= 64:
+            self.release_host_arrays()
+        self._held[key] = obj
 
     def close(self):
         if self._h:
             _lib().mckpp_hip_finalize(self._h)
             self._h = C.c_void_p()
-        self._held = []
+        self._held = {}
 
     def __del__(self):
         try:
@@ -418,7 +429,7 @@ class MckppHip:
         """Un-pin the caller's arrays this context registered (before they are freed while the context lives);
         the references this object holds on them go with the registrations."""
         _chk(_lib().mckpp_hip_release_host_arrays(self._h))
-        self._held = []
+        self._held = {}
 
     def init_ocean(self, ntime=0):
         _chk(_lib().mckpp_hip_init_ocean(self._h, int(ntime)))
@@ -507,17 +518,28 @@ class MckppHipMulti:
         dev = np.ascontiguousarray(devices, dtype=np.int32)
         _chk(_lib().mckpp_hip_multi_init(C.byref(cc), len(dev), dev.ctypes.data_as(_ip), C.byref(self._h)))
         self._npts = 0
-        self._held = []   # host arrays the shards have pinned: referenced until close() / release_host_arrays() (see MckppHip)
+        self._held = {}   # host arrays the shards have pinned: referenced until close() / release_host_arrays() (see MckppHip)
 
     def _hold(self, obj):
-        if not any(o is obj for o in self._held):
-            self._held.append(obj)
+        """Keep `obj` referenced while the library may have it pinned.  Arrays are keyed by their address range (the
+        library pins arrays of at least 256 KiB only: smaller ones are not kept), objects holding arrays by identity;
+        a loop that hands over fresh arrays step after step is bounded: at 64 entries everything is unpinned and
+        released first (a caller that wants no re-pinning reuses its arrays, or calls release_host_arrays() itself)."""
+        if isinstance(obj, np.ndarray):
+            if obj.nbytes < 256 * 1024:
+                return
+            key = (obj.ctypes.data, obj.nbytes)
+        else:
+            key = id(obj)
+        if key not in self._held and len(self._held) >= 64:
+            self.release_host_arrays()
+        self._held[key] = obj
 
     def close(self):
         if self._h:
             _lib().mckpp_hip_multi_finalize(self._h)
             self._h = C.c_void_p()
-        self._held = []
+        self._held = {}
 
     def upload(self, k3):
         self._hold(k3)
@@ -601,7 +623,7 @@ class MckppHipMulti:
 
     def release_host_arrays(self):
         _chk(_lib().mckpp_hip_multi_release_host_arrays(self._h))
-        self._held = []
+        self._held = {}
 
 
 def host_shard_mask(run_physics, ndev, dev):

@@ -749,7 +749,8 @@ __device__ __forceinline__ void ps_thomas2_uts_fwd(int W, double *slots, int SS,
 //   y(m) = (z(m) - gam(m+1) z(m+1)) / (1 - gam(m+1) g(m+1)),  y(m+1) = z(m+1) - g(m+1) y(m),
 // and the two substitutions away from it: DIR = +1 upwards from y(m), DIR = -1 downwards from y(m+1).
 template <int XV, int DIR>
-__device__ __forceinline__ void ps_thomas2_uts_back(int W, double *slots, int SS, int nz, const int *sact, int sact_stride, int lane)
+__device__ __forceinline__ void ps_thomas2_uts_back(int W, double *slots, int SS, int nz, const int *sact, int sact_stride,
+                                                    int *sbad, int sbad_stride, int lane)
 {
   constexpr int KS = XV == 2 ? (int)Q_COUNT_EXT_DD : XV == 1 ? (int)Q_COUNT_EXT : (int)Q_COUNT;
   asm volatile("" : "+v"(lane));   // (see ps_thomas2_uts_fwd)
@@ -760,7 +761,8 @@ __device__ __forceinline__ void ps_thomas2_uts_back(int W, double *slots, int SS
       double *y = base + (Q_YU + sys), *gm = base + ps_sysrows<XV>::gam(sys);
       const int m = nz >> 1;
       const double zt = y[0], zb = y[(nz + 2) * KS], gt = gm[0], gb = gm[KS];
-      const double den = 1. - gt * gb;
+      double den = 1. - gt * gb;
+      if (__builtin_expect(den == 0., 0)) { den = 1.E-12; sbad[sl * sbad_stride] = 1; }   // the middle system's pivot, like tridmat's (both waves alike)
       const double ym = (zt - gt * zb) / den;
       if (DIR > 0) {
         y[(m) * KS] = ym;
@@ -897,7 +899,7 @@ __device__ __forceinline__ void ps_lds_write1(unsigned addr, double a)
   asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(a), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void ps_thomas2_v(int W, double *slots, int SS, int KS, int gam_row, int nz, const int *sact,
-                                             int sact_stride, int lane)
+                                             int sact_stride, int *sbad, int sbad_stride, int lane)
 {
   static_assert(Q_DM == 0 && Q_DT == 1 && Q_YV == 6 && Q_GM == 7 && Q_BET == 8, "offsets of the V sweep's operands in a level block");
   asm volatile("" : "+v"(lane));   // (see ps_thomas2_uts_fwd)
@@ -975,7 +977,8 @@ __device__ __forceinline__ void ps_thomas2_v(int W, double *slots, int SS, int K
     const double other = __shfl_xor(yy, 32);
     const double zt = up ? other : yy, zb = up ? yy : other;
     const double gt = base[gam_row], gb = base[KS + gam_row];
-    const double den = 1. - gt * gb;
+    double den = 1. - gt * gb;
+    if (__builtin_expect(den == 0., 0)) { den = 1.E-12; sbad[sl * sbad_stride] = 1; }   // (as in ps_thomas2_uts_back)
     const double ym = (zt - gt * zb) / den;
     const double ym1 = zb - gb * ym;
     yy = up ? ym1 : ym;
@@ -2401,8 +2404,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       if (wv == wv2) ps_thomas2_uts_fwd<XV, -1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
       STAMP(24);
       __syncthreads();
-      if (wv == mgr) ps_thomas2_uts_back<XV, 1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, lane);
-      if (wv == wv2) ps_thomas2_uts_back<XV, -1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, lane);
+      if (wv == mgr) ps_thomas2_uts_back<XV, 1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+      if (wv == wv2) ps_thomas2_uts_back<XV, -1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
     }
     STAMP(16);
     __syncthreads();
@@ -2466,7 +2469,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           STAMP(25);
           ps_thomas_v_back(W, slots, SS, ROWS, gam_m_off, nz, sirec + I_ACT, I_COUNT, lane);
         } else {
-          ps_thomas2_v(W, slots, SS, ROWS, ps_sysrows<XV>::gam_m, nz, sirec + I_ACT, I_COUNT, lane);
+          ps_thomas2_v(W, slots, SS, ROWS, ps_sysrows<XV>::gam_m, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
         }
       }
       G_late();

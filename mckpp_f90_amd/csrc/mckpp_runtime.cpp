@@ -292,6 +292,16 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
     h->nqueues = 0;
     for (int i = 0; i < 16; ++i) h->xcc_queue[i] = (mask >> i & 1u) ? h->nqueues++ : -1;
     if (h->nqueues == 0) h->multistep = false;
+    // HIP promises nothing about where workgroups run: a launch may leave an XCD the probe saw without any (its queue is
+    // then adopted, whole, by another XCD: k_column_ps M0), or run workgroups on one the probe did not see (they start
+    // without a queue and adopt one, or end).  MCKPP_XCC_DROP=<bit mask of XCC ids> takes the queue away from those XCDs'
+    // workgroups - the queues stay - so that both paths run on a device where they otherwise never would (tests).
+    if (const char *e = getenv("MCKPP_XCC_DROP")) {
+      const unsigned drop = (unsigned)strtoul(e, nullptr, 0);
+      for (int i = 0; i < 16; ++i) if (drop >> i & 1u) h->xcc_queue[i] = -1;
+    }
+    if (getenv("MCKPP_PS_VERBOSE"))
+      fprintf(stderr, "[mckpp] XCC ids seen by the probe: mask 0x%x, %d queues\n", mask, h->nqueues);
   }
   HIPCHK(hipMalloc(&h->d_params, sizeof(mckpp_kparams)));
   h->scratch_doubles = mckpp_ps_scratch_doubles(nzp1, h->ext_kernel ? (c->LDD ? 2 : 1) : 0, h->num_cu);

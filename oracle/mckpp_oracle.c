@@ -559,7 +559,8 @@ int orc_tridmat_2e(const double *cu, const double *cc, const double *cl,
     yn[i] = (rhs[i] - cl[i] * yn[i + 1]) / betb;
   }
   const double gb = cu[m + 1] / betb;                     /* g(m+1) */
-  const double den = 1. - gt * gb;
+  double den = 1. - gt * gb;
+  if (den == 0.) { bad = 1; den = 1.E-12; }               /* the pivot of the 2x2 system in the middle: treated like tridmat's */
   const double ym = (yn[m] - gt * yn[m + 1]) / den;
   const double ym1 = yn[m + 1] - gb * ym;
   yn[m] = ym;

@@ -247,6 +247,24 @@ def test_two_ended_elimination_solves_the_same_system(nz):
         assert L.orc_tridmat_2e(dp(cu), dp(cc2), dp(cl), dp(rhs), dp(yo), nz, dp(y1), dp(g1)) == 1
 
 
+def test_two_ended_elimination_flags_a_singular_middle_system():
+    """The 2x2 system where the two eliminations of orc_tridmat_2e meet has a pivot of its own, 1 - gam(m+1) g(m+1):
+    when it vanishes the solver reports it like any zero pivot of tridmat (solvers.F90:140-151: the status bit, 1e-12 in
+    its place) instead of returning Inf / NaN unflagged - the device's solver mode 1 does the same."""
+    L = orc.lib()
+    n = 8
+    for nz in (2, 3, 6):
+        cu, cc, cl, rhs, yo, y1, g1 = (np.zeros(n + nz) for _ in range(7))
+        cc[1:nz + 1] = 1.0
+        m = nz // 2
+        cl[m] = 1.0; cu[m + 1] = 1.0          # levels m, m+1: [[1, 1], [1, 1]], decoupled from the rest
+        rhs[1:nz + 1] = 2.0
+        assert L.orc_tridmat_2e(dp(cu), dp(cc), dp(cl), dp(rhs), dp(yo), nz, dp(y1), dp(g1)) == 1
+        assert np.isfinite(y1[1:nz + 1]).all()
+        cl[m] = 0.5                            # regular again: no flag
+        assert L.orc_tridmat_2e(dp(cu), dp(cc), dp(cl), dp(rhs), dp(yo), nz, dp(y1), dp(g1)) == 0
+
+
 def test_solver_mode_and_pow_lowering_only_change_last_bits():
     """The oracle's two switches beside exp_mode: solver_mode=1 (two-ended elimination) and half_pow_mode=1 (wst built
     with pow(x, .5), as a compiler without amdflang's square-root rewrite of x**(1./2.) lowers lookup_mod.F90:60-62).

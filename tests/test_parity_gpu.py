@@ -730,6 +730,63 @@ def test_columns_left_alone_in_their_workgroup(mk, monkeypatch, ncol, nz, solver
     assert seen_long > 0 or ncol == 1 or nz not in (60, 100), "no column went past its 12th pass in step 2"
 
 
+@pytest.mark.parametrize("drop", ["0x55", "0xfe"])
+def test_queues_without_workgroups_of_their_own_are_adopted(mk, monkeypatch, drop):
+    """A launch of several steps keeps a column on one XCD (a queue per XCD, the workgroups of an XCD draw from its own:
+    k_column_ps M0).  Where workgroups run is the hardware's choice: with MCKPP_XCC_DROP the workgroups of some XCDs
+    start without a queue - every second XCD, or all but one - so that their queues have no workgroup of their own and
+    must be adopted, whole, by an XCD that has run out of work, and workgroups without a queue must find one or end.
+    Same results as a launch per step, bit for bit."""
+    ncol, nz, nsteps = 9000, 60, 6
+    res = {}
+    for tag, multi in (("one launch", "1"), ("launch per step", "0")):
+        monkeypatch.setenv("MCKPP_MULTISTEP", multi)
+        if multi == "1":
+            monkeypatch.setenv("MCKPP_XCC_DROP", drop)
+        else:
+            monkeypatch.delenv("MCKPP_XCC_DROP", raising=False)
+        kc, k3 = cm.make_hip_case(ncol, nz)
+        ctx = mk.MckppHip(kc)
+        ctx.upload(k3)
+        ctx.init_ocean(0)
+        cm.set_forcing_3d(k3, cm.synth.forcing(ncol, "bench"))
+        ctx.set_forcing(k3.sflux)
+        ctx.step(1, nsteps)
+        ctx.download(k3)
+        st, nf, npass = ctx.status()
+        res[tag] = (k3, st.copy(), npass.copy())
+        ctx.close()
+    a, b = res["one launch"], res["launch per step"]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    for name in ("U", "X", "Us", "Xs", "hmixd", "hmix", "kmix", "Tref", "uref", "vref", "Ssurf", "old", "new_", "rho", "cp", "buoy",
+                 "difm", "difs", "dift", "ghat", "wU", "wX", "wXNT", "Rig", "dbloc", "Shsq"):
+        assert np.array_equal(np.asarray(getattr(a[0], name)), np.asarray(getattr(b[0], name)), equal_nan=True), name
+
+
+def test_fresh_host_arrays_every_step_stay_bounded(mk):
+    """A drop-in loop that hands the library a fresh forcing array every step: the Python layer keeps an array referenced
+    while the library has it pinned, and releases (un-pins) everything when 64 are held - the loop's memory stays
+    bounded - with the same results as one array reused."""
+    ncol, nz = 4000, 40
+    out = []
+    for fresh in (True, False):
+        kc, k3 = cm.make_hip_case(ncol, nz)
+        ctx = mk.MckppHip(kc)
+        ctx.upload(k3)
+        ctx.init_ocean(0)
+        cm.set_forcing_3d(k3, cm.synth.forcing(ncol, "bench"))
+        for nt in range(1, 71):
+            f = k3.sflux.copy(order="F") if fresh else k3.sflux
+            assert f.nbytes >= 256 * 1024
+            ctx.set_forcing(f)
+            ctx.step(nt, 1)
+            assert len(ctx._held) <= 64
+        ctx.download(k3)
+        out.append((np.asarray(k3.hmix).copy(), np.asarray(k3.X).copy()))
+        ctx.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 # ---- shapes of the column kernel ---------------------------------------------------------------
 # One kernel (k_column_ps) serves every depth: its level phases loop over (slot, level) items, so the shape of
 # a workgroup (slots, waves, trips of the item loop) changes with nz.  The cases below straddle those changes.
