@@ -177,6 +177,10 @@ __device__ __forceinline__ ps_d2 ps_lds_read2(unsigned addr)
 }
 template <int N> __device__ __forceinline__ void ps_lds_wait(ps_d2 &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
 template <int N> __device__ __forceinline__ void ps_lds_wait(ps_d2 &a, ps_d2 &b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+template <int N> __device__ __forceinline__ void ps_lds_wait(ps_d2 &a, ps_d2 &b, ps_d2 &c)
+{
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
+}
 template <int N> __device__ __forceinline__ void ps_lds_wait(ps_d2 &a, ps_d2 &b, ps_d2 &c, ps_d2 &d)
 {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
@@ -467,6 +471,118 @@ __device__ __forceinline__ void ps_thomas_uts_fwd(int W, double *slots, int SS, 
           if (__builtin_expect(f_in != 0ull, 0)) level(i, a_p, a_q, a_r, std::true_type{});
           else level(i, a_p, a_q, a_r, std::false_type{});
         }
+      }
+      if (bet == 0.) { bad = 1; bet = 1.E-12; }
+      y[(nz) * KS] = div_by_refined(ynum, bet, rcp_refine(bet));
+      if (bad) sbad[sl * sbad_stride] = 1;
+    }
+  }
+}
+
+// ---- The same forward part with its LDS traffic issued by hand (default physics and optional physics; double diffusion
+// keeps ps_thomas_uts_fwd: its S system's q is not seven rows behind its p).  What the compiler's two-level trip spends
+// beside the recurrence - the votes as compares, or-s and a frexp per level, addresses, its own waits - is a third of
+// its instructions (69 per two levels for 38 fp64 and two reciprocals).  Here a half-trip of two levels takes its
+// operands - (p, q) of either level and the two right-hand sides: three ds_read2_b64 - from registers fetched while
+// the half before ran (two register sets in turn: ps_backsub_from), carries the smallest |pivot| and the smallest
+// exponent of a numerator along instead of comparing per level (one vote per half: a zero pivot, solvers.F90:140-151,
+// or a tiny non-zero numerator), redoes the half on the IEEE path from its entry state and its operands - still in
+// their registers - when the vote fires, and stores its four results with two ds_write2_b64.  Same operations on the
+// same operands as ps_thomas_uts_fwd.
+template <int XV>
+__device__ __forceinline__ void ps_thomas_uts_fwd4(int W, double *slots, int SS, int nz, const int *sact, int sact_stride,
+                                                   int *sbad, int sbad_stride, int lane)
+{
+  static_assert(XV != 2, "p and q rows seven apart");
+  constexpr int KS = XV == 1 ? (int)Q_COUNT_EXT : (int)Q_COUNT;
+  asm volatile("" : "+v"(lane));
+  if (lane < 3 * W) {
+    const int sl = lane / 3, sys = lane - 3 * sl;
+    if (sact[sl * sact_stride]) {
+      double *base = slots + sl * SS;
+      const double *pb = base + ps_sysrows<XV>::p(sys), *qq = pb + 7;
+      double *y = base + (Q_YU + sys), *gm = base + ps_sysrows<XV>::gam(sys);
+      int bad = 0;
+      double pm1 = pb[(1) * KS];
+      double bet = 1. + pm1;
+      double ynum = y[(1) * KS];
+      asm volatile("" : "+v"(pm1), "+v"(bet), "+v"(ynum));   // their waits here, not inside the loop
+      // one level, IEEE form, on operands at hand: gam(i) and y(i-1)
+      auto slow_level = [&](double p, double q, double rhs, double &g_out, double &y_out) {
+        if (bet == 0.) { bad = 1; bet = 1.E-12; }
+        const double rb = rcp_refine(bet);
+        const double g = div_by_refined(-pm1, bet, rb);
+        const double yprev = div_by_refined(ynum, bet, rb);
+        g_out = g; y_out = yprev;
+        bet = ((1. + p) + q) + q * g;
+        ynum = rhs + q * yprev;
+        pm1 = p;
+      };
+      int i = 2;
+      if (i + 1 <= nz) {
+        // one address register per row (p with q seven rows behind it; the solution row, whose entry i-1 takes y(i-1) and
+        // whose entries i, i+1, .. are the right-hand sides; gam), everything else is an offset field of the instruction:
+        // H = the half-trip, counted from the levels worked on (0: levels i, i+1; 1: i+2, i+3; 2: the next trip's first)
+        unsigned ap = ps_lds_addr(pb + i * KS), ay = ps_lds_addr(y + (i - 1) * KS), ag = ps_lds_addr(gm + i * KS);
+        auto rd_pq = [&](unsigned a, auto H) { constexpr int o = 2 * KS * decltype(H)::value; return ps_lds_read2<o, o + 7>(a); };             // (p, q) of a level
+        auto rd_pq1 = [&](unsigned a, auto H) { constexpr int o = 2 * KS * decltype(H)::value + KS; return ps_lds_read2<o, o + 7>(a); };      // ... of the next
+        auto rd_rr = [&](unsigned a, auto H) { constexpr int o = 2 * KS * decltype(H)::value + KS; return ps_lds_read2<o, o + KS>(a); };       // right-hand sides of the two
+        using H0 = std::integral_constant<int, 0>; using H1 = std::integral_constant<int, 1>; using H2 = std::integral_constant<int, 2>;
+        // a half-trip at the level of (ay_, ag_) on operands (pq0, pq1, rr): two levels
+        auto two = [&](auto H, const ps_d2 &pq0, const ps_d2 &pq1, const ps_d2 &rr) {
+          const double s_pm1 = pm1, s_bet = bet, s_ynum = ynum;
+          // the first level
+          double amin = __builtin_fabs(bet);
+          int emin = __builtin_amdgcn_frexp_exp(ynum);
+          double rb = rcp_refine(bet);
+          double g0 = div_fast(-pm1, bet, rb), y0 = div_fast(ynum, bet, rb);
+          bet = ((1. + pq0.x) + pq0.y) + pq0.y * g0;
+          ynum = rr.x + pq0.y * y0;
+          // the second
+          amin = __builtin_fmin(amin, __builtin_fabs(bet));
+          emin = min(emin, __builtin_amdgcn_frexp_exp(ynum));
+          rb = rcp_refine(bet);
+          double g1 = div_fast(-pq0.x, bet, rb), y1 = div_fast(ynum, bet, rb);
+          bet = ((1. + pq1.x) + pq1.y) + pq1.y * g1;
+          ynum = rr.y + pq1.y * y1;
+          pm1 = pq1.x;
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(amin == 0. || emin < -960) != 0ull, 0)) {
+            // again from the half's entry state: IEEE divisions, a zero pivot replaced (registers only: the stores below
+            // are the only LDS traffic of a half, whichever way it went - the wait counts rely on it)
+            pm1 = s_pm1; bet = s_bet; ynum = s_ynum;
+            slow_level(pq0.x, pq0.y, rr.x, g0, y0);
+            slow_level(pq1.x, pq1.y, rr.y, g1, y1);
+          }
+          // y(i-1), y(i); gam(i), gam(i+1)
+          constexpr int o = 2 * KS * decltype(H)::value;
+          ps_lds_write2<o, o + KS>(ay, y0, y1);
+          ps_lds_write2<o, o + KS>(ag, g0, g1);
+        };
+        ps_d2 a0 = rd_pq(ap, H0{}), a1 = rd_pq1(ap, H0{}), ar = rd_rr(ay, H0{}), b0, b1, br;   // levels i, i+1
+        ps_lds_wait<0>(a0, a1, ar);
+        // Four levels per trip.  The second half's operands are fetched at the top of the trip and waited for behind the
+        // first half; the next trip's first half is fetched behind the first half and waited for at the bottom of the
+        // trip, behind the second: nothing is in flight across the loop's back edge (the compiler moves loop-carried
+        // values between registers there - tools/check_inflight.py).  The fetches run two levels ahead of the levels
+        // worked on: i + 5 <= nz + 2, the last entry of the rows.
+        while (i + 3 <= nz) {
+          b0 = rd_pq(ap, H1{}); b1 = rd_pq1(ap, H1{}); br = rd_rr(ay, H1{});
+          two(H0{}, a0, a1, ar);
+          a0 = rd_pq(ap, H2{}); a1 = rd_pq1(ap, H2{}); ar = rd_rr(ay, H2{});
+          ps_lds_wait<5>(b0, b1, br);   // (behind it: the first half's two stores, the three reads just issued)
+          two(H1{}, b0, b1, br);
+          ps_lds_wait<2>(a0, a1, ar);   // (behind it: the second half's two stores)
+          constexpr unsigned step = 4u * (unsigned)KS * 8u;
+          i += 4; ap += step; ay += step; ag += step;
+        }
+        if (i + 1 <= nz) { two(H0{}, a0, a1, ar); i += 2; }
+        ps_lds_drain();
+      }
+      // the level the halves leave over, and the last pivot
+      if (i <= nz) {
+        double g, yp;
+        slow_level(pb[(i) * KS], qq[(i) * KS], y[(i) * KS], g, yp);
+        y[(i - 1) * KS] = yp; gm[(i) * KS] = g;
       }
       if (bet == 0.) { bad = 1; bet = 1.E-12; }
       y[(nz) * KS] = div_by_refined(ynum, bet, rcp_refine(bet));
@@ -1031,6 +1147,11 @@ __device__ __forceinline__ void ps_thomas2_v(int W, double *slots, int SS, int K
     }
   }
 }
+
+#ifndef MCKPP_PS_FWD4
+#define MCKPP_PS_FWD4 1
+#endif
+constexpr bool PS_FWD4 = MCKPP_PS_FWD4 != 0;   // the U,T,S forward sweep four levels per trip (ps_thomas_uts_fwd4); 0: the two-level form (A/B builds)
 
 template <int KS>
 struct strided {   // x[i] of a level-interleaved row
@@ -2317,7 +2438,10 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     const int nwaves = nthreads >> 6, lwaves = (nitems + 63) >> 6;   // (view of one slot: waves 1..lwaves hold the level items)
     // (measured, r05: 29.2 -> 27.2 us per pass at 100 levels and 22.0 -> 21.1 at 60 in workgroups of 16 and 8 waves; in a
     // one-slot workgroup of four waves the one-stream form is the faster: 26.0 against 27.5, 19.8 against 21.9)
-    const bool split = SM == 0 && do_ocnint && W == 1 && it0 != tid && nwaves >= 8;
+#ifndef MCKPP_PS_SPLIT_MINWAVES
+#define MCKPP_PS_SPLIT_MINWAVES 8
+#endif
+    const bool split = SM == 0 && do_ocnint && W == 1 && it0 != tid && nwaves >= MCKPP_PS_SPLIT_MINWAVES;
     const int wv_ctl = split ? (lwaves + 1 < nwaves ? lwaves + 1 : nwaves - 1) : mgr;
     // where gam of the momentum system is (L7, the V sweep): its row of the slot, or - two streams - of the spare block
     const int gam_m_off = split ? (int)(xsc - slots) + PS_X_GAM : (int)ps_sysrows<XV>::gam_m;
@@ -2386,7 +2510,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     if constexpr (SM == 0) {
       if (wv == mgr && do_ocnint) {
         if (!split) {
-          ps_thomas_uts_fwd<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+          if constexpr (XV != 2 && PS_FWD4) ps_thomas_uts_fwd4<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+          else ps_thomas_uts_fwd<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
           STAMP(24);
           ps_thomas_uts_back<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, lane);
         } else {
