@@ -135,12 +135,9 @@ __host__ inline int ps_ss(int L, int xv, int W)
   return best;
 }
 __host__ __device__ inline int ps_scratch_ld(int nzp1) { return (nzp1 + 7) & ~7; }   // row length of the iterate's scratch
-// the spare block of rows of the view of one slot (what ps_solo_pivots hands over: gam and the pivots of every
-// factorisation): a workgroup of several slots has an idle neighbour slot's block, a workgroup of one slot gets one here
-__host__ __device__ inline int ps_xtra_doubles(int L, int W, int xv) { return W == 1 ? ps_rows(xv) * ps_nl(L) : 0; }
 __host__ inline size_t ps_lds_bytes(int L, int W, int xv)
 {
-  return (size_t)(K_STRIDE * ps_nl(L) + 2 + W * ps_ss(L, xv, W) + W * C_COUNT + ps_xtra_doubles(L, W, xv)) * sizeof(double) +
+  return (size_t)(K_STRIDE * ps_nl(L) + 2 + W * ps_ss(L, xv, W) + W * C_COUNT) * sizeof(double) +
          (size_t)(W * I_COUNT + 16) * sizeof(int);
 }
 
@@ -591,182 +588,6 @@ __device__ __forceinline__ void ps_thomas_uts_fwd4(int W, double *slots, int SS,
   }
 }
 
-// ---- The view of one slot (one column has the workgroup to itself), solver mode 0: the same forward part as TWO
-// instruction streams on two waves.  A level of ps_thomas_uts_fwd is the pivot chain bet -> 1/bet -> gam -> bet' (13
-// dependent instructions) with the solution chain y(i-1) = num/bet, num' = rhs + q y(i-1) riding along (6 more): with
-// fifteen columns in the lanes that is the cheapest form, for ONE column the second chain only lengthens the first.
-// Here the manager wave runs the pivot chains alone (lane = factorisation: momentum | T, which is S's too unless double
-// diffusion separates them) and leaves bet(i) of every level in `xb`; another wave follows with the solution chains
-// (lane = system U, T, S), forming 1/bet again from the same bet - the same instructions on the same operand - and
-// reads how far the pivots have come from a progress word (LDS returns a wave's accesses in order, so a pivot stored
-// before the word is there when the word says so).  Same operations on the same operands as the one-stream form, the
-// replacement of a zero pivot (solvers.F90:140-151) and the IEEE division of a tiny numerator included.
-// The rows of the spare block (same level stride as a slot's): gam and the pivots, per factorisation (0 momentum, 1
-// temperature - and salinity, unless double diffusion gives it its own: 2).  The slot's own gam rows cannot take them here:
-// the momentum system's still holds dift for the L6 that runs beside the pivot chains, and gam of T (and S) would
-// overwrite the q the other stream has yet to read.
-enum { PS_X_GAM = 0, PS_X_BET = 3 };
-template <int XV> __device__ __forceinline__ int ps_solo_fact(int sys) { return XV == 2 ? sys : sys == 0 ? 0 : 1; }
-__device__ __forceinline__ void ps_lds_store_b32(unsigned addr, int v) { asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(v) : "memory"); }
-__device__ __forceinline__ int ps_lds_load_b32(unsigned addr)
-{
-  int v;
-  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-template <int XV>
-__device__ __forceinline__ void ps_solo_pivots(double *base, double *xb, int nz, int *sbad, int *prog, int lane)
-{
-  constexpr int KS = XV == 2 ? (int)Q_COUNT_EXT_DD : XV == 1 ? (int)Q_COUNT_EXT : (int)Q_COUNT;
-  constexpr int NF = XV == 2 ? 3 : 2;   // factorisations
-  asm volatile("" : "+v"(lane));
-  const unsigned pa = (unsigned)(unsigned long long)prog;
-  if (lane < NF) {
-    const int sys = lane;   // its system in ps_sysrows' numbering: 0 momentum, 1 temperature (and salinity), 2 salinity
-    const double *pb = base + ps_sysrows<XV>::p(sys), *qq = XV == 2 ? base + ps_sysrows<XV>::q(sys) : pb + 7;
-    double *gm = xb + (PS_X_GAM + sys), *o = xb + (PS_X_BET + sys);
-    int bad = 0;
-    double pm1 = pb[(1) * KS];
-    double bet = 1. + pm1;
-    auto level = [&](int i, double p, double q, auto slow) {   // the pivot of level i - 1 is final: out with it, on to level i's
-      if (slow.value && bet == 0.) { bad = 1; bet = 1.E-12; }
-      o[(i - 1) * KS] = bet;
-      const double rb = rcp_refine(bet);
-      const double g = slow.value ? div_by_refined(-pm1, bet, rb) : div_fast(-pm1, bet, rb);
-      gm[(i) * KS] = g;
-      bet = ((1. + p) + q) + q * g;
-      pm1 = p;
-    };
-    unsigned long long f_in = 0ull;
-    int i = 2;
-    double a_p = pb[(2) * KS], a_q = qq[(2) * KS];
-    for (; i + 1 <= nz; i += 2) {
-      const double b_p = pb[(i + 1) * KS], b_q = qq[(i + 1) * KS];
-      const double s_pm1 = pm1, s_bet = bet;
-      level(i, a_p, a_q, std::false_type{});
-      const unsigned long long f_mid = __builtin_amdgcn_ballot_w64(bet == 0.);
-      level(i + 1, b_p, b_q, std::false_type{});
-      if (__builtin_expect((f_in | f_mid) != 0ull, 0)) {
-        pm1 = s_pm1; bet = s_bet;
-        level(i, a_p, a_q, std::true_type{});
-        level(i + 1, b_p, b_q, std::true_type{});
-      }
-      f_in = __builtin_amdgcn_ballot_w64(bet == 0.);
-      if (lane == 0) ps_lds_store_b32(pa, i);   // the pivots of the levels up to i are in place
-      a_p = pb[(i + 2) * KS]; a_q = qq[(i + 2) * KS];   // (i + 2 <= nzp1: inside the rows; unused after the last trip)
-    }
-    if (i <= nz) {
-      if (__builtin_expect(f_in != 0ull, 0)) level(i, a_p, a_q, std::true_type{});
-      else level(i, a_p, a_q, std::false_type{});
-    }
-    if (bet == 0.) { bad = 1; bet = 1.E-12; }
-    o[(nz) * KS] = bet;
-    if (lane == 0) ps_lds_store_b32(pa, nz);
-    if (bad) *sbad = 1;
-  }
-}
-__device__ __forceinline__ double ps_lds_read1(unsigned addr)
-{
-  double v;
-  asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-template <int N> __device__ __forceinline__ void ps_lds_wait(double &a, double &b, double &c, double &d, double &e, double &f)
-{
-  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(N));
-}
-// The solution chains behind the pivots: y(i-1) = num / bet(i-1), num' = rhs(i) + q(i) y(i-1); lane = system.  Two levels
-// per trip, their six operands fetched a trip ahead (ps_lds_read1 / ps_lds_wait: nothing is in flight across the
-// progress word's read, which waits for everything), the reciprocals formed before the chain needs them.
-template <int XV>
-__device__ __forceinline__ void ps_solo_solve(double *base, const double *xb, int nz, int *prog, int lane)
-{
-  constexpr int KS = XV == 2 ? (int)Q_COUNT_EXT_DD : XV == 1 ? (int)Q_COUNT_EXT : (int)Q_COUNT;
-  asm volatile("" : "+v"(lane));
-  const unsigned pa = (unsigned)(unsigned long long)prog;
-  if (lane < 3) {
-    const int sys = lane;
-    const double *qq = base + ps_sysrows<XV>::q(sys), *o = xb + (PS_X_BET + ps_solo_fact<XV>(sys));
-    double *y = base + (Q_YU + sys);
-    double ynum = y[(1) * KS];
-    asm volatile("" : "+v"(ynum));
-    int have = 0;
-    auto need = [&](int lev) {   // the pivots of the levels up to `lev` are in place
-      while (have < lev) { have = ps_lds_load_b32(pa); if (have < lev) __builtin_amdgcn_s_sleep(1); }
-    };
-    constexpr unsigned step = (unsigned)KS * 8u;
-    unsigned aq = ps_lds_addr(qq + 2 * KS), ay = ps_lds_addr(y + 2 * KS), ab = ps_lds_addr(o + 1 * KS);   // q(i), rhs(i), bet(i-1) of i = 2
-    int i = 2;
-    if (i + 1 <= nz) {
-      double b0, q0, r0, b1, q1, r1, c0, c1, c2, c3, c4, c5;
-      need(i);
-      b0 = ps_lds_read1(ab); q0 = ps_lds_read1(aq); r0 = ps_lds_read1(ay);
-      b1 = ps_lds_read1(ab + step); q1 = ps_lds_read1(aq + step); r1 = ps_lds_read1(ay + step);
-      auto two = [&](unsigned ay_, double be0, double qv0, double rh0, double be1, double qv1, double rh1) {
-        const double y_in = ynum;
-        const double rb0 = rcp_refine(be0), rb1 = rcp_refine(be1);
-        double y0 = div_fast(ynum, be0, rb0);
-        double n1 = rh0 + qv0 * y0;
-        double y1 = div_fast(n1, be1, rb1);
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tiny_nonzero(y_in) || tiny_nonzero(n1)) != 0ull, 0)) {
-          y0 = div_by_refined(y_in, be0, rb0);
-          n1 = rh0 + qv0 * y0;
-          y1 = div_by_refined(n1, be1, rb1);
-        }
-        ynum = rh1 + qv1 * y1;
-        // y(i-1), y(i): one level apart in the solution row
-        if (KS == 9) ps_lds_write2<0, 9>(ay_ - step, y0, y1);
-        else if (KS == 11) ps_lds_write2<0, 11>(ay_ - step, y0, y1);
-        else ps_lds_write2<0, 15>(ay_ - step, y0, y1);
-      };
-      while (i + 5 <= nz) {   // this trip, the next, and one more after it (two register sets, no copies: ps_backsub_from)
-        need(i + 2);
-        c0 = ps_lds_read1(ab + 2 * step); c1 = ps_lds_read1(aq + 2 * step); c2 = ps_lds_read1(ay + 2 * step);
-        c3 = ps_lds_read1(ab + 3 * step); c4 = ps_lds_read1(aq + 3 * step); c5 = ps_lds_read1(ay + 3 * step);
-        ps_lds_wait<6>(b0, q0, r0, b1, q1, r1);
-        two(ay, b0, q0, r0, b1, q1, r1);
-        need(i + 4);
-        b0 = ps_lds_read1(ab + 4 * step); q0 = ps_lds_read1(aq + 4 * step); r0 = ps_lds_read1(ay + 4 * step);
-        b1 = ps_lds_read1(ab + 5 * step); q1 = ps_lds_read1(aq + 5 * step); r1 = ps_lds_read1(ay + 5 * step);
-        ps_lds_wait<6>(c0, c1, c2, c3, c4, c5);
-        two(ay + 2 * step, c0, c1, c2, c3, c4, c5);
-        i += 4; ab += 4 * step; aq += 4 * step; ay += 4 * step;
-      }
-      // (past the loop nothing stays in flight across a branch: see ps_backsub_from)
-      ps_lds_wait<0>(b0, q0, r0, b1, q1, r1);
-      two(ay, b0, q0, r0, b1, q1, r1);
-      i += 2;
-      if (i + 1 <= nz) {
-        need(i);
-        c0 = ps_lds_read1(ab + 2 * step); c1 = ps_lds_read1(aq + 2 * step); c2 = ps_lds_read1(ay + 2 * step);
-        c3 = ps_lds_read1(ab + 3 * step); c4 = ps_lds_read1(aq + 3 * step); c5 = ps_lds_read1(ay + 3 * step);
-        ps_lds_wait<0>(c0, c1, c2, c3, c4, c5);
-        two(ay + 2 * step, c0, c1, c2, c3, c4, c5);
-        i += 2;
-      }
-      ps_lds_drain();
-    }
-    for (; i <= nz + 1; ++i) {   // the last level or two, and y(nz) = num / bet(nz)
-      const double q = i <= nz ? qq[(i) * KS] : 0., rhs = i <= nz ? y[(i) * KS] : 0.;
-      need(i <= nz ? i - 1 : nz);
-      const double bet = o[(i - 1) * KS];
-      const double rb = rcp_refine(bet);
-      // (the last division is the one-stream form's div_by_refined; the others take it for a tiny numerator only)
-      const double yprev = (i > nz || __builtin_expect(tiny_nonzero(ynum), 0)) ? div_by_refined(ynum, bet, rb) : div_fast(ynum, bet, rb);
-      y[(i - 1) * KS] = yprev;
-      ynum = rhs + q * yprev;
-    }
-  }
-}
-
-template <int XV>
-__device__ __forceinline__ void ps_solo_back(double *base, const double *xb, int nz, int lane)
-{
-  constexpr int KS = XV == 2 ? (int)Q_COUNT_EXT_DD : XV == 1 ? (int)Q_COUNT_EXT : (int)Q_COUNT;
-  asm volatile("" : "+v"(lane));
-  if (lane < 3) ps_backsub(base + (Q_YU + lane), xb + (PS_X_GAM + ps_solo_fact<XV>(lane)), KS, nz);
-}
-
 template <int XV>
 __device__ __forceinline__ void ps_thomas_uts_back(int W, double *slots, int SS, int nz, const int *sact, int sact_stride, int lane)
 {
@@ -1183,15 +1004,13 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   double *c_misc = lds + K_STRIDE * NL;
   double *const slots0 = c_misc + 2;
   double *const screc0 = slots0 + W0 * SS;
-  double *const xtra0 = screc0 + W0 * C_COUNT;   // (a one-slot workgroup's own rows for the pivots of ps_solo_pivots)
-  int *const sirec0 = reinterpret_cast<int *>(xtra0 + ps_xtra_doubles(L, W0, XV));
+  int *const sirec0 = reinterpret_cast<int *>(screc0 + W0 * C_COUNT);
   // [0] some slot active, [1] some slot finishing, [2] the level the bulk-Ri scan of this pass ended at, [3] the level
   // down to which L3 forms the bulk Richardson numbers (a guess from the pass before), [4] the guess was too shallow,
   // [5] the scan stopped early, [6] some slot waits for its ticket, [7] the queue M0 draws from,
   // [S_SOLO] the slot the workgroup works on ALONE (-1: none), [S_GOSOLO] the slot to go on alone with from this pass's
   // L2 on (-1: none), [S_DRAIN] M0 does not refill for now (a straggler is being left alone, or the queue is used up)
-  // [S_PROG] how far the pivots of ps_solo_pivots have come, [S_L6CNT] waves done with their L6 items (view of one slot)
-  enum { S_SOLO = 8, S_DRAIN = 9, S_GOSOLO = 10, S_PROG = 11, S_L6CNT = 12 };
+  enum { S_SOLO = 8, S_DRAIN = 9, S_GOSOLO = 10 };
   int *s_flags = sirec0 + W0 * I_COUNT;
   // ---- the VIEW a pass works in.  Normally every slot of the workgroup, the items of the first trip dealt from thread 0
   // on.  A column that iterates towards itermax (200 passes where the others take 6) bounds a long run by its own chain
@@ -1202,7 +1021,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // lone column too, which with its items on the manager wave itself ran one after the other.  Same operations, same
   // operands: a view changes who works on an item, never what is done to it.
   int W = W0;
-  double *slots = slots0, *screc = screc0, *xsc = nullptr;
+  double *slots = slots0, *screc = screc0;
   int *sirec = sirec0;
 
   for (int i = tid; i < NL; i += blockDim.x) {
@@ -1249,7 +1068,6 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     const int so = one ? s : 0;
     W = one ? 1 : W0;
     slots = slots0 + so * SS; screc = screc0 + so * C_COUNT; sirec = sirec0 + so * I_COUNT;
-    xsc = !one ? nullptr : W0 == 1 ? xtra0 : slots0 + (s + 1 == W0 ? 0 : s + 1) * SS;   // free rows: its own, or an idle neighbour slot's
     nitems = W * L; nitems_lm = W * nzp1;
     it0 = one ? (tid >= 64 ? tid - 64 : 0x3fffffff) : tid;
   };
@@ -2342,10 +2160,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       }
       if (isnzp1) my[k * ROWS + Q_YU] = Uo;   // solvers.F90:159
     };
-    if (wv == mgr) {
-      M3();   // (the ocnstep control, G_early, follows behind the manager's own L6 items, where it would wait)
-      if (lane == 0) { s_flags[S_PROG] = 0; s_flags[S_L6CNT] = 0; }   // (ps_solo_pivots / ps_solo_solve, below)
-    }
+    if (wv == mgr) M3();   // (the ocnstep control, G_early, follows behind the manager's own L6 items, where it would wait)
     else if (do_ocnint) {
       FOR_ITEMS
         if (!act) continue;
@@ -2431,26 +2246,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(13);
 
     // ---- L6: right-hand sides of U, T, S (ocnint_mod.F90:51-58, tridrhs solvers.F90:53-107)
-    // In the view of one slot (solver mode 0) the manager wave does not wait for them: it starts the pivot chains of
-    // the U,T,S solve at once (ps_solo_pivots: they need the sweeps' coefficients of L5 only), wave 1 follows with the
-    // solution chains once every wave is done with its L6 items (a counter in LDS), and the ocnstep control runs on a
-    // wave that has nothing else to do.
-    const int nwaves = nthreads >> 6, lwaves = (nitems + 63) >> 6;   // (view of one slot: waves 1..lwaves hold the level items)
-    // (measured, r05: 29.2 -> 27.2 us per pass at 100 levels and 22.0 -> 21.1 at 60 in workgroups of 16 and 8 waves; in a
-    // one-slot workgroup of four waves the one-stream form is the faster: 26.0 against 27.5, 19.8 against 21.9)
-#ifndef MCKPP_PS_SPLIT_MINWAVES
-#define MCKPP_PS_SPLIT_MINWAVES 8
-#endif
-    const bool split = SM == 0 && do_ocnint && W == 1 && it0 != tid && nwaves >= MCKPP_PS_SPLIT_MINWAVES;
-    const int wv_ctl = split ? (lwaves + 1 < nwaves ? lwaves + 1 : nwaves - 1) : mgr;
-    // where gam of the momentum system is (L7, the V sweep): its row of the slot, or - two streams - of the spare block
-    const int gam_m_off = split ? (int)(xsc - slots) + PS_X_GAM : (int)ps_sysrows<XV>::gam_m;
-    if (split && wv == mgr) {
-      STAMP(14);
-      ps_solo_pivots<XV>(slots, xsc, nz, sirec + I_BAD, s_flags + S_PROG, lane);
-      STAMP(24);
-    }
-    if (do_ocnint && !(split && wv == mgr)) {
+    if (do_ocnint) {
       FOR_ITEMS
         if (!act) continue;
         const strided<ROWS> aDt = row(ps_sysrows<XV>::dl6_t), aDs = row(ps_sysrows<XV>::dl6_s), aGh = row(Q_YV);
@@ -2491,32 +2287,18 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     }
     // The ocnstep control of this pass: nothing in L5 / L6 reads what it writes, and here the manager wave - one trip of
     // items where the others have two - would only wait at the barrier.
-    if (split) {
-      if (wv >= 1 && wv <= lwaves && lane == 0)   // this wave's right-hand sides are in their rows
-        __hip_atomic_fetch_add(s_flags + S_L6CNT, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (wv == wv_ctl) G_early();
-      if (wv == 1) {
-        while (__hip_atomic_load(s_flags + S_L6CNT, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < lwaves) __builtin_amdgcn_s_sleep(2);
-        ps_solo_solve<XV>(slots, xsc, nz, s_flags + S_PROG, lane);
-      }
-    } else if (wv == mgr) {
-      G_early();
-      STAMP(14);
-    }
+    if (wv == mgr) G_early();
+    STAMP(14);
     __syncthreads();
     STAMP(15);
 
     // ---- M4: Thomas factorise + sweep for U, T, S (solvers.F90:14-44, 112-161)
     if constexpr (SM == 0) {
       if (wv == mgr && do_ocnint) {
-        if (!split) {
-          if constexpr (XV != 2 && PS_FWD4) ps_thomas_uts_fwd4<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
-          else ps_thomas_uts_fwd<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
-          STAMP(24);
-          ps_thomas_uts_back<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, lane);
-        } else {
-          ps_solo_back<XV>(slots, xsc, nz, lane);
-        }
+        if constexpr (XV != 2 && PS_FWD4) ps_thomas_uts_fwd4<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+        else ps_thomas_uts_fwd<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+        STAMP(24);
+        ps_thomas_uts_back<XV>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, lane);
       }
     } else if (do_ocnint) {
       // solver mode 1: the upper half of every system on the manager wave, the lower half on another wave
@@ -2549,7 +2331,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           // recurrence itself: the pivot and its refined reciprocal, exactly the values the U sweep formed (same
           // operations on the same p, q, gam; solvers.F90:140-151's replacement of a zero pivot included), into
           // two rows the T and S systems are done with
-          const double pk = row(Q_DM)[k], qk = row(Q_GM)[k], gk = my[k * ROWS + gam_m_off];
+          const double pk = row(Q_DM)[k], qk = row(Q_GM)[k], gk = row(ps_sysrows<XV>::gam_m)[k];
           double betk;
           if constexpr (SM == 0) {
             betk = (k == 1) ? 1. + pk : ((1. + pk) + qk) + qk * gk;
@@ -2592,7 +2374,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
         if constexpr (SM == 0) {
           ps_thomas_v_fwd(W, slots, SS, ROWS, nz, sirec + I_ACT, I_COUNT, lane);
           STAMP(25);
-          ps_thomas_v_back(W, slots, SS, ROWS, gam_m_off, nz, sirec + I_ACT, I_COUNT, lane);
+          ps_thomas_v_back(W, slots, SS, ROWS, ps_sysrows<XV>::gam_m, nz, sirec + I_ACT, I_COUNT, lane);
         } else {
           ps_thomas2_v(W, slots, SS, ROWS, ps_sysrows<XV>::gam_m, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
         }
@@ -2941,7 +2723,7 @@ ps_geom ps_choose(int L, int xv, size_t cu_lds_bytes, int cols_per_cu, int *max_
     }
   }
   int need = (best.w * L + 63) / 64;
-  if (best.w == 1) need += 2;   // a workgroup of one slot: a wave for the manager beside the waves of the level items (the view of one slot), and a free one
+  if (best.w == 1) ++need;   // a workgroup of one slot: a wave for the manager beside the waves of the level items (the view of one slot)
   if (need < best.nw) best.nw = need;
   if (max_slots_per_cu) *max_slots_per_cu = most;
   return best;
