@@ -2369,6 +2369,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(19);
 
     // ---- M5: Thomas sweep for V on the stored momentum factorisation | the next pass's L1 but for V
+    // (solver mode 1's V sweep can flag its middle pivot: there the bookkeeping stays behind it)
+    const bool late_on_mgr = SM != 0 || nthreads <= 64;
     if (wv == mgr) {
       if (do_ocnint) {
         if constexpr (SM == 0) {
@@ -2379,13 +2381,19 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           ps_thomas2_v(W, slots, SS, ROWS, ps_sysrows<XV>::gam_m, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
         }
       }
-      G_late();
-     
-    } else if (l1_ahead) {   // meanwhile: the next pass's L1, all but V, for the items of slots that go on iterating
+      if (late_on_mgr) G_late();
+    } else {
+      // The end-of-pass bookkeeping (G_late) runs here, on the workgroup's last wave, under the V sweep - not behind it on
+      // the manager wave, where its LDS round trips were 1.2 k cycles of every pass: nothing it touches (the status word,
+      // the zero-pivot flag of M4, the tiny-term flag of L2a, this pass's `may be the last` flag) is read or written by
+      // the V sweep in the reference-order mode or by the L1 that runs beside it.
+      if (!late_on_mgr && wv == (nthreads >> 6) - 1) G_late();
+      if (l1_ahead) {   // meanwhile: the next pass's L1, all but V, for the items of slots that go on iterating
       FOR_ITEMS
         if (!si[I_L1A]) continue;
         L1_item(k, kr, si, my, sc, ro, act, virt1, virt2, is1, xs_, first_, L1_ALL_BUT_V);
       END_ITEMS
+      }
     }
     STAMP(20);
     __syncthreads();
