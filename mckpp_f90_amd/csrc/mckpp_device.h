@@ -94,6 +94,7 @@ struct mckpp_kparams_t {
   // Stragglers (k_column_ps, M0 / G_late): columns on their way to itermax are left alone in their workgroup.
   P<int> sync;        // [0] stragglers the device holds right now (zeroed per launch)
   int solo_after;     // a column past this many passes of a try is one (default 12; MCKPP_SOLO_AFTER)
+  int view_kmax;      // most slots of a view (0: as many as the workgroup's waves other than the manager's hold items for; MCKPP_VIEW_KMAX)
   int solo_limit;     // workgroups leave their other slots empty for a straggler while the device holds at most this many
                       // (0: never - MCKPP_SOLO=0; default: workgroups / 32, at least 2; MCKPP_SOLO_LIMIT)
 };

@@ -138,7 +138,7 @@ __host__ __device__ inline int ps_scratch_ld(int nzp1) { return (nzp1 + 7) & ~7;
 __host__ inline size_t ps_lds_bytes(int L, int W, int xv)
 {
   return (size_t)(K_STRIDE * ps_nl(L) + 2 + W * ps_ss(L, xv, W) + W * C_COUNT) * sizeof(double) +
-         (size_t)(W * I_COUNT + 16) * sizeof(int);
+         (size_t)(W * I_COUNT + 32) * sizeof(int);
 }
 
 
@@ -1008,21 +1008,25 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // [0] some slot active, [1] some slot finishing, [2] the level the bulk-Ri scan of this pass ended at, [3] the level
   // down to which L3 forms the bulk Richardson numbers (a guess from the pass before), [4] the guess was too shallow,
   // [5] the scan stopped early, [6] some slot waits for its ticket, [7] the queue M0 draws from,
-  // [S_SOLO] the slot the workgroup works on ALONE (-1: none), [S_GOSOLO] the slot to go on alone with from this pass's
-  // L2 on (-1: none), [S_DRAIN] M0 does not refill for now (a straggler is being left alone, or the queue is used up)
-  enum { S_SOLO = 8, S_DRAIN = 9, S_GOSOLO = 10 };
+  // [S_KVIEW] the number of slots of the view the workgroup works in (0: every slot), [S_GOVIEW] the number of slots of
+  // the view to go on in from this pass's L2 on (0: no change), [S_DRAIN] M0 does not refill for now (stragglers are being
+  // left alone, or the queue is used up), [S_MAP ..] the slots of the view
+  enum { S_KVIEW = 8, S_DRAIN = 9, S_GOVIEW = 10, S_MAP = 16, S_MAPMAX = 16 };
   int *s_flags = sirec0 + W0 * I_COUNT;
   // ---- the VIEW a pass works in.  Normally every slot of the workgroup, the items of the first trip dealt from thread 0
   // on.  A column that iterates towards itermax (200 passes where the others take 6) bounds a long run by its own chain
-  // of passes, so a workgroup that holds one lets its other slots run empty (M0) and then goes on with that slot ALONE:
-  // the same code on a view of one slot (W = 1, the slot's rows and records as slot 0), its level items dealt to the
-  // waves other than the manager's - so that everything the full workgroup overlaps with the manager's serial phases
-  // (M1 | L2, the right-hand side of U under M3, the next L1 under the V sweep, the control under L6) overlaps for the
-  // lone column too, which with its items on the manager wave itself ran one after the other.  Same operations, same
-  // operands: a view changes who works on an item, never what is done to it.
-  int W = W0;
-  double *slots = slots0, *screc = screc0;
-  int *sirec = sirec0;
+  // of passes - and such columns come in bands of neighbours, which consecutive tickets hand to the slots of one
+  // workgroup.  So a workgroup that holds some lets its other slots run empty (M0) and then goes on in a view of the k
+  // slots that are left: their items - k L of them, one per thread - dealt to the waves other than the manager's, which
+  // has none.  Everything the full workgroup overlaps with the manager's serial phases (M1 | L2, the right-hand side of U
+  // under M3, the next L1 under the V sweep, the control under L6) then overlaps for these columns too - with their items
+  // on the manager wave itself, or spread over two trips among the items of empty slots, it ran one after the other.  The
+  // slots stay where they are (the manager's lanes pass over the empty ones as ever); a view is a map from item to
+  // (slot, level), and the iterate of the under-relaxation changes hands once, when the view is entered.  Same
+  // operations, same operands: a view changes who works on an item, never what is done to it.
+  const int W = W0;
+  double *const slots = slots0, *const screc = screc0;
+  int *const sirec = sirec0;
 
   for (int i = tid; i < NL; i += blockDim.x) {
     c_zm[i] = p.zm[i];
@@ -1034,7 +1038,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   }
   if (tid == 0) { c_misc[0] = rcp_refine(p.hm[1]); c_misc[1] = rcp_refine(p.vonk); }
   for (int i = tid; i < W0 * I_COUNT; i += blockDim.x) sirec0[i] = 0;   // every slot PS_EMPTY
-  if (tid < 16) s_flags[tid] = tid == 3 ? nz : (tid == S_SOLO || tid == S_GOSOLO) ? -1 : 0;
+  if (tid < 32) s_flags[tid] = tid == 3 ? nz : 0;
   // The manager is wave 0 (the item map below gives it items in the first trip only).  Measured and dropped:
   // electing the wave that sits on a given SIMD, so that the serial chains of all workgroups of a CU share one
   // SIMD (0.8-0.9x), or one SIMD per workgroup chosen from blockIdx (0.97x); raising its s_setprio (0.97x).
@@ -1058,21 +1062,29 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   const int nhelp = nthreads > 64 ? nthreads - 64 : 64, tid2 = nthreads > 64 ? tid - 64 : tid;
   int nitems_lm = W0 * nzp1;
   const unsigned Wmagic = W0 > 1 ? 0xFFFFFFFFu / (unsigned)W0 + 1u : 0u;   // it / W == umulhi(it, Wmagic) for it < 2^16 (a view of one slot: W == 1, not used)
-  // a view of one slot needs a wave for the manager and lanes for every item of a column beside it
-  const bool solo_ok = nthreads > 64 && nthreads - 64 >= L;
-  const bool solo_perm = W0 == 1 && solo_ok;   // a workgroup of one slot works in that view from the start (and refills it as ever)
-  const bool solo_dyn = p.mode == MCKPP_MODE_STEP && solo_ok && !solo_perm && p.solo_limit > 0;   // ... others may go into it
-  int it0 = tid;   // this thread's item of the first trip
-  auto set_view = [&](int s) {   // s < 0: every slot; else: slot s alone
-    const bool one = s >= 0;
-    const int so = one ? s : 0;
-    W = one ? 1 : W0;
-    slots = slots0 + so * SS; screc = screc0 + so * C_COUNT; sirec = sirec0 + so * I_COUNT;
-    nitems = W * L; nitems_lm = W * nzp1;
-    it0 = one ? (tid >= 64 ? tid - 64 : 0x3fffffff) : tid;
+  // a view needs a wave for the manager and a lane for every item of its columns beside it
+  const int kmax_view = nthreads > 64 ? min(min((nthreads - 64) / L, (int)S_MAPMAX), p.view_kmax > 0 ? p.view_kmax : (int)S_MAPMAX) : 0;
+  const bool solo_ok = kmax_view >= 1;
+  const bool solo_perm = W0 == 1 && solo_ok;   // a workgroup of one slot works in the view of that slot from the start (and refills it as ever)
+  const bool solo_dyn = p.mode == MCKPP_MODE_STEP && solo_ok && !solo_perm && p.solo_limit > 0;   // ... others may go into one
+  // this thread's item of the first trip: its index, and in a view its slot and level in slot-major (vs_) and in
+  // level-major order (lm_)
+  bool sparse = false;
+  int it0 = tid, vs_slot = 0, vs_k = 1, lm_slot = 0, lm_k = 1;
+  auto set_view = [&](int kv) {   // kv == 0: every slot; else the kv slots of s_flags[S_MAP ..]
+    sparse = kv > 0;
+    if (!sparse) { it0 = tid; nitems = W0 * L; nitems_lm = W0 * nzp1; return; }
+    nitems = kv * L; nitems_lm = kv * nzp1;
+    it0 = tid >= 64 ? tid - 64 : 0x3fffffff;
+    const int i0 = tid >= 64 ? tid - 64 : 0;
+    const int vs = (int)__umulhi((unsigned)i0, Lmagic);
+    vs_slot = s_flags[S_MAP + (vs < kv ? vs : 0)]; vs_k = i0 - vs * L + 1;
+    const int lk = i0 / kv;   // (once per view)
+    lm_slot = s_flags[S_MAP + (i0 - lk * kv)]; lm_k = lk + 1;
   };
-  if (solo_perm) { set_view(0); if (tid == 0) s_flags[S_SOLO] = 0; }
+  if (solo_perm && tid == 0) { s_flags[S_KVIEW] = 1; s_flags[S_MAP] = 0; }
   __syncthreads();
+  if (solo_perm) set_view(1);
 
   const double lambda = 0.5;
   const double epsln16 = 1.e-16, Ricr = 0.30, eps01 = 0.1, cekman = 0.7, cmonob = 1.0, epsln20 = 1.e-20;
@@ -1094,8 +1106,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 #define FOR_ITEMS                                                                         \
   PS_ITEMS_PRAGMA                                                                         \
   for (int it_ = it0, t_ = 0; it_ < nitems; it_ = tid2 >= 0 ? nthreads + t_ * nhelp + tid2 : nitems, ++t_) { \
-    const int slot = (int)__umulhi((unsigned)it_, Lmagic);                                \
-    const int k = it_ - slot * L + 1;                                                     \
+    const int slot = sparse ? vs_slot : (int)__umulhi((unsigned)it_, Lmagic);             \
+    const int k = sparse ? vs_k : it_ - slot * L + 1;                                     \
     int *const si = sirec + slot * I_COUNT;                                               \
     if (!si[I_ACT]) continue;                                                             \
     double *const my = slots + slot * SS;                                                 \
@@ -1118,8 +1130,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 #define FOR_ITEMS_BY_LEVEL                                                                \
   for (int j_ = it0, t_ = 0; j_ < nitems_lm; j_ = tid2 >= 0 ? nthreads + t_ * nhelp + tid2 : nitems_lm, ++t_) { \
     const int it_ = t_ == 0 ? j_ : nitems_lm - 1 - (j_ - nthreads);                       \
-    const int k = (W == 1 ? it_ : (int)__umulhi((unsigned)it_, Wmagic)) + 1;   /* the magic of W = 1 is 2^32 */ \
-    const int slot = it_ - (k - 1) * W;                                                   \
+    const int k = sparse ? lm_k : (W == 1 ? it_ : (int)__umulhi((unsigned)it_, Wmagic)) + 1;   /* the magic of W = 1 is 2^32 */ \
+    const int slot = sparse ? lm_slot : it_ - (k - 1) * W;                                \
     int *const si = sirec + slot * I_COUNT;                                               \
     if (!si[I_ACT]) continue;                                                             \
     double *const my = slots + slot * SS;                                                 \
@@ -1135,8 +1147,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 // phases that only have work down to some level - the waves that hold deeper levels fall through.
 #define FOR_ITEMS_RISING                                                                  \
   for (int it_ = it0, t_ = 0; it_ < nitems_lm; it_ = tid2 >= 0 ? nthreads + t_ * nhelp + tid2 : nitems_lm, ++t_) { \
-    const int k = (W == 1 ? it_ : (int)__umulhi((unsigned)it_, Wmagic)) + 1;              \
-    const int slot = it_ - (k - 1) * W;                                                   \
+    const int k = sparse ? lm_k : (W == 1 ? it_ : (int)__umulhi((unsigned)it_, Wmagic)) + 1; \
+    const int slot = sparse ? lm_slot : it_ - (k - 1) * W;                                \
     int *const si = sirec + slot * I_COUNT;                                               \
     if (!si[I_ACT]) continue;                                                             \
     double *const my = slots + slot * SS;                                                 \
@@ -1175,10 +1187,10 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     double *msc = screc + (lane < W ? lane : 0) * C_COUNT;
     int st = PS_DONE, c = 0, step = 0;
     bool want = false, ready = false, idle = false;
-    // the workgroup is in the view of one slot and that column goes on (a retry after the trap): nothing else starts here
-    // until it is done - a ticket held for another column waits that long (its column's later steps wait for it anyway)
-    const int ss = solo_perm ? -1 : s_flags[S_SOLO];
-    const bool solo_on = ss >= 0 && sirec[ss * I_COUNT + I_STATE] == PS_ACTIVE && sirec[ss * I_COUNT + I_FIN] != F_FINAL;
+    // the workgroup is in a view of a few slots and some of their columns go on: nothing else starts here until they are
+    // done - a ticket held for another column waits that long (its column's later steps wait for it anyway)
+    const int kv = solo_perm ? 0 : s_flags[S_KVIEW];
+    const bool solo_on = kv > 0 && __ballot(lane < W && sirec[lane * I_COUNT + I_STATE] == PS_ACTIVE && sirec[lane * I_COUNT + I_FIN] != F_FINAL) != 0ull;
     if (lane < W) {
       st = msi[I_STATE];
       if (st == PS_ACTIVE && msi[I_FIN] == F_FINAL) st = PS_EMPTY;   // its outputs are stored (barrier before M0)
@@ -1220,7 +1232,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       }
       drain = __ballot(is) != 0ull && glob <= p.solo_limit;
       if (solo_on) drain = true;
-      else if (ss >= 0 && lane == 0) s_flags[S_SOLO] = -1;   // that column is done: back to the view of every slot
+      else if (kv > 0 && lane == 0) s_flags[S_KVIEW] = 0;   // its columns are done: back to the view of every slot
       if (drain) refill = false;
     }
     if (lane < W) {
@@ -1334,6 +1346,10 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       // nothing will be refilled for now: stragglers are being left alone, or the queue has nothing more (G_late)
       const bool used_up = __ballot(lane < W && st == PS_DONE) != 0ull;
       if (lane == 0) s_flags[S_DRAIN] = (drain || used_up) ? 1 : 0;
+      // a column has just been started here (a ticket that was waited for, a refill): a view the control asked for in the
+      // pass before (G_early) no longer covers what the workgroup works on - it will ask again
+      const bool started = __ballot(want && st == PS_ACTIVE) != 0ull;   // (every lane votes: not inside the lane-0 branch)
+      if (lane == 0 && started) s_flags[S_GOVIEW] = 0;
     }
     if (lane == 0) { s_flags[0] = m != 0ull ? 1 : 0; s_flags[1] = 0; s_flags[6] = mw != 0ull ? 1 : 0; }
     if (multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the acquire's invalidate has completed before the barrier lets the other waves load
@@ -1531,19 +1547,22 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     }
     const unsigned long long m = __ballot(f_any);
     if (lane == 0) s_flags[1] = m != 0ull ? 1 : 0;
-    // One column left in a workgroup that does not refill for now, and that column on its way to itermax (or at itermax
-    // in its previous step): from the next pass on the workgroup works in a view of that slot alone (the iterate changes
-    // hands after that pass's L1, below).  (A slot that holds a ticket it waits to start keeps it until this column is
-    // done, M0: mostly it is this very column's next step.)  Decided here, in the manager's wait behind its L6 items.
-    if (solo_dyn && W == W0) {
-      const int f_solo = s_flags[S_SOLO], f_drain = s_flags[S_DRAIN];
-      if (f_solo < 0 && f_drain) {
-        const bool on = lane < W && sirec[lane * I_COUNT + I_STATE] == PS_ACTIVE && sirec[lane * I_COUNT + I_ACT];
-        const unsigned long long m_on = __ballot(on);
-        if (__popcll(m_on) == 1) {
-          const int s1 = __builtin_ctzll(m_on);
-          const int *msi = sirec + s1 * I_COUNT;
-          if (lane == 0 && msi[I_FIN] == F_NONE && (msi[I_STRAG] || msi[I_NPASS_TRY] > p.solo_after)) s_flags[S_GOSOLO] = s1;
+    // A few columns left in a workgroup that does not refill for now, every one of them on its way to itermax (or at
+    // itermax in its previous step): from the next pass on the workgroup works in a view of their slots (the iterate
+    // changes hands after that pass's L1, below).  (A slot that holds a ticket it waits to start keeps it until these
+    // columns are done, M0: mostly it is one of these very columns' next step.)  Decided here, in the manager's wait
+    // behind its L6 items.
+    if (solo_dyn && !sparse) {
+      const int f_kv = s_flags[S_KVIEW], f_drain = s_flags[S_DRAIN];
+      if (f_kv == 0 && f_drain) {
+        const int *msi = sirec + (lane < W ? lane : 0) * I_COUNT;
+        const bool on = lane < W && msi[I_STATE] == PS_ACTIVE && msi[I_ACT];
+        const bool ok = on && msi[I_FIN] == F_NONE && (msi[I_STRAG] || msi[I_NPASS_TRY] > p.solo_after);
+        const unsigned long long m_on = __ballot(on), m_ok = __ballot(ok);
+        const int kn = __popcll(m_on);
+        if (kn >= 1 && kn <= kmax_view && m_ok == m_on) {
+          if (on) s_flags[S_MAP + __popcll(m_on & ((1ull << lane) - 1ull))] = lane;
+          if (lane == 0) s_flags[S_GOVIEW] = kn;
         }
       }
     }
@@ -1875,8 +1894,8 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     if (!any_active && !any_waiting) break;
     int finishing = 0;
     // the view of this iteration (M0 and G_late change it between iterations only), and whether this pass ends in another
-    const int gosolo = solo_perm ? -1 : __builtin_amdgcn_readfirstlane(s_flags[S_GOSOLO]);
-    if (!solo_perm) set_view(__builtin_amdgcn_readfirstlane(s_flags[S_SOLO]));
+    const int goview = solo_perm ? 0 : __builtin_amdgcn_readfirstlane(s_flags[S_GOVIEW]);
+    if (!solo_perm && sparse && __builtin_amdgcn_readfirstlane(s_flags[S_KVIEW]) == 0) set_view(0);   // (M0: its columns are done)
     if (any_active) {
     STAMP(22);
 #ifdef MCKPP_PS_STAMPS
@@ -1892,24 +1911,22 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     STAMP(0);
     __syncthreads();
     STAMP(1);
-    if (gosolo >= 0) {
-      // From here on the workgroup works on slot `gosolo` alone (G_late of the pass before).  The slot's rows and records
-      // stay where they are; what changes hands is the iterate of the under-relaxation, which lives in the registers of
-      // the threads that own the slot's items: through the rows of a neighbour slot (empty: this is the only active one).
-      double *const stage = slots0 + (gosolo + 1 == W0 ? 0 : gosolo + 1) * SS;
-      FOR_ITEMS
-        if (slot != gosolo || !act) continue;
-        stage[4 * k + 0] = first_ == 0 ? rU : first_ == 1 ? r2U : xs_[0];
-        stage[4 * k + 1] = first_ == 0 ? rV : first_ == 1 ? r2V : xs_[LS];
-        stage[4 * k + 2] = first_ == 0 ? rT : first_ == 1 ? r2T : xs_[2 * LS];
-        stage[4 * k + 3] = first_ == 0 ? rS : first_ == 1 ? r2S : xs_[3 * LS];
-      END_ITEMS
-      __syncthreads();
-      if (tid == 0) { s_flags[S_SOLO] = gosolo; s_flags[S_GOSOLO] = -1; }
-      set_view(gosolo);
+    if (goview > 0) {
+      // From here on the workgroup works in a view of the `goview` slots of s_flags[S_MAP ..] (G_early of the pass
+      // before).  Their rows and records stay where they are; what changes hands is the iterate of the under-relaxation,
+      // which lives in the registers of the threads that own the slots' items: through the scratch rows of the iterate in
+      // global memory (a block per (workgroup, slot): where the items of a third trip keep theirs).
       FOR_ITEMS
         if (!act) continue;
-        rU = stage[4 * k + 0]; rV = stage[4 * k + 1]; rT = stage[4 * k + 2]; rS = stage[4 * k + 3];
+        if (first_ == 0) { xs_[0] = rU; xs_[LS] = rV; xs_[2 * LS] = rT; xs_[3 * LS] = rS; }
+        else if (first_ == 1) { xs_[0] = r2U; xs_[LS] = r2V; xs_[2 * LS] = r2T; xs_[3 * LS] = r2S; }
+      END_ITEMS
+      __syncthreads();
+      if (tid == 0) { s_flags[S_KVIEW] = goview; s_flags[S_GOVIEW] = 0; }
+      set_view(goview);
+      FOR_ITEMS
+        if (!act) continue;
+        rU = xs_[0]; rV = xs_[LS]; rT = xs_[2 * LS]; rS = xs_[3 * LS];
       END_ITEMS
     }
 
@@ -1933,7 +1950,11 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     // the deepest level).  MCKPP_L3_CAP caps the guess (tests).
     const int kguess = (DD || p.mode != MCKPP_MODE_STEP) ? nz : (p.l3cap > 0 && p.l3cap < s_flags[3] ? p.l3cap : s_flags[3]);
     if (wv == mgr) M1();
-    if (kguess < nz) {
+    if (kguess < nz && sparse) {   // a view of a few slots: one level-major item per thread, none on the manager wave
+      FOR_ITEMS_RISING
+        L2_item(k, si, my, sc, (size_t)si[I_COL] * p.ld, actz, is1, isnz, k == nzp1, k <= kguess);
+      END_ITEMS
+    } else if (kguess < nz) {
       // level-major order, rising: the waves that hold levels below the guess have the cheap part only
       // (all items to the waves other than the manager's, which has M1 to do - but for a last trip of a few items:
       // 915 items on 448 threads are two trips and nineteen items, which one wave would go a third time for while
@@ -2668,7 +2689,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     END_ITEMS
     }   // finish round
     }   // pass of the active slots
-    if (!finishing && !(any_waiting && (solo_perm || W == W0))) continue;   // (a workgroup in the view of one slot asks for its waiting tickets when that column is done)
+    if (!finishing && !(any_waiting && (solo_perm || !sparse))) continue;   // (a workgroup in a view of a few slots asks for its waiting tickets when their columns are done)
     // (every read of the finished slots' records and of the flags M0 rewrites is done: hand the slots to the queue;
     // every wave's stores of the finishing steps have left it - M0 publishes those steps)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2677,7 +2698,6 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     if (wv == mgr) {
       // nothing to work on but a ticket whose column another workgroup still has in its previous step: ask again in a while
       if (!any_active && !first_iteration) __builtin_amdgcn_s_sleep(64);
-      if (!solo_perm) set_view(-1);   // M0 looks at every slot
       M0();
     }
     __syncthreads();

@@ -114,6 +114,7 @@ struct mckpp_hip_ctx {
   double *d_cs = nullptr;
   int *d_ci = nullptr;
   int *d_qhead = nullptr;  // QBLOCK_INTS ints, zeroed before every launch: [0..15] queue heads, [16..31] queue owners, [32] stragglers on the device
+  int view_kmax = 0;   // mckpp_kparams_t::view_kmax (MCKPP_VIEW_KMAX)
   int solo_after = 12, solo_limit = 8;   // mckpp_kparams_t::solo_after / solo_limit (MCKPP_SOLO=0, MCKPP_SOLO_AFTER, MCKPP_SOLO_LIMIT)
   int *d_done = nullptr;   // [ncol] steps of a multi-step launch each column has completed (mckpp_kparams_t::done)
   bool multistep = true;   // mckpp_hip_step(nt, n > 1) as one launch (MCKPP_MULTISTEP=0: a launch per step)
@@ -283,6 +284,7 @@ int mckpp_hip_init(const mckpp_const_c *c, int device, mckpp_hip_handle *out)
   if (const char *e = getenv("MCKPP_SOLO")) { if (atoi(e) == 0) h->solo_limit = 0; }
   if (const char *e = getenv("MCKPP_SOLO_LIMIT")) h->solo_limit = std::max(0, atoi(e));
   if (const char *e = getenv("MCKPP_SOLO_AFTER")) h->solo_after = std::max(0, atoi(e));
+  if (const char *e = getenv("MCKPP_VIEW_KMAX")) h->view_kmax = std::max(0, atoi(e));
   {   // the device's XCDs (a column of a multi-step launch stays on one: mckpp_kernels_ps.hip, M0)
     HIPCHK(hipMemsetAsync(h->d_qhead, 0, sizeof(int), h->stream));
     HIPCHK(mckpp_launch_xcc_probe(reinterpret_cast<unsigned *>(h->d_qhead), h->stream));
@@ -853,7 +855,7 @@ static void fill_params(mckpp_hip_ctx *h, mckpp_kparams &p, int ntime, int mode)
   p.U_init = h->d_prof[P_UINIT]; p.V_init = h->d_prof[P_VINIT];
   p.cs = h->d_cs; p.ci = h->d_ci; p.qhead = h->d_qhead; p.dbg = h->d_dbg;
   p.nsteps_launch = 1; p.done = h->d_done; p.nqueues = h->nqueues; p.qowner = h->d_qhead + 16;
-  p.sync = h->d_qhead + 32; p.solo_after = h->solo_after; p.solo_limit = h->solo_limit;
+  p.sync = h->d_qhead + 32; p.solo_after = h->solo_after; p.solo_limit = h->solo_limit; p.view_kmax = h->view_kmax;
   for (int i = 0; i < 16; ++i) p.xcc_queue[i] = h->xcc_queue[i];
   p.ext = h->ext_kernel ? 1 : 0;
   p.L_RELAX_SST = h->c.L_RELAX_SST; p.L_RELAX_CALCONLY = h->c.L_RELAX_CALCONLY; p.L_FCORR = h->c.L_FCORR;

@@ -730,6 +730,45 @@ def test_columns_left_alone_in_their_workgroup(mk, monkeypatch, ncol, nz, solver
     assert seen_long > 0 or ncol == 1 or nz not in (60, 100), "no column went past its 12th pass in step 2"
 
 
+@pytest.mark.parametrize("env", [{}, {"MCKPP_VIEW_KMAX": "1"}, {"MCKPP_SOLO_AFTER": "1000000"}, {"MCKPP_SOLO_LIMIT": "1000000"},
+                                 {"MCKPP_SOLO_LIMIT": "1000000", "MCKPP_SOLO_AFTER": "0"}])
+def test_views_in_a_launch_of_several_steps(mk, monkeypatch, env):
+    """The end of a launch of several steps is made of chains: the next step's ticket of a column that is at itermax in
+    step 2 (14 % of them from the analytic start) waits in some workgroup that has little else left, and that
+    workgroup goes on in a view of the few slots it still works on - while tickets it holds for OTHER
+    columns become ready and are started between the control's decision for a view and the pass that enters it (M0 then
+    withdraws the decision: a vote of every lane, found missing in round 5 when three steps of 9000 columns came out
+    different in 50-120 columns of such bands).  Three steps in one launch under the view's switches - as shipped, views
+    of one slot only, only columns known from their previous step, every workgroup leaving slots empty, every column
+    from its first pass - against a launch per step without views, bit for bit, twice."""
+    ncol, nz, nsteps = 9000, 60, 3
+
+    def run(multi, envs):
+        for k in ("MCKPP_VIEW_KMAX", "MCKPP_SOLO_AFTER", "MCKPP_SOLO_LIMIT", "MCKPP_SOLO"):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("MCKPP_MULTISTEP", multi)
+        for k, v in envs.items():
+            monkeypatch.setenv(k, v)
+        kc, k3 = cm.make_hip_case(ncol, nz)
+        ctx = mk.MckppHip(kc)
+        ctx.upload(k3)
+        ctx.init_ocean(0)
+        cm.set_forcing_3d(k3, cm.synth.forcing(ncol, "bench"))
+        ctx.set_forcing(k3.sflux)
+        ctx.step(1, nsteps)
+        ctx.download(k3)
+        st, nf, npass = ctx.status()
+        ctx.close()
+        return k3, st.copy(), npass.copy()
+
+    ref = run("0", {"MCKPP_SOLO": "0"})
+    for _ in range(2):
+        got = run("1", env)
+        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+        for name in ("U", "X", "Us", "Xs", "hmixd", "hmix", "kmix", "Tref", "uref", "vref", "Ssurf", "difm", "dift", "ghat", "wU", "wX", "Rig"):
+            assert np.array_equal(np.asarray(getattr(got[0], name)), np.asarray(getattr(ref[0], name)), equal_nan=True), (name, env)
+
+
 @pytest.mark.parametrize("drop", ["0x55", "0xfe"])
 def test_queues_without_workgroups_of_their_own_are_adopted(mk, monkeypatch, drop):
     """A launch of several steps keeps a column on one XCD (a queue per XCD, the workgroups of an XCD draw from its own:
