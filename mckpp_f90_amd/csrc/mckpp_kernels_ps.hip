@@ -1058,29 +1058,35 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   // Item `it` of the first trip belongs to thread `it`; the later trips are dealt to the waves other than the
   // manager's only (it has its serial phases to run): item nthreads + t*(nthreads-64) + (tid-64) in trip t+1.
   const int nthreads = blockDim.x;
-  int nitems = W0 * L;
+  const int nitems = W0 * L;
   const int nhelp = nthreads > 64 ? nthreads - 64 : 64, tid2 = nthreads > 64 ? tid - 64 : tid;
-  int nitems_lm = W0 * nzp1;
+  const int nitems_lm = W0 * nzp1;
   const unsigned Wmagic = W0 > 1 ? 0xFFFFFFFFu / (unsigned)W0 + 1u : 0u;   // it / W == umulhi(it, Wmagic) for it < 2^16 (a view of one slot: W == 1, not used)
   // a view needs a wave for the manager and a lane for every item of its columns beside it
   const int kmax_view = nthreads > 64 ? min(min((nthreads - 64) / L, (int)S_MAPMAX), p.view_kmax > 0 ? p.view_kmax : (int)S_MAPMAX) : 0;
   const bool solo_ok = kmax_view >= 1;
   const bool solo_perm = W0 == 1 && solo_ok;   // a workgroup of one slot works in the view of that slot from the start (and refills it as ever)
   const bool solo_dyn = p.mode == MCKPP_MODE_STEP && solo_ok && !solo_perm && p.solo_limit > 0;   // ... others may go into one
-  // this thread's item of the first trip: its index, and in a view its slot and level in slot-major (vs_) and in
-  // level-major order (lm_)
+  // This thread's item of the first trip, in slot-major (it0) and in level-major order (it0_lm): its own number in the
+  // view of every slot; in a view of a few slots the index that the item loops' own arithmetic turns into the mapped slot
+  // and the level - slot L + level - 1 and (level - 1) W + slot - so that the loops are the same code in either view.
+  // trip_base: where the items of the later trips start (a view has one trip: past every item).
   bool sparse = false;
-  int it0 = tid, vs_slot = 0, vs_k = 1, lm_slot = 0, lm_k = 1;
+  int it0 = tid, it0_lm = tid, trip_base = nthreads;
   auto set_view = [&](int kv) {   // kv == 0: every slot; else the kv slots of s_flags[S_MAP ..]
     sparse = kv > 0;
-    if (!sparse) { it0 = tid; nitems = W0 * L; nitems_lm = W0 * nzp1; return; }
-    nitems = kv * L; nitems_lm = kv * nzp1;
-    it0 = tid >= 64 ? tid - 64 : 0x3fffffff;
-    const int i0 = tid >= 64 ? tid - 64 : 0;
-    const int vs = (int)__umulhi((unsigned)i0, Lmagic);
-    vs_slot = s_flags[S_MAP + (vs < kv ? vs : 0)]; vs_k = i0 - vs * L + 1;
-    const int lk = i0 / kv;   // (once per view)
-    lm_slot = s_flags[S_MAP + (i0 - lk * kv)]; lm_k = lk + 1;
+    if (!sparse) { it0 = tid; it0_lm = tid; trip_base = nthreads; return; }
+    trip_base = 0x20000000;
+    const int i0 = tid - 64;
+    it0 = 0x3fffffff; it0_lm = 0x3fffffff;
+    if (i0 >= 0 && i0 < kv * L) {
+      const int vs = (int)__umulhi((unsigned)i0, Lmagic);
+      it0 = s_flags[S_MAP + vs] * L + (i0 - vs * L);
+    }
+    if (i0 >= 0 && i0 < kv * nzp1) {
+      const int lk = i0 / kv;   // (once per view)
+      it0_lm = lk * W0 + s_flags[S_MAP + (i0 - lk * kv)];
+    }
   };
   if (solo_perm && tid == 0) { s_flags[S_KVIEW] = 1; s_flags[S_MAP] = 0; }
   __syncthreads();
@@ -1105,9 +1111,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 #define PS_ITEMS_PRAGMA _Pragma("clang loop unroll(disable)")
 #define FOR_ITEMS                                                                         \
   PS_ITEMS_PRAGMA                                                                         \
-  for (int it_ = it0, t_ = 0; it_ < nitems; it_ = tid2 >= 0 ? nthreads + t_ * nhelp + tid2 : nitems, ++t_) { \
-    const int slot = sparse ? vs_slot : (int)__umulhi((unsigned)it_, Lmagic);             \
-    const int k = sparse ? vs_k : it_ - slot * L + 1;                                     \
+  for (int it_ = it0, t_ = 0; it_ < nitems; it_ = tid2 >= 0 ? trip_base + t_ * nhelp + tid2 : nitems, ++t_) { \
+    const int slot = (int)__umulhi((unsigned)it_, Lmagic);                                \
+    const int k = it_ - slot * L + 1;                                                     \
     int *const si = sirec + slot * I_COUNT;                                               \
     if (!si[I_ACT]) continue;                                                             \
     double *const my = slots + slot * SS;                                                 \
@@ -1128,10 +1134,10 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 // - its lanes loop equally long - and a thread's first item comes from the top of the columns, its later ones
 // from the bottom, so every thread gets a deep and a shallow item.
 #define FOR_ITEMS_BY_LEVEL                                                                \
-  for (int j_ = it0, t_ = 0; j_ < nitems_lm; j_ = tid2 >= 0 ? nthreads + t_ * nhelp + tid2 : nitems_lm, ++t_) { \
+  for (int j_ = it0_lm, t_ = 0; j_ < nitems_lm; j_ = tid2 >= 0 ? trip_base + t_ * nhelp + tid2 : nitems_lm, ++t_) { \
     const int it_ = t_ == 0 ? j_ : nitems_lm - 1 - (j_ - nthreads);                       \
-    const int k = sparse ? lm_k : (W == 1 ? it_ : (int)__umulhi((unsigned)it_, Wmagic)) + 1;   /* the magic of W = 1 is 2^32 */ \
-    const int slot = sparse ? lm_slot : it_ - (k - 1) * W;                                \
+    const int k = (W == 1 ? it_ : (int)__umulhi((unsigned)it_, Wmagic)) + 1;   /* the magic of W = 1 is 2^32 */ \
+    const int slot = it_ - (k - 1) * W;                                                   \
     int *const si = sirec + slot * I_COUNT;                                               \
     if (!si[I_ACT]) continue;                                                             \
     double *const my = slots + slot * SS;                                                 \
@@ -1146,9 +1152,9 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
 // Level-major order again, plainly rising (item = (level-1)*W + slot, a thread's later items are deeper): for the
 // phases that only have work down to some level - the waves that hold deeper levels fall through.
 #define FOR_ITEMS_RISING                                                                  \
-  for (int it_ = it0, t_ = 0; it_ < nitems_lm; it_ = tid2 >= 0 ? nthreads + t_ * nhelp + tid2 : nitems_lm, ++t_) { \
-    const int k = sparse ? lm_k : (W == 1 ? it_ : (int)__umulhi((unsigned)it_, Wmagic)) + 1; \
-    const int slot = sparse ? lm_slot : it_ - (k - 1) * W;                                \
+  for (int it_ = it0_lm, t_ = 0; it_ < nitems_lm; it_ = tid2 >= 0 ? trip_base + t_ * nhelp + tid2 : nitems_lm, ++t_) { \
+    const int k = (W == 1 ? it_ : (int)__umulhi((unsigned)it_, Wmagic)) + 1;              \
+    const int slot = it_ - (k - 1) * W;                                                   \
     int *const si = sirec + slot * I_COUNT;                                               \
     if (!si[I_ACT]) continue;                                                             \
     double *const my = slots + slot * SS;                                                 \
