@@ -44,6 +44,8 @@ program kpp_driver
   !        32 the same step by step with an output window: mean hmix and maximum T of the run (appended)
   !        64 opt into the reduced per-step download (scalar group only) + mckpp_hip_sync_host before the output;
   !           without it every call of mckpp_physics_driver leaves all of kpp_3d_fields current, as the reference does
+  !        128 itermax = 4 (columns run beyond itermax+1 passes: the reference's located warnings on stderr) with
+  !           dlon = 0.5 ipt, dlat = -60 + 0.25 ipt
   flags = hdr(6)
   if (iand(flags, 64) /= 0) mckpp_hip_output_mask = MCKPP_F_SCALARS
   ! hdr(7) > 0: that many device shards; hdr(8) = 1 puts them all on HIP device 0 (one-GPU rehearsal of the
@@ -56,6 +58,7 @@ program kpp_driver
     end if
   end if
   call mckpp_set_dimensions(ncol, 1, nlev, hdr(5))
+  if (iand(flags, 128) /= 0) itermax = 4
   call mckpp_allocate_const_fields()
   call mckpp_allocate_3d_fields()
   read (u) kpp_const_fields%dto
@@ -70,6 +73,10 @@ program kpp_driver
   kpp_3d_fields%run_physics = mask > 0.5_c_double
   kpp_3d_fields%l_ocean = kpp_3d_fields%run_physics
   kpp_3d_fields%U_init = kpp_3d_fields%U
+  if (iand(flags, 128) /= 0) then
+    kpp_3d_fields%dlon = [(0.5_c_double * ipt, ipt = 1, ncol)]
+    kpp_3d_fields%dlat = [(-60 + 0.25_c_double * ipt, ipt = 1, ncol)]
+  end if
   if (iand(flags, 2) /= 0) then
     call mckpp_allocate_3d_optional()
     kpp_const_fields%L_VARY_BOTTOM_TEMP = .true.
@@ -177,6 +184,7 @@ contains
     c%hmix = kpp_3d_fields%hmix(i); c%kmix = kpp_3d_fields%kmix(i)
     c%old = kpp_3d_fields%old(i); c%new = kpp_3d_fields%new(i); c%jerlov = kpp_3d_fields%jerlov(i)
     c%l_ocean = kpp_3d_fields%l_ocean(i); c%l_initflag = kpp_3d_fields%l_initflag(i); c%point = i
+    c%dlat = kpp_3d_fields%dlat(i); c%dlon = kpp_3d_fields%dlon(i)   ! src/mckpp_types_transfer.F90 (what the warnings name)
   end subroutine gather_1d
 
   subroutine scatter_1d(i, c)

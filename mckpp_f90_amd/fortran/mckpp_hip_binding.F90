@@ -5,6 +5,9 @@ module mckpp_hip_binding
   use iso_c_binding
   implicit none
 
+  ! per-column status bits (include/mckpp_hip.h, MCKPP_ST_*)
+  integer(c_int32_t), parameter :: MCKPP_ST_ZERO_PIVOT = 1, MCKPP_ST_LONG_ITER = 2, MCKPP_ST_RETRIED = 4, MCKPP_ST_FAILED = 8, &
+                                   MCKPP_ST_DODGY_OLDNEW = 16
   integer(c_int), parameter :: MCKPP_F_PROFILES = 1, MCKPP_F_SAVED = 2, MCKPP_F_SCALARS = 4, MCKPP_F_DIAG = 8
   integer(c_int), parameter :: MCKPP_F_RESTART = 7, MCKPP_F_ALL = 15
   ! MCKPP_OUT_* (XIOS field ids, src/mckpp_xios_io.F90:74-210) and the window operations
@@ -357,6 +360,14 @@ module mckpp_hip_binding
     function mckpp_hip_status(handle, per_col, n_flagged, npasses) bind(C, name="mckpp_hip_status") result(rc)
       import :: c_int, c_ptr
       type(c_ptr), value :: handle, per_col, n_flagged, npasses
+      integer(c_int) :: rc
+    end function
+    !> status words and pass counts of the last step for all npts points of all devices (land: 0)
+    function mckpp_hip_multi_status(m, per_col, n_flagged, npasses) bind(C, name="mckpp_hip_multi_status") result(rc)
+      import :: c_int, c_ptr, c_int32_t, c_int64_t
+      type(c_ptr), value :: m
+      integer(c_int32_t), intent(out) :: per_col(*), npasses(*)
+      integer(c_int64_t), intent(out) :: n_flagged
       integer(c_int) :: rc
     end function
     function mckpp_hip_last_kernel_ms(handle, ms, nlaunch) bind(C, name="mckpp_hip_last_kernel_ms") result(rc)

@@ -19,6 +19,7 @@ module mckpp_hip_session
   public :: mckpp_hip_all_window_reset, mckpp_hip_all_window_accumulate, mckpp_hip_all_window_fetch
   public :: mckpp_hip_all_save_restart, mckpp_hip_all_load_restart, mckpp_hip_sync_host, mckpp_hip_device_advanced
   public :: mckpp_hip_host_behind
+  public :: mckpp_hip_warnings, mckpp_hip_abort_on_zero_pivot, mckpp_hip_report_warnings, mckpp_hip_column_messages
 
   !> All devices of the run behind one handle (include/mckpp_hip.h, mckpp_hip_multi_*): the columns of
   !! kpp_3d_fields are dealt round-robin over mckpp_hip_ndevices GPUs, HIP devices mckpp_hip_device,
@@ -51,6 +52,17 @@ module mckpp_hip_session
   !! reads them, so the device can never run on stale ancillaries; set it .false. and call
   !! mckpp_hip_push_ancillaries at the ndtupd* cadences to save the per-step upload.
   logical, save :: mckpp_hip_ancillaries_every_step = .true.
+  !> The reference's located messages.  Its column loop writes a warning to stderr, with the column's longitude,
+  !! latitude and point number, when a column iterates beyond itermax+1 passes or exhausts the ten retries of the
+  !! instability trap (src/mckpp_physics_ocnstep_mod.F90:184-191, 229-236), and stops the run on a zero pivot of the
+  !! tridiagonal solve (src/mckpp_physics_solvers.F90:140-148).  The device reports all of these as per-column status
+  !! bits (include/mckpp_hip.h, MCKPP_ST_*); after every mckpp_physics_driver call the status words (8 bytes per
+  !! column) come back and mckpp_hip_report_warnings writes the reference's messages for the flagged columns.
+  !! .false.: the host reads mckpp_hip_multi_status itself when it wants to.
+  logical, save :: mckpp_hip_warnings = .true.
+  !> .true. (the reference: CALL MCKPP_ABORT in tridmat): a zero pivot anywhere stops the run after the messages.
+  !! .false.: the step's result stands - the pivot replaced by 1.E-12, the statement behind the reference's abort.
+  logical, save :: mckpp_hip_abort_on_zero_pivot = .true.
 
 contains
 
@@ -204,6 +216,74 @@ contains
   integer(c_int) function mckpp_hip_host_behind()
     mckpp_hip_host_behind = host_behind
   end function mckpp_hip_host_behind
+
+  !> The reference's warnings for the columns the last step flagged (all devices), in point order.  `nt`: the time
+  !! step the messages name (ntime).
+  subroutine mckpp_hip_report_warnings(nt)
+    integer, intent(in) :: nt
+    integer(c_int32_t), allocatable :: st(:), np(:)
+    integer(c_int64_t) :: nflag
+    integer :: ipt
+    logical :: zero_pivot, have_scalars
+    if (.not. resident) return
+    allocate (st(npts), np(npts))
+    call mckpp_hip_check(mckpp_hip_multi_status(mckpp_hip_multi_handle, st, nflag, np), 'mckpp_hip_multi_status')
+    if (nflag == 0) return
+    have_scalars = iand(host_behind, MCKPP_F_SCALARS) == 0
+    zero_pivot = .false.
+    do ipt = 1, npts
+      if (st(ipt) == 0) cycle
+      call mckpp_hip_column_messages(st(ipt), np(ipt), nt, kpp_3d_fields%dlat(ipt), kpp_3d_fields%dlon(ipt), ipt, &
+                                     have_scalars, kpp_3d_fields%hmix(ipt), kpp_3d_fields%kmix(ipt), zero_pivot)
+    end do
+    if (zero_pivot .and. mckpp_hip_abort_on_zero_pivot) error stop 1   ! MCKPP_ABORT (src/mckpp_abort_mod.F90:7-16: STOP)
+  end subroutine mckpp_hip_report_warnings
+
+  !> One column's messages from its status word.  The values the reference prints beside the location that exist
+  !! only inside its iteration (hmixest, the last difference) are not kept per column: the new hmix, kmix and the number
+  !! of passes are printed instead (hmix and kmix when the caller's copies are current).
+  subroutine mckpp_hip_column_messages(st, np, nt, dlat, dlon, ipt, have_scalars, hmix, kmix, zero_pivot)
+    integer(c_int32_t), intent(in) :: st, np
+    integer, intent(in) :: nt, ipt
+    real(c_double), intent(in) :: dlat, dlon, hmix, kmix
+    logical, intent(in) :: have_scalars
+    logical, intent(inout) :: zero_pivot
+    character(len=200) :: message
+    character(len=*), parameter :: ocnstep = 'MCKPP_PHYSICS_OCNSTEP', tridmat = 'MCKPP_PHYSICS_SOLVERS_TRIDMAT'
+    if (iand(st, MCKPP_ST_DODGY_OLDNEW) /= 0) then   ! ocnstep_mod.F90:93-102
+      write (message, *) 'Dodgy value of old or new at ipt = ', ipt
+      call warn(ocnstep, message)
+    end if
+    if (iand(st, MCKPP_ST_LONG_ITER) /= 0) then   ! :184-191
+      write (message, *) 'long iteration at timestep', nt, ' location = (', dlon, ',', dlat, ')'
+      call warn(ocnstep, message)
+      if (have_scalars) then
+        write (message, *) 'hmixnew=', hmix, ', kmixn = ', int(kmix), ', passes = ', np, ', ipt = ', ipt
+      else
+        write (message, *) 'passes = ', np, ', ipt = ', ipt
+      end if
+      call warn(ocnstep, message)
+    end if
+    if (iand(st, MCKPP_ST_FAILED) /= 0) then   ! :229-236
+      write (message, *) 'Failed to find a reasonable solution in the semi-implicit integration after ', 10, ' iterations.'
+      call warn(ocnstep, message)
+      write (message, *) 'At point lat = ', dlat, ' lon =', dlon, ' ipt = ', ipt, ':'
+      call warn(ocnstep, message)
+    end if
+    if (iand(st, MCKPP_ST_ZERO_PIVOT) /= 0) then   ! solvers.F90:140-148 (mckpp_print_error)
+      zero_pivot = .true.
+      write (0, *) 'Error in '//tridmat//':'
+      write (0, *) 'Algorithm for solving tridiag matrix failed.'
+      write (message, *) 'bet = 0 at timestep', nt, ' lat = ', dlat, ' lon =', dlon, ' ipt = ', ipt
+      write (0, *) trim(adjustl(message))
+    end if
+  contains
+    subroutine warn(routine, msg)   ! mckpp_print_warning, src/mckpp_log_messages.F90:52-63
+      character(len=*), intent(in) :: routine, msg
+      write (0, *) 'Warning in '//routine//':'
+      write (0, *) trim(adjustl(msg))
+    end subroutine warn
+  end subroutine mckpp_hip_column_messages
 
   !> Output gather without a full download: field 0 U, 1 V, 2 T, 3 S -> out(npts,nzp1), 4 hmix -> out(npts);
   !! the shards' rows travel over the GPU interconnect to device `root` (0-based shard index) and cross

@@ -32,6 +32,8 @@ contains
     end if
     call mckpp_hip_device_advanced()
     call mckpp_hip_pull_state(mckpp_hip_output_mask)
+    ! the reference's located warnings (src/mckpp_physics_ocnstep_mod.F90:184-191, 229-236; solvers.F90:140-148)
+    if (mckpp_hip_warnings) call mckpp_hip_report_warnings(int(ntime))
   end subroutine mckpp_physics_driver
 
   subroutine mckpp_physics_finalize()

@@ -2,6 +2,11 @@ import os
 import sys
 
 import pytest
+# torch before anything loads libmckpp_hip.so: torch brings its own HIP runtime, the library links the image's; whichever
+# is loaded first serves both, and torch does not see the device through the other one (a run of a subset of the test
+# files - without tests/test_dist_cpu.py, which imports torch at collection - otherwise fails in the first fixture that
+# asks torch.cuda.is_available() after a test has used the library)
+import torch  # noqa: F401
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):

@@ -89,6 +89,50 @@ def test_fortran_driver_matches_cabi_path(built, tmp_path, ncol, nz, nsteps, use
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("use_1d", [0, 1])
+def test_fortran_layer_writes_the_located_warnings(built, tmp_path, use_1d):
+    """The reference names the column - longitude, latitude - in a warning on stderr when it iterates beyond
+    itermax+1 passes (src/mckpp_physics_ocnstep_mod.F90:184-191; mckpp_print_warning,
+    src/mckpp_log_messages.F90:52-63).  With itermax = 4 (driver flag 128) the steps from the analytic start flag
+    columns (tests/test_parity_gpu.py::test_long_iteration_status_on_device): the Fortran layer must write one
+    warning per flagged column and step, with that column's location, through mckpp_physics_driver and through the
+    one-column mckpp_physics_ocnstep alike; the results stay those of the C-ABI path."""
+    import re
+
+    import mckpp_f90_amd as mk
+
+    ncol, nz, nsteps = (120, 40, 3) if not use_1d else (24, 40, 3)
+    kc, k3 = cm.make_hip_case(ncol, nz)
+    sf = cm.synth.forcing(ncol, "bench")
+    _write_case(tmp_path / "case.bin", kc, k3, sf, nsteps, use_1d, flags=128)
+    r = subprocess.run([DRIVER, str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = _read_out(tmp_path / "out.bin", kc, ncol)
+    kc.itermax = 4
+    ctx = mk.mckpp_initialize_ocean_model(k3, kc)
+    cm.set_forcing_3d(k3, sf)
+    want = []   # (step, point) of every flagged column
+    for nt in range(1, nsteps + 1):
+        mk.mckpp_physics_driver(k3, kc, nt)
+        st, nf, npass = ctx.status()
+        want += [(nt, int(i) + 1) for i in np.nonzero(st & 2)[0]]
+    assert want, "no column ran beyond itermax+1 passes"
+    for n in ("U", "X", "hmix", "kmix", "Tref"):
+        assert np.array_equal(got[n], getattr(k3, n)), n
+    lines = [ln.strip() for ln in r.stderr.splitlines()]
+    seen = []
+    for i, ln in enumerate(lines):
+        m = re.match(r"long iteration at timestep\s+(\d+)\s+location = \(\s*([-0-9.Ee+]+)\s*,\s*([-0-9.Ee+]+)\s*\)", ln)
+        if m:
+            assert lines[i - 1] == "Warning in MCKPP_PHYSICS_OCNSTEP:"
+            ipt = round(float(m.group(2)) / 0.5)
+            assert abs(float(m.group(3)) - (-60 + 0.25 * ipt)) < 1e-9
+            assert re.search(r"passes =\s+\d+", lines[i + 2]) and re.search(rf"ipt =\s+{ipt}$", lines[i + 2])
+            seen.append((int(m.group(1)), ipt))
+    assert seen == want
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("flags", [1, 2, 3])
 def test_fortran_fluxes_and_bottomtemp_wrappers(built, tmp_path, flags):
     """mckpp_fluxes (constant forcing, L_FLUXDATA=.F., src/mckpp_fluxes_mod.F90:41-49) every step and
