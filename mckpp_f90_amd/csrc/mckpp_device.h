@@ -72,7 +72,8 @@ struct mckpp_kparams_t {
   int series_rec0, ndtocn, l_rest;
   double flsn, el;
   P<int> qowner;  // [16] per queue: 0 free, else hardware XCC id + 1 of the XCD whose workgroups serve it (zeroed per launch)
-  P<int> done;    // [ncol] steps of this launch a column has completed (zeroed per launch; nsteps_launch > 1 only)
+  P<int> done;    // [ncol] steps of this launch a column has completed, then [ncol] steps of it that have been started
+                  // (zeroed per launch; nsteps_launch > 1 only)
   P<unsigned long long> dbg;   // optional [32] phase-cycle accumulators (diagnostic builds of a run only)
   // optional physics: ext != 0 selects the kernel build that carries it
   int ext, L_RELAX_SST, L_RELAX_CALCONLY, L_FCORR, L_FCORR_WITHZ, L_SFCORR, L_SFCORR_WITHZ;

@@ -1184,19 +1184,45 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     int lane = lane_k; asm volatile("" : "+v"(lane));
     bool a = false, wt = false, sticky = false;
     const bool multi = p.nsteps_launch > 1;
-    if (multi) {
-      const bool pub = lane < W && sirec[lane * I_COUNT + I_STATE] == PS_ACTIVE && sirec[lane * I_COUNT + I_FIN] == F_FINAL;
-      if (pub) __hip_atomic_store(p.done + sirec[lane * I_COUNT + I_COL], sirec[lane * I_COUNT + I_STEP] + 1, __ATOMIC_RELAXED,
-                                  __HIP_MEMORY_SCOPE_AGENT);
-    }
     int *msi = sirec + (lane < W ? lane : 0) * I_COUNT;
     double *msc = screc + (lane < W ? lane : 0) * C_COUNT;
     int st = PS_DONE, c = 0, step = 0;
-    bool want = false, ready = false, idle = false;
+    bool want = false, ready = false, idle = false, dropped = false;
+    // Who starts a column's next step.  A step is started by whoever first moves the column's count of started steps
+    // (p.done[ncol + c]) from s to s+1, and there are two who try:
+    //  - the slot that draws its ticket, if it finds the step before complete (p.done[c] >= s).  If it does not, it DROPS
+    //    the ticket and draws the next - it does not hold it: a column on its way to itermax falls behind the queue by
+    //    tens of steps in a long launch, and every ticket held for it was a slot that waited, empty (with fewer columns
+    //    than slots the whole launch then moved in lockstep with its slowest column);
+    //  - the slot that finishes the step before, if that ticket is out already (the queue's head is beyond it): the
+    //    column goes on where it is, without a gap in the very chain the launch ends with.  A column whose next ticket
+    //    has not been drawn ends here as ever - the queue's order is what keeps the workgroups' rounds together - and
+    //    the ticket, when it is drawn, finds the step complete.
+    // No step is lost between the two: the finishing slot publishes the step (an atomic exchange, waited for) BEFORE it
+    // reads the head, the drawing slot has moved the head (an atomic add whose result names the column) BEFORE it reads
+    // the column's count - if the one misses the other's write, the other sees the one's.  A column that goes on this
+    // way counts as a straggler from its first pass (it is behind).
+    bool cont = false;
+    if (multi) {
+      const bool pub = lane < W && msi[I_STATE] == PS_ACTIVE && msi[I_FIN] == F_FINAL;
+      if (pub) {
+        const int fc = msi[I_COL], fs = msi[I_STEP];
+        int was = __hip_atomic_exchange(p.done + fc, fs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(was) : : "memory");   // performed, before the head is read
+        if (fs + 1 < p.nsteps_launch) {
+          const int q = fc % p.nqueues, nloc = (p.ncol - q + p.nqueues - 1) / p.nqueues;
+          const int tnext = (fs + 1) * nloc + fc / p.nqueues;   // c = q + nq j is ticket step nloc + j of queue q
+          if (__hip_atomic_load((int *)p.qhead + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > tnext)
+            cont = atomicCAS((int *)p.done + p.ncol + fc, fs + 1, fs + 2) == fs + 1;
+          if (cont) { c = fc; step = fs + 1; want = true; }
+        }
+      }
+    }
+    const bool any_cont = __ballot(cont) != 0ull;
     // the workgroup is in a view of a few slots and some of their columns go on: nothing else starts here until they are
     // done - a ticket held for another column waits that long (its column's later steps wait for it anyway)
     const int kv = solo_perm ? 0 : s_flags[S_KVIEW];
-    const bool solo_on = kv > 0 && __ballot(lane < W && sirec[lane * I_COUNT + I_STATE] == PS_ACTIVE && sirec[lane * I_COUNT + I_FIN] != F_FINAL) != 0ull;
+    const bool solo_on = kv > 0 && (any_cont || __ballot(lane < W && sirec[lane * I_COUNT + I_STATE] == PS_ACTIVE && sirec[lane * I_COUNT + I_FIN] != F_FINAL) != 0ull);
     if (lane < W) {
       st = msi[I_STATE];
       if (st == PS_ACTIVE && msi[I_FIN] == F_FINAL) st = PS_EMPTY;   // its outputs are stored (barrier before M0)
@@ -1210,7 +1236,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     // one by one took 6.0).  So a slot that comes free alone waits, empty, for the next round: slots are refilled
     // when at least half of those that take part in the rounds are free - a column past its twelfth pass does not
     // (it is on its way to itermax: nobody waits for it, and when it ends its slot waits for the others).
-    const int n_empty = __popcll(__ballot(lane < W && st == PS_EMPTY));
+    const int n_empty = __popcll(__ballot(lane < W && st == PS_EMPTY && !cont));
     const int n_busy = __popcll(__ballot(lane < W && st == PS_ACTIVE && sirec[lane * I_COUNT + I_NPASS_TRY] <= 12));
     bool refill = 2 * n_empty >= n_empty + n_busy;
     // Stragglers.  A column past its solo_after-th pass of a try - or one that went to itermax in its previous step: they
@@ -1231,19 +1257,19 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       if (gone) msi[I_STRAG] = 0;
       const int delta = __popcll(__ballot(is && !was)) - __popcll(__ballot(gone));
       int glob = 0;
-      if (__ballot(is) != 0ull || delta != 0) {
+      if (__ballot(is) != 0ull || delta != 0 || any_cont) {
         if (lane == 0) glob = delta != 0 ? atomicAdd((int *)p.sync, delta) + delta
                                          : __hip_atomic_load((int *)p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         glob = __shfl(glob, 0);
       }
-      drain = __ballot(is) != 0ull && glob <= p.solo_limit;
+      drain = (__ballot(is) != 0ull || any_cont) && glob <= p.solo_limit;
       if (solo_on) drain = true;
       else if (kv > 0 && lane == 0) s_flags[S_KVIEW] = 0;   // its columns are done: back to the view of every slot
       if (drain) refill = false;
     }
     if (lane < W) {
       if (st == PS_EMPTY) { msi[I_FIN] = F_NONE; msi[I_ACT] = 0; }
-      if (st == PS_EMPTY && refill) {
+      if (st == PS_EMPTY && refill && !cont) {
         if (!multi) {
           const int t = atomicAdd((int *)p.qhead, 1);
           if (t >= p.ncol) { st = PS_DONE; msi[I_ACT] = 0; }
@@ -1253,16 +1279,32 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           msi[I_ACT] = 0;
           const int q = s_flags[7];
           const int nloc = q < 0 ? 0 : (p.ncol - q + p.nqueues - 1) / p.nqueues;   // its columns: c = q + nq j
-          const int t = nloc > 0 ? atomicAdd((int *)p.qhead + q, 1) : 0;
-          if (nloc <= 0 || t >= nloc * p.nsteps_launch) idle = true;   // stays PS_EMPTY: the workgroup looks for another queue
-          else {
+          for (;;) {   // (every trip takes a ticket off the queue)
+            const int t = nloc > 0 ? atomicAdd((int *)p.qhead + q, 1) : 0;
+            if (nloc <= 0 || t >= nloc * p.nsteps_launch) { idle = true; break; }   // stays PS_EMPTY: the workgroup looks for another queue
             step = t / nloc;
             c = q + p.nqueues * (t - step * nloc);
-            want = true;
+            int *const started = (int *)p.done + p.ncol + c;
+            if (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > step) continue;   // its column went on by itself
+            if (step > 0 && __hip_atomic_load(p.done + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < step) continue;   // ... and will
+            if (atomicCAS(started, step, step + 1) != step) continue;
+            want = true; ready = true;
+            break;
           }
         }
       }
-      if (want) ready = !(multi && step > 0) || __hip_atomic_load(p.done + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= step;
+      if (cont || ready) ready = true;
+      else if (want && multi) {   // (a ticket held from an earlier M0: none is, since tickets are dropped - kept for the adoption path's sake)
+        // a ticket: void if the step has been started already (its column went on by itself, above); ready once the
+        // step before is complete, and then this slot's if it is the one to move the count of started steps
+        int *const started = (int *)p.done + p.ncol + c;
+        bool mine = false;
+        if (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= step) {
+          ready = step == 0 || __hip_atomic_load(p.done + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= step;
+          mine = !ready || atomicCAS(started, step, step + 1) == step;
+        }
+        if (!mine) { want = false; ready = false; dropped = true; st = PS_EMPTY; msi[I_ACT] = 0; }   // (M0 again at the next iteration: the slot draws another)
+      } else if (want) ready = true;
     }
     if (multi && __ballot(want && ready && step > 0) != 0ull)
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // before anything of those columns is read (here, and by every thread after the barrier)
@@ -1307,7 +1349,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
           msi[I_KBLC] = 0x7fffffff; msi[I_NVIOL] = 0; msi[I_NU] = 0; msi[I_NV] = 0; msi[I_NF] = 0; msi[I_PAR] = 0;
           msi[I_L1A] = 0; msi[I_MAYBE_NEXT] = msi[I_MAYBE]; msi[I_TINY] = 0;
           // (at itermax in its previous step - ci holds that step's pass count: a straggler from its first pass on)
-          sticky = p.solo_limit > 0 && p.mode == MCKPP_MODE_STEP && ci[CI_NPASS] > 50;
+          sticky = p.solo_limit > 0 && p.mode == MCKPP_MODE_STEP && (ci[CI_NPASS] > 50 || cont);
           msi[I_STRAG] = sticky ? 1 : 0;
           s_flags[3] = nz;   // no guess for a new column: L3 forms the bulk Richardson numbers of every level
           msc[C_F] = cs[CS_F]; msc[C_WXNT0] = 0.0; msc[C_HMIXE] = 0.0; msc[C_HMIXN] = 0.0;
@@ -1343,7 +1385,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       }
       msi[I_STATE] = st;
       a = st == PS_ACTIVE;
-      wt = st == PS_WAIT || (idle && more);
+      wt = st == PS_WAIT || (idle && more) || dropped;
     }
     const unsigned long long m = __ballot(a), mw = __ballot(wt);
     {

@@ -116,7 +116,7 @@ struct mckpp_hip_ctx {
   int *d_qhead = nullptr;  // QBLOCK_INTS ints, zeroed before every launch: [0..15] queue heads, [16..31] queue owners, [32] stragglers on the device
   int view_kmax = 0;   // mckpp_kparams_t::view_kmax (MCKPP_VIEW_KMAX)
   int solo_after = 12, solo_limit = 8;   // mckpp_kparams_t::solo_after / solo_limit (MCKPP_SOLO=0, MCKPP_SOLO_AFTER, MCKPP_SOLO_LIMIT)
-  int *d_done = nullptr;   // [ncol] steps of a multi-step launch each column has completed (mckpp_kparams_t::done)
+  int *d_done = nullptr;   // [2][ncol] steps of a multi-step launch each column has completed, and has started (mckpp_kparams_t::done)
   bool multistep = true;   // mckpp_hip_step(nt, n > 1) as one launch (MCKPP_MULTISTEP=0: a launch per step)
   int nqueues = 0;         // XCDs of the device, found by a probe at init: the queues of such a launch
   int xcc_queue[16];       // hardware XCC id -> queue (-1: no workgroup of the probe ran there)
@@ -901,7 +901,7 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode, const forced_r
   // columns are independent; every step still stores its outputs and diagnostics).  The forced run too: a step
   // that is a flux update assembles its column's forcing from the resident record itself.  Not for a step at ntime = 0.
   if (mode == MCKPP_MODE_STEP && nsteps > 1 && ntime >= 1 && h->multistep) {
-    if (!h->d_done) HIPCHK(hipMalloc(&h->d_done, (size_t)h->ncol * sizeof(int)));
+    if (!h->d_done) HIPCHK(hipMalloc(&h->d_done, 2 * (size_t)h->ncol * sizeof(int)));   // done[ncol], then the steps started (k_column_ps, M0)
     const int per_launch = (int)std::max<int64_t>(1, ((int64_t)1 << 30) / h->ncol);   // tickets are 32-bit (per queue: fewer still)
     for (int i = 0; i < nsteps; i += per_launch) {
       const int n = nsteps - i < per_launch ? nsteps - i : per_launch;
@@ -917,7 +917,7 @@ static int run(mckpp_hip_ctx *h, int ntime, int nsteps, int mode, const forced_r
       HIPCHK(hipMemcpyAsync(h->d_params, &h->h_params[slot], sizeof(mckpp_kparams), hipMemcpyHostToDevice, h->stream));
       HIPCHK(hipEventRecord(h->ev_params[slot], h->stream));
       HIPCHK(hipMemsetAsync(h->d_qhead, 0, QBLOCK_INTS * sizeof(int), h->stream));
-      HIPCHK(hipMemsetAsync(h->d_done, 0, (size_t)h->ncol * sizeof(int), h->stream));
+      HIPCHK(hipMemsetAsync(h->d_done, 0, 2 * (size_t)h->ncol * sizeof(int), h->stream));
       HIPCHK(mckpp_launch_column_kernel_ps(h->h_params[slot], h->d_params, h->num_cu, h->stream, &h->last_launch));
     }
     HIPCHK(hipEventRecord(h->ev1, h->stream));
