@@ -1600,6 +1600,15 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
     // changes hands after that pass's L1, below).  (A slot that holds a ticket it waits to start keeps it until these
     // columns are done, M0: mostly it is one of these very columns' next step.)  Decided here, in the manager's wait
     // behind its L6 items.
+#ifdef MCKPP_PS_STAMPS
+    {   // census of the stragglers' passes (p.sync[1..6]; MCKPP_LIST_DEBUG=1 prints it): theirs in a view | beside other
+        // columns, the workgroup passes of either kind, and the active slots of those
+      const bool sg = lane < W && sirec[lane * I_COUNT + I_STATE] == PS_ACTIVE && sirec[lane * I_COUNT + I_ACT] && sirec[lane * I_COUNT + I_STRAG];
+      const int n = __popcll(__ballot(sg));
+      const int nact = __popcll(__ballot(lane < W && sirec[lane * I_COUNT + I_STATE] == PS_ACTIVE && sirec[lane * I_COUNT + I_ACT]));
+      if (lane == 0 && n > 0) { atomicAdd((int *)p.sync + (sparse ? 1 : 2), n); atomicAdd((int *)p.sync + (sparse ? 3 : 4), 1); atomicAdd((int *)p.sync + (sparse ? 5 : 6), nact); }
+    }
+#endif
     if (solo_dyn && !sparse) {
       const int f_kv = s_flags[S_KVIEW], f_drain = s_flags[S_DRAIN];
       if (f_kv == 0 && f_drain) {

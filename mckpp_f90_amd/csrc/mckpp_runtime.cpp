@@ -997,6 +997,14 @@ int mckpp_hip_synchronize(mckpp_hip_handle h)
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (getenv("MCKPP_LIST_DEBUG") && h->d_qhead) {   // after the last launch: the queues' heads, and (stamp builds) the stragglers' passes
+    int qb[QBLOCK_INTS];
+    HIPCHK(hipMemcpy(qb, h->d_qhead, sizeof qb, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[mckpp queues] stragglers left %d; (stamp builds: straggler passes in a view %d, beside others %d; workgroup passes with one %d | %d, their active slots %d | %d); heads",
+            qb[32], qb[33], qb[34], qb[35], qb[36], qb[37], qb[38]);
+    for (int q = 0; q < h->nqueues; ++q) fprintf(stderr, " %d", qb[q]);
+    fprintf(stderr, "\n");
+  }
   if (h->d_dbg) {   // MCKPP_STAMP=1: print and reset the per-segment cycle sums of the stamping wave of every workgroup
     unsigned long long t[32];
     HIPCHK(hipMemcpy(t, h->d_dbg, sizeof t, hipMemcpyDeviceToHost));

@@ -769,6 +769,44 @@ def test_views_in_a_launch_of_several_steps(mk, monkeypatch, env):
             assert np.array_equal(np.asarray(getattr(got[0], name)), np.asarray(getattr(ref[0], name)), equal_nan=True), (name, env)
 
 
+@pytest.mark.parametrize("ncol,nz,nsteps,env", [(64, 100, 12, {}), (300, 60, 10, {}), (2000, 40, 8, {}), (64, 60, 12, {"MCKPP_PS": "15x8x2"}),
+                                                 (300, 60, 10, {"MCKPP_XCC_DROP": "0x55"}), (700, 100, 6, {"MCKPP_SOLVER_MODE": "1"})])
+def test_columns_behind_the_queue_go_on_where_they_are(mk, monkeypatch, ncol, nz, nsteps, env):
+    """A launch of several steps with FEWER columns than the device has slots: every ticket of the later steps is drawn
+    long before its column has finished the step before.  Such tickets are dropped, not held (held, each was a slot that
+    waited, and with as many columns as workgroups the launch moved in lockstep with its slowest column: 64 columns x
+    300 steps took 478 ms where the longest chain alone takes 174), and the slot that finishes a step whose successor's
+    ticket is out starts that successor itself (k_column_ps, M0: the count of started steps, moved by whoever comes
+    first).  No step may be lost or run twice between the two: steps 2.. from the analytic start (many columns at
+    itermax) in one launch against a launch per step - every field, the status words and pass counts of the last step,
+    and the time levels' parity (a lost or repeated step shows there) - twice, for the races' sake."""
+    def run(multi):
+        for k in ("MCKPP_PS", "MCKPP_XCC_DROP", "MCKPP_SOLVER_MODE"):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("MCKPP_MULTISTEP", multi)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        kc, k3 = cm.make_hip_case(ncol, nz, land_every=9)
+        ctx = mk.MckppHip(kc)
+        ctx.upload(k3)
+        ctx.init_ocean(0)
+        cm.set_forcing_3d(k3, cm.synth.forcing(ncol, "bench"))
+        ctx.set_forcing(k3.sflux)
+        ctx.step(1, nsteps)
+        ctx.download(k3)
+        st, nf, npass = ctx.status()
+        ctx.close()
+        return k3, st.copy(), npass.copy()
+
+    ref = run("0")
+    for _ in range(2):
+        got = run("1")
+        assert np.array_equal(np.asarray(got[0].old), np.asarray(ref[0].old)) and np.array_equal(np.asarray(got[0].new_), np.asarray(ref[0].new_))
+        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+        for name in ("U", "X", "Us", "Xs", "hmixd", "hmix", "kmix", "Tref", "uref", "vref", "Ssurf", "difm", "dift", "ghat", "wU", "wX", "Rig"):
+            assert np.array_equal(np.asarray(getattr(got[0], name)), np.asarray(getattr(ref[0], name)), equal_nan=True), (name, env)
+
+
 @pytest.mark.parametrize("drop", ["0x55", "0xfe"])
 def test_queues_without_workgroups_of_their_own_are_adopted(mk, monkeypatch, drop):
     """A launch of several steps keeps a column on one XCD (a queue per XCD, the workgroups of an XCD draw from its own:

@@ -26,16 +26,21 @@ nt = settle + 1
 tot = np.zeros(len(idx), dtype=np.int64)
 nit = np.zeros(len(idx), dtype=np.int64)
 per_step = []
+hist = []
 for _ in range(nsteps):
     ctx.step(nt, 1); ctx.synchronize()
     st, nf, npass = ctx.status()
     tot += npass
     nit += npass > 50
     per_step.append(int((npass > 50).sum()))
+    hist.append(npass.copy())
     nt += 1
 order = np.argsort(-tot)
 print(f"nz={nz} ncol={len(idx)}: {nsteps} steps after {settle}; columns over 50 passes per step: mean {np.mean(per_step):.1f} max {max(per_step)}")
 print(f"  passes of a column over the {nsteps} steps: mean {tot.mean():.0f}, longest chains {list(tot[order][:8])} (steps at itermax {list(nit[order][:8])})")
+hist = np.asarray(hist)
+for r in range(3):
+    print(f"  column {idx[order[r]]}: steps (of the {nsteps}) at itermax: {list(np.flatnonzero(hist[:, order[r]] > 50))}")
 for thr in (1, 5, 10, 20, 40):
     print(f"  columns with >= {thr} steps at itermax: {(nit >= thr).sum()}")
 for us in (43.5, 26.0, 19.0):
@@ -61,7 +66,22 @@ def alone(cols, label):
     c2.close()
 
 
-if os.environ.get("ALONE", "1") != "0":
+if os.environ.get("ALONE", "1") == "4":
+    reg = nit == 0
+    for n in (7, 50, 156):
+        sel = reg.copy(); sel[order[:n]] = True
+        alone(idx[sel], f"the columns never at itermax + the {n} longest chains (MCKPP_GATHER={os.environ.get('MCKPP_GATHER')})")
+elif os.environ.get("ALONE", "1") == "3":
+    for k in (1, 2, 4, 9, 19):
+        alone(idx[order[:k]], f"the {k} longest in one workgroup (MCKPP_PS={os.environ.get('MCKPP_PS')})")
+        print(f"    their passes: {list(tot[order[:k]])}")
+elif os.environ.get("ALONE", "1") == "2":
+    alone(idx, "every column")
+    alone(idx[nit < 20], "all but those with >= 20 steps at itermax")
+    alone(idx[nit < 10], "all but those with >= 10")
+    alone(idx[nit < 5], "all but those with >= 5")
+    alone(idx[nit < 1], "all but those with >= 1")
+elif os.environ.get("ALONE", "1") != "0":
     alone(idx[order[:1]], "the longest chain")
     alone(idx[order[:8]], "the 8 longest")
     alone(idx[order[:64]], "the 64 longest")
