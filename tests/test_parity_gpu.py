@@ -770,6 +770,7 @@ def test_views_in_a_launch_of_several_steps(mk, monkeypatch, env):
 
 
 @pytest.mark.parametrize("ncol,nz,nsteps,env", [(64, 100, 12, {}), (300, 60, 10, {}), (2000, 40, 8, {}), (64, 60, 12, {"MCKPP_PS": "15x8x2"}),
+                                                 (200, 100, 60, {}), (5000, 100, 24, {"MCKPP_SOLO_LIMIT": "1000000"}),
                                                  (300, 60, 10, {"MCKPP_XCC_DROP": "0x55"}), (700, 100, 6, {"MCKPP_SOLVER_MODE": "1"})])
 def test_columns_behind_the_queue_go_on_where_they_are(mk, monkeypatch, ncol, nz, nsteps, env):
     """A launch of several steps with FEWER columns than the device has slots: every ticket of the later steps is drawn
@@ -781,7 +782,7 @@ def test_columns_behind_the_queue_go_on_where_they_are(mk, monkeypatch, ncol, nz
     itermax) in one launch against a launch per step - every field, the status words and pass counts of the last step,
     and the time levels' parity (a lost or repeated step shows there) - twice, for the races' sake."""
     def run(multi):
-        for k in ("MCKPP_PS", "MCKPP_XCC_DROP", "MCKPP_SOLVER_MODE"):
+        for k in ("MCKPP_PS", "MCKPP_XCC_DROP", "MCKPP_SOLVER_MODE", "MCKPP_SOLO_LIMIT"):
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setenv("MCKPP_MULTISTEP", multi)
         for k, v in env.items():
