@@ -97,16 +97,18 @@ __host__ __device__ inline int ps_nl(int L) { return L; }   // level indices 0..
 // (60, 69, 100 levels, both solver modes; the shipped-namelist shape within noise): bank conflicts are not what
 // these phases wait for.  So the default stays round 3's rule - rows*L rounded up to odd, not +-1 mod 32 (the manager
 // lanes' pattern) - and MCKPP_PS_CONFLICT_FREE=1 selects the stride below (the counters of both are on record).
+__host__ __device__ constexpr int ps_ss_default(int s0)   // the default rule: rows * L rounded up to odd, not +-1 mod 32
+{
+  int s = s0;
+  if (!(s & 1)) ++s;
+  while ((s & 31) == 1 || (s & 31) == 31) s += 2;
+  return s;
+}
 __host__ inline int ps_ss(int L, int xv, int W)
 {
   const int rows = ps_rows(xv), s0 = rows * ps_nl(L);
   static const bool conflict_free = getenv("MCKPP_PS_CONFLICT_FREE") != nullptr && atoi(getenv("MCKPP_PS_CONFLICT_FREE")) != 0;
-  if (!conflict_free) {
-    int s = s0;
-    if (!(s & 1)) ++s;
-    while ((s & 31) == 1 || (s & 31) == 31) s += 2;
-    return s;
-  }
+  if (!conflict_free) return ps_ss_default(s0);
   if (W <= 1) return s0 | 1;
   int best = s0, best_cost = 1 << 30;
   for (int pad = 0; pad < 32; ++pad) {
@@ -982,13 +984,18 @@ struct strided {   // x[i] of a level-interleaved row
 
 // XV: physics variant (rows above); SM: tridiagonal solver mode - 0 the reference's order of operations
 // (solvers.F90:112-161), 1 the two-ended elimination (opt-in, ps_thomas2_*)
-template <int XV, int SM>
+// LF: 0, or the number of level items per column (nzp1 + 2) as a compile-time constant - the item arithmetic of the level
+// phases (item -> slot, level; the rows' strides) with literals instead of uniform values held in (spilled) SGPRs
+// (the slot count and the slot stride as literals too: measured, -1 % at 60 levels, not kept)
+template <int XV, int SM, int LF = 0>
 #ifndef MCKPP_PS_MINW
 #define MCKPP_PS_MINW 4
 #endif
-__global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_kparams *__restrict__ pp, const int ntime, const int L,
-                                                     const int W0, const unsigned Lmagic, const int SS /* ps_ss(L, XV, W0) */)
+__global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_kparams *__restrict__ pp, const int ntime, const int L_arg,
+                                                     const int W0, const unsigned Lmagic_arg, const int SS /* ps_ss(L, XV, W0) */)
 {
+  const int L = LF > 0 ? LF : L_arg;
+  const unsigned Lmagic = LF > 0 ? (unsigned)(0x100000000ull / (unsigned long long)(LF > 0 ? LF : 1)) + 1u : Lmagic_arg;
   // through the block typed with global pointers (mckpp_device.h): global_load / global_store, SGPR bases
   const mckpp_kparams_dev &p = *reinterpret_cast<const mckpp_kparams_dev *>(pp);
   extern __shared__ double lds[];
@@ -997,7 +1004,7 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
   const int NL = ps_nl(L);
   const int tid = threadIdx.x, lane = tid & 63, lane_k = lane;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nz = p.nz, nzp1 = p.nzp1;
+  const int nz = LF > 0 ? LF - 3 : p.nz, nzp1 = LF > 0 ? LF - 2 : p.nzp1;   // (L = nzp1 + 2)
   double *cst = lds;
   const strided<K_STRIDE> c_zm{cst + K_ZM}, c_hm{cst + K_HM}, c_t0{cst + K_T0}, c_t1{cst + K_T1}, c_rdz{cst + K_RDZ},
       c_dtohk{cst + K_DTOHK};
@@ -2850,10 +2857,17 @@ hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kpa
   const size_t lds = ps_lds_bytes(L, g.w, xv);
   if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
   using kern_t = void (*)(const mckpp_kparams *, int, int, int, unsigned, int);
+  // the default-physics kernels of BASELINE's shapes (60, 69, 100 levels) with the number of level items as a literal: half the
+  // spilled SGPRs (104 -> 55), 6 % fewer vector instructions in the item loops; +3 % at 60 levels, +1.4 % at 100
+  // (MCKPP_PS_FIXED_L=0: the general kernels, for A/B runs and tests)
+  static const kern_t kerns_63[2] = {k_column_ps<0, 0, 63>, k_column_ps<0, 1, 63>}, kerns_72[2] = {k_column_ps<0, 0, 72>, k_column_ps<0, 1, 72>},
+                      kerns_103[2] = {k_column_ps<0, 0, 103>, k_column_ps<0, 1, 103>};
   static const kern_t kerns[2][3] = {{k_column_ps<0, 0>, k_column_ps<1, 0>, k_column_ps<2, 0>},
                                      {k_column_ps<0, 1>, k_column_ps<1, 1>, k_column_ps<2, 1>}};
   if (p.solver_mode < 0 || p.solver_mode > 1) return hipErrorInvalidValue;
-  const kern_t kern = kerns[p.solver_mode][xv];
+  const bool fixed_l = !(getenv("MCKPP_PS_FIXED_L") && atoi(getenv("MCKPP_PS_FIXED_L")) == 0);   // (read at every launch: tests switch it)
+  const kern_t kern = (fixed_l && xv == 0 && L == 63) ? kerns_63[p.solver_mode] : (fixed_l && xv == 0 && L == 72) ? kerns_72[p.solver_mode]
+                    : (fixed_l && xv == 0 && L == 103) ? kerns_103[p.solver_mode] : kerns[p.solver_mode][xv];
   const void *fn = reinterpret_cast<const void *>(kern);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

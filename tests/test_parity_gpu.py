@@ -808,6 +808,41 @@ def test_columns_behind_the_queue_go_on_where_they_are(mk, monkeypatch, ncol, nz
             assert np.array_equal(np.asarray(getattr(got[0], name)), np.asarray(getattr(ref[0], name)), equal_nan=True), (name, env)
 
 
+@pytest.mark.parametrize("nz,grid,solver", [(60, "uniform", 0), (69, "stretched", 0), (100, "uniform", 0), (60, "uniform", 1), (100, "uniform", 1)])
+def test_kernels_with_the_level_count_as_a_literal(mk, monkeypatch, nz, grid, solver):
+    """BASELINE's shapes (60, 69, 100 levels, default physics) run kernels compiled with the number of level items as a
+    literal (k_column_ps<XV, SM, LF>: half the spilled SGPRs, +3 % at 60 levels); every other shape, the optional
+    physics, and MCKPP_PS_FIXED_L=0 the general ones.  Same source, same operations: three steps from the analytic start
+    (step 2 takes a seventh of the columns to itermax) through either must agree in every bit - and the other tests of
+    these shapes compare the literal kernels with the oracle."""
+    ncol = 1500
+
+    def run(fixed):
+        monkeypatch.setenv("MCKPP_PS_FIXED_L", fixed)
+        monkeypatch.setenv("MCKPP_SOLVER_MODE", str(solver))
+        kc, k3 = cm.make_hip_case(ncol, nz, grid=grid, land_every=11)
+        ctx = mk.MckppHip(kc)
+        ctx.upload(k3)
+        ctx.init_ocean(0)
+        cm.set_forcing_3d(k3, cm.synth.forcing(ncol, "bench"))
+        ctx.set_forcing(k3.sflux)
+        out = []
+        for nt, n in ((1, 1), (2, 2)):   # a launch of one step, then one of two
+            ctx.step(nt, n)
+            ctx.download(k3)
+            st, nf, npass = ctx.status()
+            out.append((st.copy(), npass.copy(), {n_: np.array(getattr(k3, n_), copy=True) for n_ in
+                        ("U", "X", "Us", "Xs", "hmixd", "hmix", "kmix", "Tref", "uref", "vref", "Ssurf", "difm", "difs", "dift", "ghat", "wU", "wX", "wXNT", "Rig", "rho", "cp", "buoy")}))
+        ctx.close()
+        return out
+
+    a, b = run("0"), run("1")
+    for (sa, pa, fa), (sb, pb, fb) in zip(a, b):
+        assert np.array_equal(sa, sb) and np.array_equal(pa, pb)
+        for n_ in fa:
+            assert np.array_equal(fa[n_], fb[n_], equal_nan=True), n_
+
+
 @pytest.mark.parametrize("drop", ["0x55", "0xfe"])
 def test_queues_without_workgroups_of_their_own_are_adopted(mk, monkeypatch, drop):
     """A launch of several steps keeps a column on one XCD (a queue per XCD, the workgroups of an XCD draw from its own:

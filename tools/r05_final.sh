@@ -13,6 +13,7 @@ if [ "${PART:-a}" = "a" ]; then
   MCKPP_SOLO_AFTER=0 MCKPP_SOLO_LIMIT=1000000 MCKPP_SOLVER_MODE=1 timeout -k 10 900 python -m pytest tests/test_parity_gpu.py -x -q -m gpu -k "$S" > $O/tests_forced_solo_sm1.log 2>&1; echo "pytest (the same, solver mode 1) rc=$?"; tail -2 $O/tests_forced_solo_sm1.log
   MCKPP_SOLO=0 timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "$S" > $O/tests_solo_off.log 2>&1; echo "pytest (MCKPP_SOLO=0) rc=$?"; tail -2 $O/tests_solo_off.log
   MCKPP_MULTISTEP=0 timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "$S" > $O/tests_multistep0.log 2>&1; echo "pytest (MCKPP_MULTISTEP=0) rc=$?"; tail -2 $O/tests_multistep0.log
+  MCKPP_PS_FIXED_L=0 timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "$S" > $O/tests_general_kernels.log 2>&1; echo "pytest (MCKPP_PS_FIXED_L=0) rc=$?"; tail -2 $O/tests_general_kernels.log
   MCKPP_L3_CAP=3 timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "$S" > $O/tests_l3cap3.log 2>&1; echo "pytest (MCKPP_L3_CAP=3) rc=$?"; tail -2 $O/tests_l3cap3.log
   timeout -k 10 800 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"
   python tools/r05_digest.py $O/bench_n1.json | tee $O/bench_n1_digest.txt
