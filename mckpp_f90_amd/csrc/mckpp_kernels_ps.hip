@@ -684,6 +684,116 @@ __device__ __forceinline__ void ps_thomas2_uts_fwd(int W, double *slots, int SS,
   }
 }
 
+// The same with its LDS traffic issued by hand, as ps_thomas_uts_fwd4 above (default and optional physics): half-trips of
+// two levels on two register sets, one vote per half, the half redone on the IEEE path from its entry state when the vote
+// fires, results stored with two ds_write2_b64.  A half's addresses are those of the LOWER of its two levels (lo): the
+// way down it works lo then lo + 1, the way up lo + 1 then lo; the three address registers move by two levels per half in
+// the sweep's direction, every other displacement is an offset field.  Same operations on the same operands as
+// ps_thomas2_uts_fwd.
+template <int XV, int DIR>
+__device__ __forceinline__ void ps_thomas2_uts_fwd4(int W, double *slots, int SS, int nz, const int *sact, int sact_stride,
+                                                    int *sbad, int sbad_stride, int lane)
+{
+  static_assert(XV != 2, "p and q rows seven apart");
+  constexpr int KS = XV == 1 ? (int)Q_COUNT_EXT : (int)Q_COUNT;
+  asm volatile("" : "+v"(lane));
+  if (lane < 3 * W) {
+    const int sl = lane / 3, sys = lane - 3 * sl;
+    if (sact[sl * sact_stride]) {
+      double *base = slots + sl * SS;
+      const double *pb = base + ps_sysrows<XV>::p(sys), *qq = pb + 7;
+      double *y = base + (Q_YU + sys), *gm = base + ps_sysrows<XV>::gam(sys);
+      const int m = nz >> 1;
+      const int i0 = DIR > 0 ? 1 : nz;
+      int bad = 0;
+      double carry = DIR > 0 ? pb[(1) * KS] : qq[(nz) * KS];
+      double bet = DIR > 0 ? 1. + carry : (1. + pb[(nz) * KS]) + carry;   // cc(1) | cc(nz)
+      if (DIR < 0 && bet == 0.) { bad = 1; bet = 1.E-12; }
+      double ynum = y[(i0) * KS];
+      asm volatile("" : "+v"(carry), "+v"(bet), "+v"(ynum));   // their waits here, not inside the loop
+      auto slow_level = [&](double p, double q, double rhs, double &g_out, double &y_out) {
+        if (bet == 0.) { bad = 1; bet = 1.E-12; }
+        const double rb = rcp_refine(bet);
+        const double g = div_by_refined(-carry, bet, rb);
+        const double yprev = div_by_refined(ynum, bet, rb);
+        g_out = g; y_out = yprev;
+        const double mult = DIR > 0 ? q : p;
+        bet = ((1. + p) + q) + mult * g;
+        ynum = rhs + mult * yprev;
+        carry = DIR > 0 ? p : q;
+      };
+      int i = i0 + DIR, left = (DIR > 0 ? m : nz - m) - 1;   // the next level, and how many there are
+      if (left >= 2) {
+        // ap: (p, q) of level lo; ay: the solution row at lo - 1 (down) | lo (up); ag: gam at lo (down) | lo + 1 (up)
+        const int lo = DIR > 0 ? i : i - 1;
+        unsigned ap = ps_lds_addr(pb + lo * KS), ay = ps_lds_addr(y + (DIR > 0 ? lo - 1 : lo) * KS), ag = ps_lds_addr(gm + (DIR > 0 ? lo : lo + 1) * KS);
+        const unsigned hstep = (unsigned)(DIR * 2 * KS * 8);   // a half further (two levels, in bytes; wraps as it should the way up)
+        auto rd_lo = [&](unsigned a) { return ps_lds_read2<0, 7>(a); };             // (p, q) of lo
+        auto rd_hi = [&](unsigned a) { return ps_lds_read2<KS, KS + 7>(a); };       // ... of lo + 1
+        auto rd_rr = [&](unsigned a) { return DIR > 0 ? ps_lds_read2<KS, 2 * KS>(a) : ps_lds_read2<0, KS>(a); };   // right-hand sides of lo, lo + 1
+        // a half at (ay_, ag_) on the operands of its two levels
+        auto two = [&](unsigned ay_, unsigned ag_, const ps_d2 &pq_lo, const ps_d2 &pq_hi, const ps_d2 &rr) {
+          const ps_d2 &pq0 = DIR > 0 ? pq_lo : pq_hi, &pq1 = DIR > 0 ? pq_hi : pq_lo;   // in the order they are worked
+          const double r0 = DIR > 0 ? rr.x : rr.y, r1 = DIR > 0 ? rr.y : rr.x;
+          const double s_carry = carry, s_bet = bet, s_ynum = ynum;
+          double amin = __builtin_fabs(bet);
+          int emin = __builtin_amdgcn_frexp_exp(ynum);
+          double rb = rcp_refine(bet);
+          double g0 = div_fast(-carry, bet, rb), y0 = div_fast(ynum, bet, rb);
+          const double m0 = DIR > 0 ? pq0.y : pq0.x;
+          bet = ((1. + pq0.x) + pq0.y) + m0 * g0;
+          ynum = r0 + m0 * y0;
+          amin = __builtin_fmin(amin, __builtin_fabs(bet));
+          emin = min(emin, __builtin_amdgcn_frexp_exp(ynum));
+          rb = rcp_refine(bet);
+          double g1 = div_fast(DIR > 0 ? -pq0.x : -pq0.y, bet, rb), y1 = div_fast(ynum, bet, rb);
+          const double m1 = DIR > 0 ? pq1.y : pq1.x;
+          bet = ((1. + pq1.x) + pq1.y) + m1 * g1;
+          ynum = r1 + m1 * y1;
+          carry = DIR > 0 ? pq1.x : pq1.y;
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(amin == 0. || emin < -960) != 0ull, 0)) {
+            carry = s_carry; bet = s_bet; ynum = s_ynum;
+            slow_level(pq0.x, pq0.y, r0, g0, y0);
+            slow_level(pq1.x, pq1.y, r1, g1, y1);
+          }
+          // down: y(lo-1), y(lo) and gam(lo), gam(lo+1); up: y(lo+2) <- the first level's, y(lo+1) and gam(lo+2), gam(lo+1)
+          if (DIR > 0) { ps_lds_write2<0, KS>(ay_, y0, y1); ps_lds_write2<0, KS>(ag_, g0, g1); }
+          else { ps_lds_write2<KS, 2 * KS>(ay_, y1, y0); ps_lds_write2<0, KS>(ag_, g1, g0); }
+        };
+        ps_d2 a0 = rd_lo(ap), a1 = rd_hi(ap), ar = rd_rr(ay), b0, b1, br;
+        ps_lds_wait<0>(a0, a1, ar);
+        // Four levels per trip (see ps_thomas_uts_fwd4): the second half's operands fetched at the top and waited for
+        // behind the first half, the next trip's first half fetched behind the first half and waited for at the bottom.
+        // The fetches run two levels ahead of the levels worked on - inside the rows either way (levels >= m - 3 > 0 the
+        // way up, <= m + 4 the way down; nz >= 16 here).
+        while (left >= 4) {
+          const unsigned apb = ap + hstep, ayb = ay + hstep, agb = ag + hstep;
+          b0 = rd_lo(apb); b1 = rd_hi(apb); br = rd_rr(ayb);
+          two(ay, ag, a0, a1, ar);
+          ap = apb + hstep; ay = ayb + hstep; ag = agb + hstep;
+          a0 = rd_lo(ap); a1 = rd_hi(ap); ar = rd_rr(ay);
+          ps_lds_wait<5>(b0, b1, br);   // (behind it: the first half's two stores, the three reads just issued)
+          two(ayb, agb, b0, b1, br);
+          ps_lds_wait<2>(a0, a1, ar);   // (behind it: the second half's two stores)
+          left -= 4; i += 4 * DIR;
+        }
+        if (left >= 2) { two(ay, ag, a0, a1, ar); left -= 2; i += 2 * DIR; }
+        ps_lds_drain();
+      }
+      if (left == 1) {   // the level the halves leave over
+        double g, yp;
+        slow_level(pb[(i) * KS], qq[(i) * KS], y[(i) * KS], g, yp);
+        y[(i - DIR) * KS] = yp; gm[(DIR > 0 ? i : i + 1) * KS] = g;
+      }
+      if (bet == 0.) { bad = 1; bet = 1.E-12; }
+      const double rb = rcp_refine(bet);
+      y[(DIR > 0 ? 0 : nz + 2) * KS] = div_by_refined(ynum, bet, rb);        // z(m) | z(m+1) at the free ends of the row
+      gm[(DIR > 0 ? 0 : 1) * KS] = div_by_refined(-carry, bet, rb);          // gam(m+1) | g(m+1)
+      if (bad) sbad[sl * sbad_stride] = 1;
+    }
+  }
+}
+
 // ... then (after a barrier) the two unknowns in the middle from their 2x2 system, by both waves alike,
 //   y(m) = (z(m) - gam(m+1) z(m+1)) / (1 - gam(m+1) g(m+1)),  y(m+1) = z(m+1) - g(m+1) y(m),
 // and the two substitutions away from it: DIR = +1 upwards from y(m), DIR = -1 downwards from y(m+1).
@@ -2392,8 +2502,18 @@ __global__ __launch_bounds__(1024, MCKPP_PS_MINW) void k_column_ps(const mckpp_k
       // 1,3,0,2,1,3,0,2 (tools/ubench/hwid.hip) - wave 1 of the first shares a SIMD with the manager wave of the second,
       // wave 2 does not (+0.5 ... 0.7 % at 60 and 69 levels; with one 16-wave workgroup per CU wave 1 is the better one)
       const int wv2 = nthreads == 512 ? 2 : nthreads > 64 ? 1 : 0;
-      if (wv == mgr) ps_thomas2_uts_fwd<XV, 1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
-      if (wv == wv2) ps_thomas2_uts_fwd<XV, -1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+      if constexpr (XV != 2 && PS_FWD4) {
+        if (nz >= 16) {
+          if (wv == mgr) ps_thomas2_uts_fwd4<XV, 1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+          if (wv == wv2) ps_thomas2_uts_fwd4<XV, -1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+        } else {
+          if (wv == mgr) ps_thomas2_uts_fwd<XV, 1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+          if (wv == wv2) ps_thomas2_uts_fwd<XV, -1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+        }
+      } else {
+        if (wv == mgr) ps_thomas2_uts_fwd<XV, 1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+        if (wv == wv2) ps_thomas2_uts_fwd<XV, -1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+      }
       STAMP(24);
       __syncthreads();
       if (wv == mgr) ps_thomas2_uts_back<XV, 1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);

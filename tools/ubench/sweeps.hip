@@ -5,12 +5,13 @@
 #include "../../mckpp_f90_amd/csrc/mckpp_kernels_ps.hip"
 
 namespace {
-enum { T_FUSED_FWD = 0, T_BACK, T_V_FWD, T_V_BACK, T_SCAN, T_CHAIN, T_2E_FWD, T_2E_BACK, T_2E_V, T_FUSED_FWD_OLD, T_COUNT };
+enum { T_FUSED_FWD = 0, T_BACK, T_V_FWD, T_V_BACK, T_SCAN, T_CHAIN, T_2E_FWD, T_2E_BACK, T_2E_V, T_FUSED_FWD_OLD, T_2E_FWD_OLD, T_COUNT };
 const char *t_name[T_COUNT] = {"U,T,S forward", "back substitution U,T,S", "V forward", "V back substitution", "bulk-Ri scan",
                                "register chain x = a_i - g_i x, nz levels (reference: no LDS)",
                                "two-ended U,T,S forward (waves 0 and 1)", "two-ended U,T,S middle + substitutions (waves 0 and 1)",
                                "two-ended V, all of it (one wave)",
-                               "U,T,S forward, the compiler's two-level trip (ps_thomas_uts_fwd: rounds 3-4, double diffusion)"};
+                               "U,T,S forward, the compiler's two-level trip (ps_thomas_uts_fwd: rounds 3-4, double diffusion)",
+                               "two-ended U,T,S forward, the compiler's two-level trip (ps_thomas2_uts_fwd: rounds 4-5, double diffusion)"};
 
 template <int TEST>
 __global__ __launch_bounds__(1024, 4) void k_sweep(int W, int nz, int busy, unsigned long long *cyc, double *out, int SS)
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(1024, 4) void k_sweep(int W, int nz, int busy, unsi
     const int sl = i / NL, k = i - sl * NL;
     double *my = slots + sl * SS + k * ROWS;
     my[Q_YU] = 0.1 + 0.001 * k; my[Q_YT] = 10.0 + 0.01 * k; my[Q_YS] = 0.2 - 0.001 * k; my[Q_YV] = 0.05 + 0.001 * k;
-    if (TEST == T_FUSED_FWD || TEST == T_FUSED_FWD_OLD || TEST == T_2E_FWD) { my[Q_DM] = 0.31 + 0.001 * k; my[Q_DT] = 0.29; my[Q_GM] = 0.3; my[Q_BET] = 0.28 + 0.001 * k; }   // p, q
+    if (TEST == T_FUSED_FWD || TEST == T_FUSED_FWD_OLD || TEST == T_2E_FWD || TEST == T_2E_FWD_OLD) { my[Q_DM] = 0.31 + 0.001 * k; my[Q_DT] = 0.29; my[Q_GM] = 0.3; my[Q_BET] = 0.28 + 0.001 * k; }   // p, q
     if (TEST == T_V_FWD || TEST == T_2E_V) { my[Q_BET] = 1.5 + 0.001 * k; my[Q_DT] = 1. / (1.5 + 0.001 * k); my[Q_GM] = 0.3; }   // pivots, reciprocals, q
     if (TEST == T_BACK || TEST == T_V_BACK || TEST == T_2E_BACK) { my[Q_DS] = -0.2; my[Q_BET] = -0.2; }   // gam
     if (TEST == T_2E_V) { my[Q_DS] = -0.2; my[Q_DM] = -0.2; }   // gam at the ends of its row, multipliers of the substitution
@@ -41,9 +42,12 @@ __global__ __launch_bounds__(1024, 4) void k_sweep(int W, int nz, int busy, unsi
   __syncthreads();
   unsigned long long t0 = 0, t1 = 0;
   double sink = 0.0;
-  if (TEST == T_2E_FWD || TEST == T_2E_BACK) {   // both waves; the time of wave 0 from its start to the barrier behind them
+  if (TEST == T_2E_FWD || TEST == T_2E_FWD_OLD || TEST == T_2E_BACK) {   // both waves; the time of wave 0 from its start to the barrier behind them
     t0 = __builtin_amdgcn_s_memtime();
     if (TEST == T_2E_FWD) {
+      if (wv == 0) ps_thomas2_uts_fwd4<XV, 1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+      if (wv == 1) ps_thomas2_uts_fwd4<XV, -1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
+    } else if (TEST == T_2E_FWD_OLD) {
       if (wv == 0) ps_thomas2_uts_fwd<XV, 1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
       if (wv == 1) ps_thomas2_uts_fwd<XV, -1>(W, slots, SS, nz, sirec + I_ACT, I_COUNT, sirec + I_BAD, I_COUNT, lane);
     } else {
@@ -117,6 +121,7 @@ int main(int argc, char **argv)
     run<T_CHAIN>(W, nz, waves, busy, dc, dout);
     if (busy == 0) {
       run<T_2E_FWD>(W, nz, waves, busy, dc, dout);
+      run<T_2E_FWD_OLD>(W, nz, waves, busy, dc, dout);
       run<T_2E_BACK>(W, nz, waves, busy, dc, dout);
       run<T_2E_V>(W, nz, waves, busy, dc, dout);
     }
