@@ -2982,12 +2982,17 @@ hipError_t mckpp_launch_column_kernel_ps(const mckpp_kparams &p, const mckpp_kpa
   // (MCKPP_PS_FIXED_L=0: the general kernels, for A/B runs and tests)
   static const kern_t kerns_63[2] = {k_column_ps<0, 0, 63>, k_column_ps<0, 1, 63>}, kerns_72[2] = {k_column_ps<0, 0, 72>, k_column_ps<0, 1, 72>},
                       kerns_103[2] = {k_column_ps<0, 0, 103>, k_column_ps<0, 1, 103>};
+  // ... and the optional-physics kernels (relaxation, flux corrections, advection, ...; not double diffusion) of the same shapes
+  static const kern_t kernx_63[2] = {k_column_ps<1, 0, 63>, k_column_ps<1, 1, 63>}, kernx_72[2] = {k_column_ps<1, 0, 72>, k_column_ps<1, 1, 72>},
+                      kernx_103[2] = {k_column_ps<1, 0, 103>, k_column_ps<1, 1, 103>};
   static const kern_t kerns[2][3] = {{k_column_ps<0, 0>, k_column_ps<1, 0>, k_column_ps<2, 0>},
                                      {k_column_ps<0, 1>, k_column_ps<1, 1>, k_column_ps<2, 1>}};
   if (p.solver_mode < 0 || p.solver_mode > 1) return hipErrorInvalidValue;
   const bool fixed_l = !(getenv("MCKPP_PS_FIXED_L") && atoi(getenv("MCKPP_PS_FIXED_L")) == 0);   // (read at every launch: tests switch it)
   const kern_t kern = (fixed_l && xv == 0 && L == 63) ? kerns_63[p.solver_mode] : (fixed_l && xv == 0 && L == 72) ? kerns_72[p.solver_mode]
-                    : (fixed_l && xv == 0 && L == 103) ? kerns_103[p.solver_mode] : kerns[p.solver_mode][xv];
+                    : (fixed_l && xv == 0 && L == 103) ? kerns_103[p.solver_mode]
+                    : (fixed_l && xv == 1 && L == 63) ? kernx_63[p.solver_mode] : (fixed_l && xv == 1 && L == 72) ? kernx_72[p.solver_mode]
+                    : (fixed_l && xv == 1 && L == 103) ? kernx_103[p.solver_mode] : kerns[p.solver_mode][xv];
   const void *fn = reinterpret_cast<const void *>(kern);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
