@@ -14,6 +14,17 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+@pytest.fixture(autouse=True)
+def _collect_contexts_between_tests():
+    """Device contexts that a test leaves to the garbage collector (mckpp_initialize_ocean_model keeps one on its
+    kpp_const_fields: a reference cycle) are finalized - their host arrays un-pinned, their device memory freed - when
+    the test ends, not at some allocation in the middle of a later test."""
+    yield
+    import gc
+
+    gc.collect()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
